@@ -1,0 +1,209 @@
+#!/usr/bin/env python3
+"""bench.py — cells aggregated / s on drillUp(sum), MI355X.
+
+  python bench.py [--gpus N --steps K --warmup W]          (N > 1: launched by torch.distributed.run)
+
+A step is one drillUp(sum) of the outermost dimension over a device-resident Float32 measure
+(in-memory.js:265-334 through libolapgpu's C ABI):
+
+  N = 1   BASELINE.json's 10^8-cell cube, shape [10]*8, dim0 -> 'all'   (the configuration the
+          >= 70 % HBM-read target is quoted on; configs[1]'s 10^6-cell cube fits the Infinity Cache
+          and is reported beside it as `cache_resident_1e6`)
+  N > 1   the 10^9-cell family sharded on dim0, 40 rows per GPU: [40*N,5,5,5,5,5,5,10,20]
+          (1.25e8 cells per GPU, = configs[3]'s shard-friendly shape at N = 8); each rank reduces
+          its rows, one RCCL reduce-scatter over xGMI combines the partials.  Weak scaling.
+
+One JSON line on rank 0.  `value` = input cells of all ranks per second, buffers resident in HBM.
+`roofline` = algorithmic bytes (4 B read per input cell + 4 B value and 4 B status written per
+output cell) / the kernel's mean duration from HIP events on the launch stream.  `cpu_baseline` =
+the CPU oracle (oracle/olap_oracle.c, a single-thread C port of the reference loop) timed on this
+host on a bounded sample; a reported baseline, not a target.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def cpu_baseline(seconds_budget=12.0):
+    """Single-thread C port of the reference's drillUp loop on [10, 2*10^6] (2*10^7 cells)."""
+    from oracle.oracle import OracleStore
+
+    lens = [10, 2_000_000]
+    n = lens[0] * lens[1]
+    s = OracleStore(n, "float32", 0.0)
+    s.fill_seeded(20240807, 1.0)
+    maps = [np.zeros(10, np.uint32), np.arange(lens[1], dtype=np.uint32)]
+    reps, spent = 0, 0.0
+    while reps < 2 or (spent < seconds_budget and reps < 20):
+        t0 = time.perf_counter()
+        out = s.drill_up(lens, [1, lens[1]], maps, "sum")
+        spent += time.perf_counter() - t0
+        reps += 1
+        del out
+    return {"value": n * reps / spent, "unit": "cells/s", "cores": 1, "kind": "port",
+            "sample": "drillUp(sum) dim0 of a [10, 2000000] float32 cube (2e7 cells), %d repetitions, "
+                      "oracle/olap_oracle.c (Map-semantics C port of in-memory.js:265-334)" % reps}
+
+
+def read_traffic():
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/traffic_r*.json)."""
+    pdir = os.path.join(ROOT, "profiles")
+    best = None
+    if os.path.isdir(pdir):
+        for f in sorted(os.listdir(pdir)):
+            if f.startswith("traffic_r") and f.endswith(".json"):
+                best = os.path.join(pdir, f)
+    if not best:
+        return None
+    try:
+        with open(best) as fh:
+            return json.load(fh).get("hbm_bytes_per_launch")
+    except Exception:
+        return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    from __graft_entry__ import load_package
+
+    pkg = load_package()
+    from olap_in_memory_amd.sharded import HipEngine, ShardedStore
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d" % (args.gpus, args.gpus))
+        raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: libolapgpu has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    pkg.capi.check(pkg.lib().olap_set_device(local_rank))
+    if world > 1:
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    engine = HipEngine(torch.device("cuda", local_rank))
+
+    if world == 1:
+        lens = [10] * 8
+        workload = "drillUp(sum) dimension0->all, 8-dim 10^8-cell Float32 cube [10]*8, all cells set"
+    else:
+        lens = [40 * world, 5, 5, 5, 5, 5, 5, 10, 20]
+        workload = ("drillUp(sum) of the sharded dimension0->all, 9-dim cube [%d,5,5,5,5,5,5,10,20] "
+                    "(1.25e8 cells per GPU, %.3g cells), RCCL reduce-scatter of the partials" % (lens[0], float(np.prod(lens))))
+    store = ShardedStore(lens, "float32", 0.0, rank, world, engine).fill_seeded(20240807, 1.0)
+    op = store.plan_drillup_dim0(np.zeros(lens[0], np.uint32), 1, "sum")
+    torch.cuda.synchronize()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        op.step()
+    barrier()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(args.steps):
+        op.step()
+    ev1.record()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # kernel-only duration on the launch stream (HIP events), separately from the step loop
+    k0, k1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    k0.record()
+    for _ in range(args.steps):
+        op.local.run(store.values, None, op.partial, op.partial_status)
+    k1.record()
+    torch.cuda.synchronize()
+    kernel_ms = k0.elapsed_time(k1) / args.steps
+
+    local_cells = store.local_cells
+    total_cells = float(np.prod(lens))
+    n_out = op.n_out
+    alg_bytes = local_cells * 4 + n_out * 4 + n_out * 4
+    achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+
+    extra = {}
+    if world == 1:
+        # configs[1]: 10^6 cells, drillUp on axes 0 / 3 / 5 (resident in the 256 MiB Infinity Cache)
+        small = ShardedStore([10] * 6, "float32", 0.0, 0, 1, engine).fill_seeded(20240807, 1.0)
+        res = {}
+        for axis in (0, 3, 5):
+            lens6 = [10] * 6
+            new6 = list(lens6)
+            new6[axis] = 1
+            maps = [np.zeros(10, np.uint32) if i == axis else np.arange(10, dtype=np.uint32) for i in range(6)]
+            o = engine.make_drillup("float32", 0.0, "sum", lens6, new6, maps)
+            ov, os_ = engine.empty(10 ** 5, "float32"), engine.empty(10 ** 5, "int32")
+            for _ in range(20):
+                o.run(small.values, None, ov, os_)
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(200):
+                o.run(small.values, None, ov, os_)
+            b.record()
+            torch.cuda.synchronize()
+            us = a.elapsed_time(b) / 200 * 1e3
+            res["axis%d" % axis] = {"us_per_launch": round(us, 3), "cells_per_s": 1e6 / (us * 1e-6)}
+        extra["cache_resident_1e6"] = res
+
+    if rank == 0:
+        line = {
+            "metric": "cells aggregated/sec on drillUp(sum)",
+            "value": total_cells * args.steps / elapsed,
+            "unit": "cells/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32 cells, f64 accumulate",
+            "data": "synthetic (seeded mulberry32, values in [0.5,1.5), generated on device)",
+            "config": {"workload": workload, "shape": lens, "cells_per_gpu": local_cells,
+                       "kernel": op.local.plan.kernel_name, "collective": ("reduce_scatter" if op.scatter else "all_reduce") if world > 1 else "none"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": read_traffic() if world == 1 else None,
+                         "kernel_ms": kernel_ms, "algorithmic_bytes": alg_bytes,
+                         "hbm_read_frac": local_cells * 4 / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+        }
+        line.update(extra)
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

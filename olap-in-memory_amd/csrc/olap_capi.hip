@@ -1,0 +1,1137 @@
+// olap_capi.hip — host side of libolapgpu: argument validation, launch planning (folding the
+// per-dimension index maps of the reference's store methods into kernel views), the C ABI of
+// include/olap_hip.h and the store handles used by the Node.js addon.
+//
+// Reference interface being replaced: InMemoryStore, /root/reference/src/store/in-memory.js
+// (drillUp :265-334, drillDown :336-430, dice :213-263, reorder :178-211, load :139-176,
+// accessors :8-137).  There is no CPU fallback anywhere in this file.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "olap_kernels.hpp"
+
+using namespace olap;
+
+// ------------------------------------------------------------------ errors
+static thread_local std::string g_last_error;
+
+static int fail(int code, const char *fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_last_error = buf;
+  return code;
+}
+
+static int hip_fail(hipError_t e, const char *what) {
+  if (e == hipErrorOutOfMemory) return fail(OLAP_ERR_OUT_OF_MEMORY, "%s: %s", what, hipGetErrorString(e));
+  return fail(OLAP_ERR_HIP, "%s: %s", what, hipGetErrorString(e));
+}
+
+#define HIP_TRY(expr)                                  \
+  do {                                                 \
+    hipError_t e__ = (expr);                           \
+    if (e__ != hipSuccess) return hip_fail(e__, #expr); \
+  } while (0)
+
+extern "C" const char *olap_last_error(void) { return g_last_error.c_str(); }
+extern "C" int olap_abi_version(void) { return OLAP_ABI_VERSION; }
+
+extern "C" int olap_method_from_name(const char *name) {
+  if (!name) return OLAP_SUM;  // default parameter, in-memory.js:265
+  static const char *names[] = {"sum", "average", "highest", "lowest", "first", "last", "product"};
+  for (int i = 0; i < 7; ++i)
+    if (!strcmp(name, names[i])) return i;
+  return fail(OLAP_ERR_UNSUPPORTED_METHOD, "Unsupported aggregation method: %s", name);
+}
+
+extern "C" int olap_dtype_from_name(const char *name) {
+  static const char *names[] = {"int32", "uint32", "float32", "float64"};
+  if (name)
+    for (int i = 0; i < 4; ++i)
+      if (!strcmp(name, names[i])) return i;
+  return fail(OLAP_ERR_INVALID_TYPE, "Invalid type");
+}
+
+extern "C" size_t olap_dtype_size(int dtype) {
+  switch (dtype) {
+    case OLAP_INT32:
+    case OLAP_UINT32:
+    case OLAP_FLOAT32: return 4;
+    case OLAP_FLOAT64: return 8;
+    default: return 0;
+  }
+}
+
+static int check_dtype(int dtype) {
+  if (dtype < OLAP_INT32 || dtype > OLAP_FLOAT64) return fail(OLAP_ERR_INVALID_TYPE, "Invalid type");
+  return OLAP_OK;
+}
+static int check_default(int kind) {
+  if (kind != OLAP_DEFAULT_ZERO && kind != OLAP_DEFAULT_NAN)
+    return fail(OLAP_ERR_INVALID_DEFAULT, "Invalid default value, only NaN and 0 are supported");
+  return OLAP_OK;
+}
+
+// ------------------------------------------------------------------ device
+extern "C" int olap_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  return n;
+}
+
+static int require_device() {
+  static thread_local int ok = -1;
+  if (ok == 1) return OLAP_OK;
+  if (olap_device_count() <= 0)
+    return fail(OLAP_ERR_NO_DEVICE, "no HIP device available: libolapgpu has no CPU fallback");
+  ok = 1;
+  return OLAP_OK;
+}
+
+extern "C" int olap_set_device(int device) {
+  int n = olap_device_count();
+  if (n <= 0) return fail(OLAP_ERR_NO_DEVICE, "no HIP device available: libolapgpu has no CPU fallback");
+  if (device < 0 || device >= n) return fail(OLAP_ERR_INVALID_ARGUMENT, "device %d out of range [0, %d)", device, n);
+  HIP_TRY(hipSetDevice(device));
+  return OLAP_OK;
+}
+
+extern "C" int olap_device_synchronize(void) {
+  int rc = require_device();
+  if (rc) return rc;
+  HIP_TRY(hipDeviceSynchronize());
+  return OLAP_OK;
+}
+
+// ------------------------------------------------------------------ plans
+enum PlanKind { PLAN_DRILLUP_AXIS, PLAN_DRILLUP_GENERIC, PLAN_GATHER, PLAN_LOAD, PLAN_DRILLDOWN };
+
+struct olap_plan {
+  PlanKind kind;
+  int dtype = 0, def_nan = 0, his_def_nan = 0, method = 0;
+  uint64_t in_cells = 0, out_cells = 0;
+  int vec = 1;
+  DrillUpAxis axis{};
+  DrillUpGeneric gen{};
+  Remap remap{};
+  DrillDown dd{};
+  void *dev_tab = nullptr;                 // index tables
+  double *dev_dist = nullptr;              // drillDown distributions
+  unsigned long long *dev_err = nullptr;   // drillDown deferred error word
+  std::string kernel_name;
+  hipStream_t last_stream = nullptr;
+  bool ran = false;
+};
+
+static uint64_t product(const uint32_t *v, int n) {
+  uint64_t p = 1;
+  for (int i = 0; i < n; ++i) p *= v[i];
+  return p;
+}
+
+static int check_dims(int ndim, const uint32_t *a, const uint32_t *b) {
+  if (ndim < 0 || ndim > OLAP_MAX_DIMS) return fail(OLAP_ERR_INVALID_ARGUMENT, "ndim %d out of range [0, %d]", ndim, OLAP_MAX_DIMS);
+  if (ndim > 0 && (!a || !b)) return fail(OLAP_ERR_INVALID_ARGUMENT, "dimension length vectors must not be NULL");
+  // 2^40 cells (4 TiB of float32) is far beyond one device; it also keeps index math in range
+  long double pa = 1, pb = 1;
+  for (int d = 0; d < ndim; ++d) {
+    pa *= a[d];
+    pb *= b[d];
+  }
+  if (pa > 1.0e12L || pb > 1.0e12L) return fail(OLAP_ERR_INVALID_ARGUMENT, "cube too large");
+  return OLAP_OK;
+}
+
+static int upload(void **dev, const void *host, size_t bytes) {
+  *dev = nullptr;
+  if (bytes == 0) bytes = 16;
+  HIP_TRY(hipMalloc(dev, bytes));
+  if (host) HIP_TRY(hipMemcpy(*dev, host, bytes, hipMemcpyHostToDevice));
+  return OLAP_OK;
+}
+
+static int vec_for(int dtype, uint64_t contiguous) {
+  const int maxv = dtype == OLAP_FLOAT64 ? 2 : 4;  // 16 B per lane
+  for (int v = maxv; v > 1; v >>= 1)
+    if (contiguous % (uint64_t)v == 0) return v;
+  return 1;
+}
+
+extern "C" void olap_plan_destroy(olap_plan *p) {
+  if (!p) return;
+  if (p->dev_tab) (void)hipFree(p->dev_tab);
+  if (p->dev_dist) (void)hipFree(p->dev_dist);
+  if (p->dev_err) (void)hipFree(p->dev_err);
+  delete p;
+}
+
+extern "C" uint64_t olap_plan_in_cells(const olap_plan *p) { return p ? p->in_cells : 0; }
+extern "C" uint64_t olap_plan_out_cells(const olap_plan *p) { return p ? p->out_cells : 0; }
+extern "C" const char *olap_plan_kernel_name(const olap_plan *p) { return p ? p->kernel_name.c_str() : ""; }
+
+static bool is_identity_u32(const uint32_t *m, uint32_t old_len, uint32_t new_len) {
+  if (old_len != new_len) return false;
+  for (uint32_t k = 0; k < old_len; ++k)
+    if (m[k] != k) return false;
+  return true;
+}
+
+// ---- drillUp ------------------------------------------------------------------------------
+extern "C" int olap_drillup_plan(olap_plan **out, int dtype, int default_kind, int method, int ndim,
+                                 const uint32_t *old_len, const uint32_t *new_len,
+                                 const uint32_t *const *maps) {
+  if (!out) return fail(OLAP_ERR_INVALID_ARGUMENT, "plan out-pointer is NULL");
+  *out = nullptr;
+  int rc;
+  if ((rc = check_dtype(dtype)) || (rc = check_default(default_kind))) return rc;
+  if (method < OLAP_SUM || method > OLAP_PRODUCT)
+    return fail(OLAP_ERR_UNSUPPORTED_METHOD, "Unsupported aggregation method: %d", method);
+  if ((rc = check_dims(ndim, old_len, new_len))) return rc;
+  if (ndim > 0 && !maps) return fail(OLAP_ERR_INVALID_ARGUMENT, "maps is NULL");
+  std::vector<bool> ident(ndim);
+  int n_changed = 0, changed = -1;
+  for (int d = 0; d < ndim; ++d) {
+    if (old_len[d] && !maps[d]) return fail(OLAP_ERR_INVALID_ARGUMENT, "maps[%d] is NULL", d);
+    for (uint32_t k = 0; k < old_len[d]; ++k)
+      if (maps[d][k] >= new_len[d])
+        return fail(OLAP_ERR_INDEX_RANGE, "drillUp map of dimension %d: entry %u = %u is outside the new dimension (%u items)", d, k, maps[d][k], new_len[d]);
+    ident[d] = is_identity_u32(maps[d], old_len[d], new_len[d]);
+    if (!ident[d]) {
+      ++n_changed;
+      changed = d;
+    }
+  }
+  if ((rc = require_device())) return rc;
+
+  olap_plan *p = new (std::nothrow) olap_plan();
+  if (!p) return fail(OLAP_ERR_OUT_OF_MEMORY, "out of host memory");
+  p->dtype = dtype;
+  p->def_nan = default_kind == OLAP_DEFAULT_NAN;
+  p->method = method;
+  p->in_cells = product(old_len, ndim);
+  p->out_cells = product(new_len, ndim);
+
+  // CSR of a K->G map: members of each group in ascending order (counting sort, stable)
+  auto build_csr = [](const uint32_t *m, uint32_t K, uint32_t G, std::vector<uint32_t> &gstart, std::vector<uint32_t> &order) {
+    gstart.assign((size_t)G + 1, 0);
+    for (uint32_t k = 0; k < K; ++k) gstart[m[k] + 1]++;
+    for (uint32_t g = 0; g < G; ++g) gstart[g + 1] += gstart[g];
+    order.resize(K);
+    std::vector<uint32_t> cur(gstart.begin(), gstart.end() - 1);
+    for (uint32_t k = 0; k < K; ++k) order[cur[m[k]]++] = k;
+  };
+
+  if (n_changed <= 1) {
+    // One changed axis (or none: then the whole cube is a single untouched "axis" of length 1).
+    p->kind = PLAN_DRILLUP_AXIS;
+    DrillUpAxis &a = p->axis;
+    std::vector<uint32_t> gstart, order;
+    if (n_changed == 1) {
+      a.outer = product(old_len, changed);
+      a.K = old_len[changed];
+      a.G = new_len[changed];
+      a.inner = product(old_len + changed + 1, ndim - changed - 1);
+      build_csr(maps[changed], old_len[changed], new_len[changed], gstart, order);
+    } else {
+      a.outer = 1;
+      a.K = 1;
+      a.G = 1;
+      a.inner = p->in_cells;
+      gstart = {0, 1};
+      order = {0};
+    }
+    bool contiguous = true;
+    for (size_t j = 0; j < order.size(); ++j)
+      if (order[j] != j) contiguous = false;
+    p->vec = vec_for(dtype, a.inner);
+    a.def_nan = p->def_nan;
+    std::vector<uint32_t> tab(gstart);
+    const size_t order_off = tab.size();
+    if (!contiguous) tab.insert(tab.end(), order.begin(), order.end());
+    if ((rc = upload(&p->dev_tab, tab.data(), tab.size() * sizeof(uint32_t)))) {
+      olap_plan_destroy(p);
+      return rc;
+    }
+    a.gstart = (const uint32_t *)p->dev_tab;
+    a.order = contiguous ? nullptr : (const uint32_t *)p->dev_tab + order_off;
+    p->kernel_name = "drillup_direct";
+  } else {
+    p->kind = PLAN_DRILLUP_GENERIC;
+    DrillUpGeneric &g = p->gen;
+    std::vector<uint32_t> tab;
+    std::vector<uint64_t> old_stride(ndim);
+    {
+      uint64_t s = 1;
+      for (int d = ndim - 1; d >= 0; --d) {
+        old_stride[d] = s;
+        s *= old_len[d];
+      }
+    }
+    int nd = 0;
+    for (int d = 0; d < ndim; ++d) {
+      if (ident[d] && nd > 0 && g.csr[nd - 1] < 0 && ident[d - 1]) {
+        // merge with the previous identity dim
+        g.new_len[nd - 1] *= new_len[d];
+        g.old_stride[nd - 1] = old_stride[d];
+        continue;
+      }
+      if (nd == kMaxDims) {
+        olap_plan_destroy(p);
+        return fail(OLAP_ERR_INVALID_ARGUMENT, "drillUp: more than %d non-mergeable dimensions", kMaxDims);
+      }
+      g.new_len[nd] = new_len[d];
+      g.old_stride[nd] = old_stride[d];
+      if (ident[d]) {
+        g.csr[nd] = -1;
+        g.ord[nd] = -1;
+      } else {
+        std::vector<uint32_t> gstart, order;
+        build_csr(maps[d], old_len[d], new_len[d], gstart, order);
+        const uint32_t ord_base = (uint32_t)(tab.size() + gstart.size());
+        g.csr[nd] = (int32_t)tab.size();
+        g.ord[nd] = 0;  // gstart entries index straight into `tab` (absolute)
+        for (auto &x : gstart) x += ord_base;
+        tab.insert(tab.end(), gstart.begin(), gstart.end());
+        tab.insert(tab.end(), order.begin(), order.end());
+      }
+      ++nd;
+    }
+    g.nd = nd;
+    g.total = p->out_cells;
+    g.def_nan = p->def_nan;
+    if ((rc = upload(&p->dev_tab, tab.data(), tab.size() * sizeof(uint32_t)))) {
+      olap_plan_destroy(p);
+      return rc;
+    }
+    g.tab = (const uint32_t *)p->dev_tab;
+    p->kernel_name = "drillup_generic";
+  }
+  *out = p;
+  return OLAP_OK;
+}
+
+// ---- shared: build a Remap over destination dims -------------------------------------------
+struct RemapDim {
+  uint32_t len;
+  bool arithmetic;
+  uint64_t stride;              // arithmetic dims
+  std::vector<int64_t> table;   // table dims: offset or -1
+};
+
+static int finish_remap(olap_plan *p, std::vector<RemapDim> &dims, uint64_t iter_cells, bool allow_vec) {
+  // merge adjacent arithmetic dims whose strides nest (outer.stride == inner.stride * inner.len)
+  std::vector<RemapDim> m;
+  for (auto &d : dims) {
+    if (!m.empty() && m.back().arithmetic && d.arithmetic && m.back().stride == d.stride * d.len &&
+        (uint64_t)m.back().len * d.len <= 0xFFFFFFFFull) {
+      m.back().len *= d.len;
+      m.back().stride = d.stride;
+    } else {
+      m.push_back(d);
+    }
+  }
+  if ((int)m.size() > kMaxDims) return fail(OLAP_ERR_INVALID_ARGUMENT, "more than %d non-mergeable dimensions", kMaxDims);
+  Remap &r = p->remap;
+  std::vector<int64_t> tab;
+  r.nd = (int)m.size();
+  for (int d = 0; d < r.nd; ++d) {
+    r.len[d] = m[d].len;
+    r.stride[d] = m[d].stride;
+    if (m[d].arithmetic) {
+      r.tab_off[d] = -1;
+    } else {
+      r.tab_off[d] = (int32_t)tab.size();
+      tab.insert(tab.end(), m[d].table.begin(), m[d].table.end());
+    }
+  }
+  p->vec = 1;
+  if (allow_vec && r.nd > 0 && m.back().arithmetic && m.back().stride == 1) p->vec = vec_for(p->dtype, m.back().len);
+  if (r.nd == 0) p->vec = 1;
+  r.total = iter_cells / (uint64_t)p->vec;
+  r.def_nan = p->def_nan;
+  r.src_def_nan = p->his_def_nan;
+  int rc = upload(&p->dev_tab, tab.data(), tab.size() * sizeof(int64_t));
+  if (rc) return rc;
+  r.tab = (const int64_t *)p->dev_tab;
+  return OLAP_OK;
+}
+
+// ---- dice -----------------------------------------------------------------------------------
+extern "C" int olap_dice_plan(olap_plan **out, int dtype, int default_kind, int ndim,
+                              const uint32_t *old_len, const uint32_t *new_len,
+                              const int32_t *const *sel) {
+  if (!out) return fail(OLAP_ERR_INVALID_ARGUMENT, "plan out-pointer is NULL");
+  *out = nullptr;
+  int rc;
+  if ((rc = check_dtype(dtype)) || (rc = check_default(default_kind))) return rc;
+  if ((rc = check_dims(ndim, old_len, new_len))) return rc;
+  if (ndim > 0 && !sel) return fail(OLAP_ERR_INVALID_ARGUMENT, "sel is NULL");
+  for (int d = 0; d < ndim; ++d) {
+    if (new_len[d] && !sel[d]) return fail(OLAP_ERR_INVALID_ARGUMENT, "sel[%d] is NULL", d);
+    for (uint32_t j = 0; j < new_len[d]; ++j)
+      if (sel[d][j] >= 0 && (uint32_t)sel[d][j] >= old_len[d])
+        return fail(OLAP_ERR_INDEX_RANGE, "dice selection of dimension %d: entry %u = %d is outside the old dimension (%u items)", d, j, sel[d][j], old_len[d]);
+  }
+  if ((rc = require_device())) return rc;
+  olap_plan *p = new (std::nothrow) olap_plan();
+  if (!p) return fail(OLAP_ERR_OUT_OF_MEMORY, "out of host memory");
+  p->kind = PLAN_GATHER;
+  p->dtype = dtype;
+  p->def_nan = default_kind == OLAP_DEFAULT_NAN;
+  p->in_cells = product(old_len, ndim);
+  p->out_cells = product(new_len, ndim);
+  std::vector<RemapDim> dims(ndim);
+  uint64_t stride = 1;
+  for (int d = ndim - 1; d >= 0; --d) {
+    RemapDim &rd = dims[d];
+    rd.len = new_len[d];
+    rd.stride = stride;
+    bool ident = old_len[d] == new_len[d];
+    for (uint32_t j = 0; ident && j < new_len[d]; ++j) ident = sel[d][j] == (int32_t)j;
+    rd.arithmetic = ident;
+    if (!ident) {
+      // Map(oldIdx -> newIdx) built left to right (in-memory.js:219-224): of two new items naming
+      // the same old item only the LAST receives the cells
+      rd.table.assign(new_len[d], -1);
+      std::vector<int64_t> last(old_len[d] ? old_len[d] : 1, -1);
+      for (uint32_t j = 0; j < new_len[d]; ++j)
+        if (sel[d][j] >= 0) last[sel[d][j]] = j;
+      for (uint32_t j = 0; j < new_len[d]; ++j)
+        if (sel[d][j] >= 0 && last[sel[d][j]] == (int64_t)j) rd.table[j] = (int64_t)sel[d][j] * (int64_t)stride;
+    }
+    stride *= old_len[d];
+  }
+  if ((rc = finish_remap(p, dims, p->out_cells, true))) {
+    olap_plan_destroy(p);
+    return rc;
+  }
+  p->kernel_name = "gather(dice)";
+  *out = p;
+  return OLAP_OK;
+}
+
+// ---- reorder --------------------------------------------------------------------------------
+extern "C" int olap_reorder_plan(olap_plan **out, int dtype, int default_kind, int ndim,
+                                 const uint32_t *old_len, const int32_t *perm) {
+  if (!out) return fail(OLAP_ERR_INVALID_ARGUMENT, "plan out-pointer is NULL");
+  *out = nullptr;
+  int rc;
+  if ((rc = check_dtype(dtype)) || (rc = check_default(default_kind))) return rc;
+  if ((rc = check_dims(ndim, old_len, old_len))) return rc;
+  if (ndim > 0 && !perm) return fail(OLAP_ERR_INVALID_ARGUMENT, "perm is NULL");
+  std::vector<bool> seen(ndim, false);
+  for (int d = 0; d < ndim; ++d) {
+    if (perm[d] < 0 || perm[d] >= ndim || seen[perm[d]])
+      return fail(OLAP_ERR_INVALID_ARGUMENT, "reorder: perm is not a permutation of the dimensions");
+    seen[perm[d]] = true;
+  }
+  if ((rc = require_device())) return rc;
+  olap_plan *p = new (std::nothrow) olap_plan();
+  if (!p) return fail(OLAP_ERR_OUT_OF_MEMORY, "out of host memory");
+  p->kind = PLAN_GATHER;
+  p->dtype = dtype;
+  p->def_nan = default_kind == OLAP_DEFAULT_NAN;
+  p->in_cells = p->out_cells = product(old_len, ndim);
+  std::vector<uint64_t> old_stride(ndim);
+  uint64_t s = 1;
+  for (int d = ndim - 1; d >= 0; --d) {
+    old_stride[d] = s;
+    s *= old_len[d];
+  }
+  std::vector<RemapDim> dims(ndim);
+  for (int d = 0; d < ndim; ++d) {
+    dims[d].len = old_len[perm[d]];
+    dims[d].arithmetic = true;
+    dims[d].stride = old_stride[perm[d]];
+  }
+  if ((rc = finish_remap(p, dims, p->out_cells, true))) {
+    olap_plan_destroy(p);
+    return rc;
+  }
+  p->kernel_name = "gather(reorder)";
+  *out = p;
+  return OLAP_OK;
+}
+
+// ---- load -----------------------------------------------------------------------------------
+extern "C" int olap_load_plan(olap_plan **out, int dtype, int my_default_kind, int his_default_kind,
+                              int ndim, const uint32_t *my_len, const uint32_t *his_len,
+                              const int32_t *const *his_to_mine) {
+  if (!out) return fail(OLAP_ERR_INVALID_ARGUMENT, "plan out-pointer is NULL");
+  *out = nullptr;
+  int rc;
+  if ((rc = check_dtype(dtype)) || (rc = check_default(my_default_kind)) || (rc = check_default(his_default_kind))) return rc;
+  if ((rc = check_dims(ndim, my_len, his_len))) return rc;
+  if (ndim > 0 && !his_to_mine) return fail(OLAP_ERR_INVALID_ARGUMENT, "his_to_mine is NULL");
+  for (int d = 0; d < ndim; ++d) {
+    if (his_len[d] && !his_to_mine[d]) return fail(OLAP_ERR_INVALID_ARGUMENT, "his_to_mine[%d] is NULL", d);
+    for (uint32_t j = 0; j < his_len[d]; ++j)
+      if (his_to_mine[d][j] >= 0 && (uint32_t)his_to_mine[d][j] >= my_len[d])
+        return fail(OLAP_ERR_INDEX_RANGE, "load map of dimension %d: entry %u = %d is outside this store's dimension (%u items)", d, j, his_to_mine[d][j], my_len[d]);
+  }
+  if ((rc = require_device())) return rc;
+  olap_plan *p = new (std::nothrow) olap_plan();
+  if (!p) return fail(OLAP_ERR_OUT_OF_MEMORY, "out of host memory");
+  p->kind = PLAN_LOAD;
+  p->dtype = dtype;
+  p->def_nan = my_default_kind == OLAP_DEFAULT_NAN;
+  p->his_def_nan = his_default_kind == OLAP_DEFAULT_NAN;
+  p->in_cells = product(his_len, ndim);
+  p->out_cells = product(my_len, ndim);
+  std::vector<RemapDim> dims(ndim);
+  uint64_t stride = 1;
+  for (int d = ndim - 1; d >= 0; --d) {
+    RemapDim &rd = dims[d];
+    rd.len = his_len[d];
+    rd.stride = stride;
+    bool ident = his_len[d] == my_len[d];
+    for (uint32_t j = 0; ident && j < his_len[d]; ++j) ident = his_to_mine[d][j] == (int32_t)j;
+    rd.arithmetic = ident;
+    if (!ident) {
+      rd.table.resize(his_len[d]);
+      for (uint32_t j = 0; j < his_len[d]; ++j)
+        rd.table[j] = his_to_mine[d][j] < 0 ? -1 : (int64_t)his_to_mine[d][j] * (int64_t)stride;
+    }
+    stride *= my_len[d];
+  }
+  if ((rc = finish_remap(p, dims, p->in_cells, false))) {
+    olap_plan_destroy(p);
+    return rc;
+  }
+  p->kernel_name = "load_scatter";
+  *out = p;
+  return OLAP_OK;
+}
+
+// ---- drillDown ------------------------------------------------------------------------------
+extern "C" int olap_drilldown_plan(olap_plan **out, int dtype, int default_kind, int method, int ndim,
+                                   const uint32_t *old_len, const uint32_t *new_len,
+                                   const uint32_t *const *maps, const double *distributions,
+                                   uint64_t n_dist) {
+  if (!out) return fail(OLAP_ERR_INVALID_ARGUMENT, "plan out-pointer is NULL");
+  *out = nullptr;
+  int rc;
+  if ((rc = check_dtype(dtype)) || (rc = check_default(default_kind))) return rc;
+  if ((rc = check_dims(ndim, old_len, new_len))) return rc;
+  if (ndim > 0 && !maps) return fail(OLAP_ERR_INVALID_ARGUMENT, "maps is NULL");
+  for (int d = 0; d < ndim; ++d) {
+    if (new_len[d] && !maps[d]) return fail(OLAP_ERR_INVALID_ARGUMENT, "maps[%d] is NULL", d);
+    for (uint32_t j = 0; j < new_len[d]; ++j)
+      if (maps[d][j] >= old_len[d])
+        return fail(OLAP_ERR_INDEX_RANGE, "drillDown map of dimension %d: entry %u = %u is outside the old dimension (%u items)", d, j, maps[d][j], old_len[d]);
+  }
+  if ((rc = require_device())) return rc;
+  olap_plan *p = new (std::nothrow) olap_plan();
+  if (!p) return fail(OLAP_ERR_OUT_OF_MEMORY, "out of host memory");
+  p->kind = PLAN_DRILLDOWN;
+  p->dtype = dtype;
+  p->def_nan = default_kind == OLAP_DEFAULT_NAN;
+  p->method = method;
+  p->in_cells = product(old_len, ndim);
+  p->out_cells = product(new_len, ndim);
+  DrillDown &a = p->dd;
+  std::vector<uint32_t> tab;
+  std::vector<uint64_t> old_stride(ndim);
+  {
+    uint64_t s = 1;
+    for (int d = ndim - 1; d >= 0; --d) {
+      old_stride[d] = s;
+      s *= old_len[d];
+    }
+  }
+  int nd = 0;
+  bool prev_ident = false;
+  for (int d = 0; d < ndim; ++d) {
+    const bool ident = is_identity_u32(maps[d], new_len[d], old_len[d]);
+    if (ident && prev_ident && (uint64_t)a.new_len[nd - 1] * new_len[d] <= 0xFFFFFFFFull) {
+      a.new_len[nd - 1] *= new_len[d];
+      a.old_stride[nd - 1] = old_stride[d];
+      continue;
+    }
+    if (nd == kMaxDims) {
+      olap_plan_destroy(p);
+      return fail(OLAP_ERR_INVALID_ARGUMENT, "drillDown: more than %d non-mergeable dimensions", kMaxDims);
+    }
+    a.new_len[nd] = new_len[d];
+    a.old_stride[nd] = old_stride[d];
+    if (ident) {
+      a.tab_off[nd] = -1;
+    } else {
+      const uint32_t L = new_len[d];
+      a.tab_off[nd] = (int32_t)tab.size();
+      std::vector<uint32_t> count(old_len[d] ? old_len[d] : 1, 0), rank(L);
+      for (uint32_t j = 0; j < L; ++j) rank[j] = count[maps[d][j]]++;
+      for (uint32_t j = 0; j < L; ++j) tab.push_back(maps[d][j]);
+      for (uint32_t j = 0; j < L; ++j) tab.push_back(count[maps[d][j]]);
+      for (uint32_t j = 0; j < L; ++j) tab.push_back(rank[j]);
+    }
+    prev_ident = ident;
+    ++nd;
+  }
+  a.nd = nd;
+  a.total = p->out_cells;
+  a.def_nan = p->def_nan;
+  a.method = method;
+  a.use_rounding = (dtype == OLAP_INT32 || dtype == OLAP_UINT32);  // in-memory.js:343
+  a.dist = nullptr;
+  a.n_dist = 0;
+  if ((rc = upload(&p->dev_tab, tab.data(), tab.size() * sizeof(uint32_t)))) {
+    olap_plan_destroy(p);
+    return rc;
+  }
+  a.tab = (const uint32_t *)p->dev_tab;
+  if (distributions) {
+    void *dv = nullptr;
+    if ((rc = upload(&dv, distributions, n_dist * sizeof(double)))) {
+      olap_plan_destroy(p);
+      return rc;
+    }
+    p->dev_dist = (double *)dv;
+    a.dist = p->dev_dist;
+    a.n_dist = n_dist;
+    a.added_len = (double)p->out_cells / (double)p->in_cells;  // :392
+    const double shared = (double)n_dist / a.added_len;        // :393
+    a.chunk = (double)p->out_cells / shared;                   // :395
+  }
+  {
+    void *ev = nullptr;
+    const unsigned long long init = ~0ull;
+    if ((rc = upload(&ev, &init, sizeof(init)))) {
+      olap_plan_destroy(p);
+      return rc;
+    }
+    p->dev_err = (unsigned long long *)ev;
+    a.err = p->dev_err;
+  }
+  p->kernel_name = "drilldown";
+  *out = p;
+  return OLAP_OK;
+}
+
+// ---- run ------------------------------------------------------------------------------------
+static bool aligned16(const void *p) { return ((uintptr_t)p & 15u) == 0; }
+
+template <typename T>
+static int run_typed(olap_plan *p, const void *in_v, const int32_t *in_s, void *out_v, int32_t *out_s,
+                     hipStream_t stream) {
+  const T *in = (const T *)in_v;
+  T *out = (T *)out_v;
+  const bool hs = in_s != nullptr;
+  hipError_t e = hipSuccess;
+  switch (p->kind) {
+    case PLAN_DRILLUP_AXIS: {
+      DrillUpAxis a = p->axis;
+      int vec = p->vec;
+      if (!(aligned16(in) && aligned16(out) && (!in_s || aligned16(in_s)) && (!out_s || aligned16(out_s)))) vec = 1;
+      a.n_vec = a.inner / (uint64_t)vec;
+      a.total = a.outer * a.G * a.n_vec;
+      e = Launch<T>::drillup_axis(p->method, hs, vec, in, in_s, out, out_s, a, stream);
+      break;
+    }
+    case PLAN_DRILLUP_GENERIC:
+      e = Launch<T>::drillup_generic(p->method, hs, in, in_s, out, out_s, p->gen, stream);
+      break;
+    case PLAN_GATHER: {
+      Remap r = p->remap;
+      int vec = p->vec;
+      if (vec > 1 && !(aligned16(in) && aligned16(out) && (!in_s || aligned16(in_s)) && (!out_s || aligned16(out_s)))) {
+        r.total *= (uint64_t)vec;
+        vec = 1;
+      }
+      e = Launch<T>::gather(hs, vec, in, in_s, out, out_s, r, stream);
+      break;
+    }
+    case PLAN_LOAD:
+      e = Launch<T>::load_scatter(hs, in, in_s, out, out_s, p->remap, stream);
+      break;
+    case PLAN_DRILLDOWN: {
+      const unsigned long long init = ~0ull;
+      e = hipMemcpyAsync(p->dev_err, &init, sizeof(init), hipMemcpyHostToDevice, stream);
+      if (e == hipSuccess) e = Launch<T>::drilldown(hs, in, in_s, out, out_s, p->dd, stream);
+      break;
+    }
+  }
+  if (e != hipSuccess) return hip_fail(e, p->kernel_name.c_str());
+  return OLAP_OK;
+}
+
+extern "C" int olap_plan_run(olap_plan *p, const void *in_values, const int32_t *in_status,
+                             void *out_values, int32_t *out_status, void *stream) {
+  if (!p) return fail(OLAP_ERR_INVALID_ARGUMENT, "plan is NULL");
+  if ((p->in_cells && !in_values) || (p->out_cells && !out_values))
+    return fail(OLAP_ERR_INVALID_ARGUMENT, "values pointers must not be NULL");
+  hipStream_t s = (hipStream_t)stream;
+  p->last_stream = s;
+  p->ran = true;
+  switch (p->dtype) {
+    case OLAP_INT32: return run_typed<int32_t>(p, in_values, in_status, out_values, out_status, s);
+    case OLAP_UINT32: return run_typed<uint32_t>(p, in_values, in_status, out_values, out_status, s);
+    case OLAP_FLOAT32: return run_typed<float>(p, in_values, in_status, out_values, out_status, s);
+    default: return run_typed<double>(p, in_values, in_status, out_values, out_status, s);
+  }
+}
+
+extern "C" int olap_plan_status(olap_plan *p) {
+  if (!p) return fail(OLAP_ERR_INVALID_ARGUMENT, "plan is NULL");
+  if (p->kind != PLAN_DRILLDOWN || !p->dd.dist || !p->ran) return OLAP_OK;
+  unsigned long long bad = ~0ull;
+  HIP_TRY(hipMemcpy(&bad, p->dev_err, sizeof(bad), hipMemcpyDeviceToHost));
+  if (bad == ~0ull) return OLAP_OK;
+  const DrillDown &a = p->dd;
+  const double di = std::floor((double)bad / a.chunk) * a.added_len + std::fmod((double)bad, a.added_len);
+  // JS prints an integral double without a fraction
+  if (di == std::floor(di) && std::fabs(di) < 1e15) return fail(OLAP_ERR_DISTRIBUTION_MISSING, "distribution missing for index %lld", (long long)di);
+  return fail(OLAP_ERR_DISTRIBUTION_MISSING, "distribution missing for index %.17g", di);
+}
+
+// ------------------------------------------------------------------ element-wise helpers
+#define DISPATCH_DTYPE(dtype, CALL)                      \
+  switch (dtype) {                                       \
+    case OLAP_INT32: { using T = int32_t; CALL; break; } \
+    case OLAP_UINT32: { using T = uint32_t; CALL; break; } \
+    case OLAP_FLOAT32: { using T = float; CALL; break; }  \
+    default: { using T = double; CALL; break; }           \
+  }
+
+extern "C" int olap_canonicalize(void *values, int32_t *status, uint64_t n, int dtype, int default_kind,
+                                 int use_existing_status, void *stream) {
+  int rc;
+  if ((rc = check_dtype(dtype)) || (rc = check_default(default_kind))) return rc;
+  if (n && !values) return fail(OLAP_ERR_INVALID_ARGUMENT, "values is NULL");
+  if (use_existing_status && !status) return fail(OLAP_ERR_INVALID_ARGUMENT, "use_existing_status needs a status buffer");
+  if ((rc = require_device())) return rc;
+  hipError_t e = hipSuccess;
+  DISPATCH_DTYPE(dtype, e = Launch<T>::canonicalize((T *)values, status, n, default_kind == OLAP_DEFAULT_NAN, use_existing_status, (hipStream_t)stream));
+  if (e != hipSuccess) return hip_fail(e, "canonicalize");
+  return OLAP_OK;
+}
+
+extern "C" int olap_convert_from_f64(const double *src, void *values, int32_t *status, uint64_t n, int dtype,
+                                     int default_kind, void *stream) {
+  int rc;
+  if ((rc = check_dtype(dtype)) || (rc = check_default(default_kind))) return rc;
+  if (n && (!values || !src)) return fail(OLAP_ERR_INVALID_ARGUMENT, "src/values is NULL");
+  if ((rc = require_device())) return rc;
+  hipError_t e = hipSuccess;
+  DISPATCH_DTYPE(dtype, e = Launch<T>::from_f64(src, (T *)values, status, n, default_kind == OLAP_DEFAULT_NAN, (hipStream_t)stream));
+  if (e != hipSuccess) return hip_fail(e, "convert_from_f64");
+  return OLAP_OK;
+}
+
+extern "C" int olap_convert_to_f64(const void *values, double *dst, uint64_t n, int dtype, void *stream) {
+  int rc;
+  if ((rc = check_dtype(dtype))) return rc;
+  if (n && (!values || !dst)) return fail(OLAP_ERR_INVALID_ARGUMENT, "values/dst is NULL");
+  if ((rc = require_device())) return rc;
+  hipError_t e = hipSuccess;
+  DISPATCH_DTYPE(dtype, e = Launch<T>::to_f64((const T *)values, dst, n, (hipStream_t)stream));
+  if (e != hipSuccess) return hip_fail(e, "convert_to_f64");
+  return OLAP_OK;
+}
+
+extern "C" int olap_fill_seeded(void *values, int32_t *status, uint64_t n, uint64_t first_cell, int dtype,
+                                uint32_t seed, double frac, void *stream) {
+  int rc;
+  if ((rc = check_dtype(dtype))) return rc;
+  if (n && !values) return fail(OLAP_ERR_INVALID_ARGUMENT, "values is NULL");
+  if ((rc = require_device())) return rc;
+  hipError_t e = hipSuccess;
+  DISPATCH_DTYPE(dtype, e = Launch<T>::fill_seeded((T *)values, status, n, first_cell, seed, frac, (hipStream_t)stream));
+  if (e != hipSuccess) return hip_fail(e, "fill_seeded");
+  return OLAP_OK;
+}
+
+extern "C" int olap_total(const void *values, const int32_t *status, uint64_t n, int dtype, int default_kind,
+                          double *total, uint64_t *n_set, void *stream) {
+  int rc;
+  if ((rc = check_dtype(dtype)) || (rc = check_default(default_kind))) return rc;
+  if (n && !values) return fail(OLAP_ERR_INVALID_ARGUMENT, "values is NULL");
+  if ((rc = require_device())) return rc;
+  struct Acc {
+    double total;
+    unsigned long long count;
+  } host = {0.0, 0};
+  Acc *dev = nullptr;
+  HIP_TRY(hipMalloc((void **)&dev, sizeof(Acc)));
+  hipError_t e = hipMemcpyAsync(dev, &host, sizeof(host), hipMemcpyHostToDevice, (hipStream_t)stream);
+  if (e == hipSuccess) {
+    DISPATCH_DTYPE(dtype, e = Launch<T>::total((const T *)values, status, n, default_kind == OLAP_DEFAULT_NAN, &dev->total, &dev->count, (hipStream_t)stream));
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
+  if (e == hipSuccess) e = hipMemcpy(&host, dev, sizeof(host), hipMemcpyDeviceToHost);
+  (void)hipFree(dev);
+  if (e != hipSuccess) return hip_fail(e, "total");
+  if (total) *total = host.total;
+  if (n_set) *n_set = host.count;
+  return OLAP_OK;
+}
+
+// ------------------------------------------------------------------ store handles
+struct olap_store {
+  uint64_t size;
+  int dtype;
+  int default_kind;
+  void *values;
+  int32_t *status;
+};
+
+static int store_alloc(olap_store **out, uint64_t size, int dtype, int default_kind) {
+  olap_store *s = new (std::nothrow) olap_store();
+  if (!s) return fail(OLAP_ERR_OUT_OF_MEMORY, "out of host memory");
+  s->size = size;
+  s->dtype = dtype;
+  s->default_kind = default_kind;
+  s->values = nullptr;
+  s->status = nullptr;
+  const size_t vb = (size ? size : 1) * olap_dtype_size(dtype), sb = (size ? size : 1) * sizeof(int32_t);
+  hipError_t e = hipMalloc(&s->values, vb);
+  if (e == hipSuccess) e = hipMalloc((void **)&s->status, sb);
+  if (e != hipSuccess) {
+    if (s->values) (void)hipFree(s->values);
+    delete s;
+    return hip_fail(e, "hipMalloc(store)");
+  }
+  *out = s;
+  return OLAP_OK;
+}
+
+// every cell unset: status 0, values = default
+static int store_clear(olap_store *s) {
+  HIP_TRY(hipMemsetAsync(s->status, 0, (s->size ? s->size : 1) * sizeof(int32_t), nullptr));
+  const bool fnan = s->default_kind == OLAP_DEFAULT_NAN && (s->dtype == OLAP_FLOAT32 || s->dtype == OLAP_FLOAT64);
+  if (!fnan) {
+    HIP_TRY(hipMemsetAsync(s->values, 0, (s->size ? s->size : 1) * olap_dtype_size(s->dtype), nullptr));
+  } else {
+    // canonicalize with an all-zero mask writes the NaN default everywhere
+    hipError_t e = hipSuccess;
+    DISPATCH_DTYPE(s->dtype, e = Launch<T>::canonicalize((T *)s->values, s->status, s->size, 1, 1, nullptr));
+    if (e != hipSuccess) return hip_fail(e, "store_clear");
+  }
+  HIP_TRY(hipStreamSynchronize(nullptr));
+  return OLAP_OK;
+}
+
+extern "C" int olap_store_create(olap_store **store, uint64_t size, int dtype, int default_kind) {
+  if (!store) return fail(OLAP_ERR_INVALID_ARGUMENT, "store out-pointer is NULL");
+  *store = nullptr;
+  int rc;
+  if ((rc = check_default(default_kind)) || (rc = check_dtype(dtype))) return rc;  // same order as in-memory.js:56-60
+  if (size > 1000000000000ull) return fail(OLAP_ERR_INVALID_ARGUMENT, "cube too large");
+  if ((rc = require_device())) return rc;
+  olap_store *s = nullptr;
+  if ((rc = store_alloc(&s, size, dtype, default_kind))) return rc;
+  if ((rc = store_clear(s))) {
+    olap_store_destroy(s);
+    return rc;
+  }
+  *store = s;
+  return OLAP_OK;
+}
+
+extern "C" void olap_store_destroy(olap_store *s) {
+  if (!s) return;
+  if (s->values) (void)hipFree(s->values);
+  if (s->status) (void)hipFree(s->status);
+  delete s;
+}
+
+extern "C" int olap_store_clone(const olap_store *s, olap_store **out) {
+  if (!s || !out) return fail(OLAP_ERR_INVALID_ARGUMENT, "store is NULL");
+  *out = nullptr;
+  olap_store *c = nullptr;
+  int rc = store_alloc(&c, s->size, s->dtype, s->default_kind);
+  if (rc) return rc;
+  hipError_t e = hipMemcpy(c->values, s->values, s->size * olap_dtype_size(s->dtype), hipMemcpyDeviceToDevice);
+  if (e == hipSuccess) e = hipMemcpy(c->status, s->status, s->size * sizeof(int32_t), hipMemcpyDeviceToDevice);
+  if (e != hipSuccess) {
+    olap_store_destroy(c);
+    return hip_fail(e, "store_clone");
+  }
+  *out = c;
+  return OLAP_OK;
+}
+
+extern "C" uint64_t olap_store_size(const olap_store *s) { return s ? s->size : 0; }
+extern "C" int olap_store_dtype(const olap_store *s) { return s ? s->dtype : -1; }
+extern "C" int olap_store_default(const olap_store *s) { return s ? s->default_kind : -1; }
+extern "C" uint64_t olap_store_byte_length(const olap_store *s) { return s ? s->size * olap_dtype_size(s->dtype) : 0; }
+extern "C" void *olap_store_values_ptr(const olap_store *s) { return s ? s->values : nullptr; }
+extern "C" int32_t *olap_store_status_ptr(const olap_store *s) { return s ? s->status : nullptr; }
+
+static int check_length(const olap_store *s, uint64_t n) {
+  if (!s) return fail(OLAP_ERR_INVALID_ARGUMENT, "store is NULL");
+  if (s->size != n)
+    return fail(OLAP_ERR_LENGTH_MISMATCH, "value length is invalid: %llu !== %llu", (unsigned long long)s->size, (unsigned long long)n);
+  return OLAP_OK;
+}
+
+extern "C" int olap_store_set_data(olap_store *s, const void *host_values, uint64_t n) {
+  int rc = check_length(s, n);
+  if (rc) return rc;
+  if (n && !host_values) return fail(OLAP_ERR_INVALID_ARGUMENT, "values is NULL");
+  if (n == 0) return OLAP_OK;
+  HIP_TRY(hipMemcpy(s->values, host_values, n * olap_dtype_size(s->dtype), hipMemcpyHostToDevice));
+  if ((rc = olap_canonicalize(s->values, s->status, n, s->dtype, s->default_kind, 0, nullptr))) return rc;
+  HIP_TRY(hipStreamSynchronize(nullptr));
+  return OLAP_OK;
+}
+
+extern "C" int olap_store_set_data_f64(olap_store *s, const double *host_values, uint64_t n) {
+  int rc = check_length(s, n);
+  if (rc) return rc;
+  if (n && !host_values) return fail(OLAP_ERR_INVALID_ARGUMENT, "values is NULL");
+  if (n == 0) return OLAP_OK;
+  double *tmp = nullptr;
+  HIP_TRY(hipMalloc((void **)&tmp, n * sizeof(double)));
+  hipError_t e = hipMemcpy(tmp, host_values, n * sizeof(double), hipMemcpyHostToDevice);
+  if (e == hipSuccess) {
+    rc = olap_convert_from_f64(tmp, s->values, s->status, n, s->dtype, s->default_kind, nullptr);
+    if (!rc) e = hipStreamSynchronize(nullptr);
+  }
+  (void)hipFree(tmp);
+  if (rc) return rc;
+  if (e != hipSuccess) return hip_fail(e, "set_data_f64");
+  return OLAP_OK;
+}
+
+extern "C" int olap_store_get_data(const olap_store *s, void *host_values) {
+  if (!s || (s->size && !host_values)) return fail(OLAP_ERR_INVALID_ARGUMENT, "store/values is NULL");
+  if (s->size) HIP_TRY(hipMemcpy(host_values, s->values, s->size * olap_dtype_size(s->dtype), hipMemcpyDeviceToHost));
+  return OLAP_OK;
+}
+
+extern "C" int olap_store_get_data_f64(const olap_store *s, double *host_values) {
+  if (!s || (s->size && !host_values)) return fail(OLAP_ERR_INVALID_ARGUMENT, "store/values is NULL");
+  if (!s->size) return OLAP_OK;
+  if (s->dtype == OLAP_FLOAT64) return olap_store_get_data(s, host_values);
+  double *tmp = nullptr;
+  HIP_TRY(hipMalloc((void **)&tmp, s->size * sizeof(double)));
+  int rc = olap_convert_to_f64(s->values, tmp, s->size, s->dtype, nullptr);
+  hipError_t e = hipSuccess;
+  if (!rc) e = hipMemcpy(host_values, tmp, s->size * sizeof(double), hipMemcpyDeviceToHost);
+  (void)hipFree(tmp);
+  if (rc) return rc;
+  if (e != hipSuccess) return hip_fail(e, "get_data_f64");
+  // integer cells under a NaN default read back as NaN where unset, like getValue (:118-120)
+  if (s->default_kind == OLAP_DEFAULT_NAN && (s->dtype == OLAP_INT32 || s->dtype == OLAP_UINT32)) {
+    std::vector<int32_t> st(s->size);
+    HIP_TRY(hipMemcpy(st.data(), s->status, s->size * sizeof(int32_t), hipMemcpyDeviceToHost));
+    for (uint64_t i = 0; i < s->size; ++i)
+      if (!(st[i] & OLAP_STATUS_SET)) host_values[i] = NAN;
+  }
+  return OLAP_OK;
+}
+
+extern "C" int olap_store_get_status(const olap_store *s, int32_t *host_status) {
+  if (!s || (s->size && !host_status)) return fail(OLAP_ERR_INVALID_ARGUMENT, "store/status is NULL");
+  if (s->size) HIP_TRY(hipMemcpy(host_status, s->status, s->size * sizeof(int32_t), hipMemcpyDeviceToHost));
+  return OLAP_OK;
+}
+
+extern "C" int olap_store_count_set(const olap_store *s, uint64_t *n_set) {
+  if (!s || !n_set) return fail(OLAP_ERR_INVALID_ARGUMENT, "store is NULL");
+  return olap_total(s->values, s->status, s->size, s->dtype, s->default_kind, nullptr, n_set, nullptr);
+}
+
+extern "C" int olap_store_get_keys(const olap_store *s, uint64_t *host_keys, uint64_t cap, uint64_t *n_keys) {
+  if (!s || !n_keys) return fail(OLAP_ERR_INVALID_ARGUMENT, "store is NULL");
+  std::vector<int32_t> st(s->size ? s->size : 1);
+  if (s->size) HIP_TRY(hipMemcpy(st.data(), s->status, s->size * sizeof(int32_t), hipMemcpyDeviceToHost));
+  uint64_t n = 0;
+  for (uint64_t i = 0; i < s->size; ++i)
+    if (st[i] & OLAP_STATUS_SET) {
+      if (host_keys && n < cap) host_keys[n] = i;
+      ++n;
+    }
+  *n_keys = n;
+  return OLAP_OK;
+}
+
+extern "C" int olap_store_get_value(const olap_store *s, uint64_t index, double *value, int *is_set) {
+  if (!s) return fail(OLAP_ERR_INVALID_ARGUMENT, "store is NULL");
+  if (index >= s->size) {  // Map.get of an absent key: the default (:118-120)
+    if (value) *value = s->default_kind == OLAP_DEFAULT_NAN ? NAN : 0.0;
+    if (is_set) *is_set = 0;
+    return OLAP_OK;
+  }
+  int32_t st = 0;
+  HIP_TRY(hipMemcpy(&st, s->status + index, sizeof(st), hipMemcpyDeviceToHost));
+  double v = 0;
+  const size_t es = olap_dtype_size(s->dtype);
+  unsigned char raw[8];
+  HIP_TRY(hipMemcpy(raw, (const char *)s->values + index * es, es, hipMemcpyDeviceToHost));
+  switch (s->dtype) {
+    case OLAP_INT32: { int32_t x; memcpy(&x, raw, 4); v = x; break; }
+    case OLAP_UINT32: { uint32_t x; memcpy(&x, raw, 4); v = x; break; }
+    case OLAP_FLOAT32: { float x; memcpy(&x, raw, 4); v = x; break; }
+    default: memcpy(&v, raw, 8);
+  }
+  const bool set = (st & OLAP_STATUS_SET) != 0;
+  if (value) *value = set ? v : (s->default_kind == OLAP_DEFAULT_NAN ? NAN : 0.0);
+  if (is_set) *is_set = set;
+  return OLAP_OK;
+}
+
+extern "C" int olap_store_set_value(olap_store *s, uint64_t index, double value, int is_null) {
+  if (!s) return fail(OLAP_ERR_INVALID_ARGUMENT, "store is NULL");
+  if (index >= s->size) return fail(OLAP_ERR_INDEX_RANGE, "cell index %llu out of bounds [0, %llu[", (unsigned long long)index, (unsigned long long)s->size);
+  hipError_t e = hipSuccess;
+  DISPATCH_DTYPE(s->dtype, e = Launch<T>::set_cell((T *)s->values, s->status, index, value, is_null, s->default_kind == OLAP_DEFAULT_NAN, nullptr));
+  if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
+  if (e != hipSuccess) return hip_fail(e, "set_value");
+  return OLAP_OK;
+}
+
+extern "C" int olap_store_fill(olap_store *s, double value) {
+  if (!s) return fail(OLAP_ERR_INVALID_ARGUMENT, "store is NULL");
+  if (!s->size) return OLAP_OK;
+  // fill = setValue(i, value) for every i (:135-137): one converted cell, broadcast
+  std::vector<double> one(1, value);
+  double *tmp = nullptr;
+  HIP_TRY(hipMalloc((void **)&tmp, sizeof(double)));
+  hipError_t e = hipMemcpy(tmp, one.data(), sizeof(double), hipMemcpyHostToDevice);
+  int rc = OLAP_OK;
+  if (e == hipSuccess) rc = olap_convert_from_f64(tmp, s->values, s->status, 1, s->dtype, s->default_kind, nullptr);
+  if (e == hipSuccess && !rc) e = hipStreamSynchronize(nullptr);
+  (void)hipFree(tmp);
+  if (rc) return rc;
+  if (e != hipSuccess) return hip_fail(e, "fill");
+  // replicate cell 0 (value + status) by doubling copies
+  const size_t es = olap_dtype_size(s->dtype);
+  uint64_t done = 1;
+  while (done < s->size) {
+    const uint64_t n = std::min(done, s->size - done);
+    HIP_TRY(hipMemcpyAsync((char *)s->values + done * es, s->values, n * es, hipMemcpyDeviceToDevice, nullptr));
+    HIP_TRY(hipMemcpyAsync(s->status + done, s->status, n * sizeof(int32_t), hipMemcpyDeviceToDevice, nullptr));
+    done += n;
+  }
+  HIP_TRY(hipStreamSynchronize(nullptr));
+  return OLAP_OK;
+}
+
+extern "C" int olap_store_total(const olap_store *s, double *total) {
+  if (!s || !total) return fail(OLAP_ERR_INVALID_ARGUMENT, "store is NULL");
+  return olap_total(s->values, s->status, s->size, s->dtype, s->default_kind, total, nullptr, nullptr);
+}
+
+// Integer cells under a NaN default are the one case where the mask carries information the
+// values cannot; everywhere else the kernels derive "set" from the value and skip the mask read.
+static const int32_t *mask_needed(const olap_store *s) {
+  const bool int_nan = s->default_kind == OLAP_DEFAULT_NAN && (s->dtype == OLAP_INT32 || s->dtype == OLAP_UINT32);
+  return int_nan ? s->status : nullptr;
+}
+
+static int run_to_new_store(olap_plan *plan, const olap_store *in, olap_store **out) {
+  olap_store *o = nullptr;
+  int rc = store_alloc(&o, olap_plan_out_cells(plan), in->dtype, in->default_kind);
+  if (!rc) rc = olap_plan_run(plan, in->values, mask_needed(in), o->values, o->status, nullptr);
+  if (!rc) {
+    hipError_t e = hipStreamSynchronize(nullptr);
+    if (e != hipSuccess) rc = hip_fail(e, "plan_run");
+  }
+  if (!rc) rc = olap_plan_status(plan);
+  olap_plan_destroy(plan);
+  if (rc) {
+    olap_store_destroy(o);
+    return rc;
+  }
+  *out = o;
+  return OLAP_OK;
+}
+
+static int check_store_cells(const olap_store *s, const olap_plan *plan) {
+  if (s->size != olap_plan_in_cells(plan))
+    return fail(OLAP_ERR_LENGTH_MISMATCH, "store holds %llu cells but the dimensions describe %llu", (unsigned long long)s->size, (unsigned long long)olap_plan_in_cells(plan));
+  return OLAP_OK;
+}
+
+extern "C" int olap_store_drillup(const olap_store *s, olap_store **out, int ndim, const uint32_t *old_len,
+                                  const uint32_t *new_len, const uint32_t *const *maps, int method) {
+  if (!s || !out) return fail(OLAP_ERR_INVALID_ARGUMENT, "store is NULL");
+  *out = nullptr;
+  olap_plan *plan = nullptr;
+  int rc = olap_drillup_plan(&plan, s->dtype, s->default_kind, method, ndim, old_len, new_len, maps);
+  if (rc) return rc;
+  if ((rc = check_store_cells(s, plan))) {
+    olap_plan_destroy(plan);
+    return rc;
+  }
+  return run_to_new_store(plan, s, out);
+}
+
+extern "C" int olap_store_drilldown(const olap_store *s, olap_store **out, int ndim, const uint32_t *old_len,
+                                    const uint32_t *new_len, const uint32_t *const *maps, int method,
+                                    const double *distributions, uint64_t n_dist) {
+  if (!s || !out) return fail(OLAP_ERR_INVALID_ARGUMENT, "store is NULL");
+  *out = nullptr;
+  olap_plan *plan = nullptr;
+  int rc = olap_drilldown_plan(&plan, s->dtype, s->default_kind, method, ndim, old_len, new_len, maps, distributions, n_dist);
+  if (rc) return rc;
+  if ((rc = check_store_cells(s, plan))) {
+    olap_plan_destroy(plan);
+    return rc;
+  }
+  return run_to_new_store(plan, s, out);
+}
+
+extern "C" int olap_store_dice(const olap_store *s, olap_store **out, int ndim, const uint32_t *old_len,
+                               const uint32_t *new_len, const int32_t *const *sel) {
+  if (!s || !out) return fail(OLAP_ERR_INVALID_ARGUMENT, "store is NULL");
+  *out = nullptr;
+  olap_plan *plan = nullptr;
+  int rc = olap_dice_plan(&plan, s->dtype, s->default_kind, ndim, old_len, new_len, sel);
+  if (rc) return rc;
+  if ((rc = check_store_cells(s, plan))) {
+    olap_plan_destroy(plan);
+    return rc;
+  }
+  return run_to_new_store(plan, s, out);
+}
+
+extern "C" int olap_store_reorder(const olap_store *s, olap_store **out, int ndim, const uint32_t *old_len,
+                                  const int32_t *perm) {
+  if (!s || !out) return fail(OLAP_ERR_INVALID_ARGUMENT, "store is NULL");
+  *out = nullptr;
+  olap_plan *plan = nullptr;
+  int rc = olap_reorder_plan(&plan, s->dtype, s->default_kind, ndim, old_len, perm);
+  if (rc) return rc;
+  if ((rc = check_store_cells(s, plan))) {
+    olap_plan_destroy(plan);
+    return rc;
+  }
+  return run_to_new_store(plan, s, out);
+}
+
+extern "C" int olap_store_load(olap_store *s, const olap_store *other, int ndim, const uint32_t *my_len,
+                               const uint32_t *his_len, const int32_t *const *his_to_mine) {
+  if (!s || !other) return fail(OLAP_ERR_INVALID_ARGUMENT, "store is NULL");
+  if (s->dtype != other->dtype) return fail(OLAP_ERR_INVALID_TYPE, "load: stores have different cell types");
+  olap_plan *plan = nullptr;
+  int rc = olap_load_plan(&plan, s->dtype, s->default_kind, other->default_kind, ndim, my_len, his_len, his_to_mine);
+  if (rc) return rc;
+  if (other->size != olap_plan_in_cells(plan) || s->size != olap_plan_out_cells(plan)) {
+    olap_plan_destroy(plan);
+    return fail(OLAP_ERR_LENGTH_MISMATCH, "load: store sizes do not match the dimensions");
+  }
+  rc = olap_plan_run(plan, other->values, mask_needed(other), s->values, s->status, nullptr);
+  if (!rc) {
+    hipError_t e = hipStreamSynchronize(nullptr);
+    if (e != hipSuccess) rc = hip_fail(e, "load");
+  }
+  olap_plan_destroy(plan);
+  return rc;
+}

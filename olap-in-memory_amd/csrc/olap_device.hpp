@@ -1,0 +1,153 @@
+// olap_device.hpp — device-side building blocks shared by the gfx950 kernels.
+//
+// Cell semantics restate /root/reference/src/store/in-memory.js on dense typed buffers:
+//   * a cell is set iff (status & 0x2, when a mask is given) and value != default  (:122-133)
+//   * accumulation is float64 whatever the declared type                        (:282-290)
+//   * results are stored with ECMAScript TypedArray conversion                  (:77-92)
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/olap_hip.h"
+
+namespace olap {
+
+constexpr int kBlock = 256;  // 4 wavefronts of 64 lanes
+
+// ---------------------------------------------------------------- typed <-> float64
+__device__ __forceinline__ uint32_t js_to_uint32(double d) {
+  // ToUint32: NaN / +-Inf -> 0, truncate toward zero, modulo 2^32
+  if (!(fabs(d) < 1.7976931348623157e308)) return 0u;  // NaN or Inf
+  double t = trunc(d);
+  double m = fmod(t, 4294967296.0);
+  if (m < 0) m += 4294967296.0;
+  return (uint32_t)m;
+}
+
+template <typename T> struct Cell;
+template <> struct Cell<float> {
+  static constexpr int dtype = OLAP_FLOAT32;
+  static __device__ __forceinline__ double to_f64(float v) { return (double)v; }
+  static __device__ __forceinline__ float from_f64(double d) { return (float)d; }
+  static __device__ __forceinline__ bool is_default(float v, bool def_nan) { return def_nan ? (v != v) : (v == 0.0f); }
+  static __device__ __forceinline__ float default_value(bool def_nan) { return def_nan ? __builtin_nanf("") : 0.0f; }
+};
+template <> struct Cell<double> {
+  static constexpr int dtype = OLAP_FLOAT64;
+  static __device__ __forceinline__ double to_f64(double v) { return v; }
+  static __device__ __forceinline__ double from_f64(double d) { return d; }
+  static __device__ __forceinline__ bool is_default(double v, bool def_nan) { return def_nan ? (v != v) : (v == 0.0); }
+  static __device__ __forceinline__ double default_value(bool def_nan) { return def_nan ? __builtin_nan("") : 0.0; }
+};
+template <> struct Cell<int32_t> {
+  static constexpr int dtype = OLAP_INT32;
+  static __device__ __forceinline__ double to_f64(int32_t v) { return (double)v; }
+  static __device__ __forceinline__ int32_t from_f64(double d) { return (int32_t)js_to_uint32(d); }
+  static __device__ __forceinline__ bool is_default(int32_t v, bool def_nan) { return def_nan ? false : (v == 0); }
+  static __device__ __forceinline__ int32_t default_value(bool) { return 0; }
+};
+template <> struct Cell<uint32_t> {
+  static constexpr int dtype = OLAP_UINT32;
+  static __device__ __forceinline__ double to_f64(uint32_t v) { return (double)v; }
+  static __device__ __forceinline__ uint32_t from_f64(double d) { return js_to_uint32(d); }
+  static __device__ __forceinline__ bool is_default(uint32_t v, bool def_nan) { return def_nan ? false : (v == 0u); }
+  static __device__ __forceinline__ uint32_t default_value(bool) { return 0u; }
+};
+
+__device__ __forceinline__ bool is_default_f64(double r, bool def_nan) { return def_nan ? (r != r) : (r == 0.0); }
+
+// Math.max / Math.min (in-memory.js:285-286): NaN-propagating, +0 > -0
+__device__ __forceinline__ double js_max(double a, double b) {
+  if (a != a || b != b) return __builtin_nan("");
+  if (a == 0.0 && b == 0.0) return __builtin_signbit(a) ? b : a;
+  return a > b ? a : b;
+}
+__device__ __forceinline__ double js_min(double a, double b) {
+  if (a != a || b != b) return __builtin_nan("");
+  if (a == 0.0 && b == 0.0) return __builtin_signbit(a) ? a : b;
+  return a < b ? a : b;
+}
+
+// ---------------------------------------------------------------- vector access (16 B per lane where it divides)
+template <typename T, int N> struct alignas(sizeof(T) * N) Vec { T v[N]; };
+
+template <typename T, int N>
+__device__ __forceinline__ Vec<T, N> load_vec(const T *p) {
+  return *reinterpret_cast<const Vec<T, N> *>(p);
+}
+template <typename T, int N>
+__device__ __forceinline__ void store_vec(T *p, const Vec<T, N> &x) {
+  *reinterpret_cast<Vec<T, N> *>(p) = x;
+}
+
+// ---------------------------------------------------------------- the per-output-cell aggregate
+// Restates the body of the drillUp loop, in-memory.js:311-320: the first contribution stores the
+// value, later ones store agg(current, value); setValue drops the key when the running value
+// equals the default, so the next contribution starts over; contributions are counted apart.
+template <int METHOD>
+struct Agg {
+  double acc;
+  uint32_t count;
+  bool has;
+
+  __device__ __forceinline__ void init() {
+    acc = 0.0;
+    count = 0;
+    has = false;
+  }
+  // `v` is the value of a SET input cell
+  __device__ __forceinline__ void add(double v, bool def_nan) {
+    if (!has) {
+      acc = v;  // a set cell never holds the default, so the key now exists
+      has = true;
+    } else {
+      double r;
+      if constexpr (METHOD == OLAP_SUM || METHOD == OLAP_AVERAGE) r = acc + v;
+      else if constexpr (METHOD == OLAP_HIGHEST) r = js_max(acc, v);
+      else if constexpr (METHOD == OLAP_LOWEST) r = js_min(acc, v);
+      else if constexpr (METHOD == OLAP_FIRST) r = acc;
+      else if constexpr (METHOD == OLAP_LAST) r = v;
+      else r = acc * v;
+      if (is_default_f64(r, def_nan)) has = false;  // setValue(idx, default) deletes the key
+      else acc = r;
+    }
+    ++count;
+  }
+  // in-memory.js:323-331
+  __device__ __forceinline__ void finish(bool def_nan) {
+    if constexpr (METHOD == OLAP_AVERAGE) {
+      const uint32_t c16 = count & 0xFFFFu;  // Uint16Array counter
+      if (c16) {
+        const double cur = has ? acc : (def_nan ? __builtin_nan("") : 0.0);
+        const double r = cur / (double)c16;
+        has = !is_default_f64(r, def_nan);
+        acc = r;
+      }
+    }
+  }
+};
+
+// Writes one output cell: typed conversion, then the store invariant (set => value != default).
+template <typename T>
+__device__ __forceinline__ void emit_cell(double acc, bool has, bool def_nan, T &value, int32_t &status) {
+  T tv = has ? Cell<T>::from_f64(acc) : Cell<T>::default_value(def_nan);
+  bool set = has && !Cell<T>::is_default(tv, def_nan);
+  value = set ? tv : Cell<T>::default_value(def_nan);
+  status = set ? OLAP_STATUS_SET : 0;
+}
+
+template <typename T>
+__device__ __forceinline__ bool cell_is_set(T v, int32_t st, bool has_status, bool def_nan) {
+  return (!has_status || (st & OLAP_STATUS_SET)) && !Cell<T>::is_default(v, def_nan);
+}
+
+// mulberry32 at stream position n (1-based draw index): state = seed + n * 0x6D2B79F5
+__device__ __host__ __forceinline__ double mulberry32_at(uint32_t seed, uint64_t n) {
+  uint32_t a = seed + (uint32_t)(n * 0x6D2B79F5ull);
+  uint32_t t = (a ^ (a >> 15)) * (1u | a);
+  t = (t + ((t ^ (t >> 7)) * (61u | t))) ^ t;
+  return (double)(t ^ (t >> 14)) / 4294967296.0;
+}
+
+}  // namespace olap

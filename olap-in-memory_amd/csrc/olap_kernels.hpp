@@ -1,0 +1,655 @@
+// olap_kernels.hpp — gfx950 kernels of the cube aggregation path and their launchers.
+//
+// Every kernel is bound by HBM bandwidth (one add per 4 B read), so the rules that matter are
+// coalesced 16 B/lane accesses, enough loads in flight per lane, >> 256 workgroups per launch,
+// and reading each input cell exactly once.  No MFMA: there is no contraction here.
+//
+// Instantiated once per cell type in olap_kernels_{f32,f64,i32,u32}.hip.
+#pragma once
+
+#include "olap_device.hpp"
+
+namespace olap {
+
+constexpr int kMaxDims = 12;  // collapsed dimensions a plan may keep (see plan.cpp)
+
+// ======================================================================= K1: drillUp, one axis
+// View [outer, K, inner] -> [outer, G, inner] (in-memory.js:265-334 with one non-identity map,
+// which is all Cube.drillUp ever asks for, src/cube.js:999-1000).  The K->G map arrives as a
+// CSR: gstart[g]..gstart[g+1] indexes `order`, the old indices of group g in ascending order
+// (order == nullptr: groups are the contiguous runs themselves, e.g. calendars and 'all').
+struct DrillUpAxis {
+  uint64_t outer, K, inner, G;
+  uint64_t n_vec;         // inner / VEC
+  uint64_t total;         // outer * G * n_vec  (threads needed)
+  const uint32_t *order;  // device
+  const uint32_t *gstart; // device
+  int def_nan;
+};
+
+// Direct regime: lanes run along `inner` (contiguous), each lane owns VEC adjacent output
+// cells of one (outer, group) pair and walks that group's rows in ascending order, which is the
+// reference's accumulation order, so float64 sums are bit-identical.  Loads of one wave are
+// VEC*4*64 contiguous bytes; U rows are kept in flight per lane.
+template <typename T, int METHOD, bool HAS_STATUS, int VEC, int U>
+__global__ __launch_bounds__(kBlock) void drillup_direct_kernel(const T *__restrict__ in,
+                                                                const int32_t *__restrict__ st_in,
+                                                                T *__restrict__ out,
+                                                                int32_t *__restrict__ st_out,
+                                                                const DrillUpAxis a) {
+  const uint64_t t = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (t >= a.total) return;
+  const uint64_t iv = t % a.n_vec;
+  const uint64_t og = t / a.n_vec;
+  const uint64_t g = og % a.G;
+  const uint64_t o = og / a.G;
+  const uint64_t i0 = iv * VEC;
+  const bool def_nan = a.def_nan != 0;
+
+  const T *base = in + (o * a.K) * a.inner + i0;
+  const int32_t *sbase = HAS_STATUS ? st_in + (o * a.K) * a.inner + i0 : nullptr;
+  uint32_t j = a.gstart[g];
+  const uint32_t jend = a.gstart[g + 1];
+
+  // Fast form for sum/average over a zero default without a mask: an unset cell holds 0, adding
+  // it changes nothing, and the "restart after the running sum hits 0" of the reference is
+  // invisible for addition.  Otherwise the exact state machine of Agg<> runs.
+  constexpr bool kAdditive = (METHOD == OLAP_SUM || METHOD == OLAP_AVERAGE);
+  const bool fast = kAdditive && !HAS_STATUS && !def_nan;
+
+  Agg<METHOD> agg[VEC];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) agg[e].init();
+
+  for (; j < jend; j += U) {
+    const uint32_t n = (jend - j) < (uint32_t)U ? (jend - j) : (uint32_t)U;
+    Vec<T, VEC> v[U];
+    Vec<int32_t, VEC> s[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if ((uint32_t)u < n) {
+        const uint64_t k = a.order ? a.order[j + u] : (uint64_t)(j + u);
+        v[u] = load_vec<T, VEC>(base + k * a.inner);
+        if constexpr (HAS_STATUS) s[u] = load_vec<int32_t, VEC>(sbase + k * a.inner);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if ((uint32_t)u < n) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          const T x = v[u].v[e];
+          if (fast) {
+            agg[e].acc += Cell<T>::to_f64(x);
+            agg[e].count += Cell<T>::is_default(x, false) ? 0u : 1u;
+          } else {
+            const int32_t sx = HAS_STATUS ? s[u].v[e] : OLAP_STATUS_SET;
+            if (cell_is_set<T>(x, sx, HAS_STATUS, def_nan)) agg[e].add(Cell<T>::to_f64(x), def_nan);
+          }
+        }
+      }
+    }
+  }
+
+  Vec<T, VEC> ov;
+  Vec<int32_t, VEC> os;
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) {
+    if (fast) agg[e].has = agg[e].count != 0 && agg[e].acc != 0.0;
+    agg[e].finish(def_nan);
+    emit_cell<T>(agg[e].acc, agg[e].has, def_nan, ov.v[e], os.v[e]);
+  }
+  const uint64_t oidx = (o * a.G + g) * a.inner + i0;
+  store_vec<T, VEC>(out + oidx, ov);
+  if (st_out) store_vec<int32_t, VEC>(st_out + oidx, os);
+}
+
+// ======================================================================= K1g: drillUp, any maps
+// The store method accepts a map on every dimension (in-memory.js:270-274).  One lane per output
+// cell walks the cartesian product of its groups' member lists in ascending flat order.
+struct DrillUpGeneric {
+  int nd;                       // collapsed dims
+  uint32_t new_len[kMaxDims];
+  uint64_t old_stride[kMaxDims];
+  int32_t csr[kMaxDims];        // -1: identity dim; else offset of this dim's gstart in `tab`
+  int32_t ord[kMaxDims];        // offset of this dim's order list in `tab`
+  const uint32_t *tab;          // device
+  uint64_t total;               // output cells
+  int def_nan;
+};
+
+template <typename T, int METHOD, bool HAS_STATUS>
+__global__ __launch_bounds__(kBlock) void drillup_generic_kernel(const T *__restrict__ in,
+                                                                 const int32_t *__restrict__ st_in,
+                                                                 T *__restrict__ out,
+                                                                 int32_t *__restrict__ st_out,
+                                                                 const DrillUpGeneric a) {
+  const uint64_t t = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (t >= a.total) return;
+  const bool def_nan = a.def_nan != 0;
+  uint32_t lo[kMaxDims], hi[kMaxDims], cur[kMaxDims];
+  uint64_t fixed = 0;  // offset contributed by identity dims
+  {
+    uint64_t c = t;
+    for (int d = a.nd - 1; d >= 0; --d) {
+      const uint32_t digit = (uint32_t)(c % a.new_len[d]);
+      c /= a.new_len[d];
+      if (a.csr[d] < 0) {
+        fixed += (uint64_t)digit * a.old_stride[d];
+        lo[d] = hi[d] = 0;
+      } else {
+        lo[d] = a.tab[a.csr[d] + digit];
+        hi[d] = a.tab[a.csr[d] + digit + 1];
+      }
+      cur[d] = lo[d];
+    }
+  }
+  bool empty = false;
+  for (int d = 0; d < a.nd; ++d)
+    if (a.csr[d] >= 0 && lo[d] == hi[d]) empty = true;
+
+  Agg<METHOD> agg;
+  agg.init();
+  while (!empty) {
+    uint64_t off = fixed;
+    for (int d = 0; d < a.nd; ++d)
+      if (a.csr[d] >= 0) off += (uint64_t)a.tab[a.ord[d] + cur[d]] * a.old_stride[d];
+    const T x = in[off];
+    const int32_t sx = HAS_STATUS ? st_in[off] : OLAP_STATUS_SET;
+    if (cell_is_set<T>(x, sx, HAS_STATUS, def_nan)) agg.add(Cell<T>::to_f64(x), def_nan);
+    // odometer, last changed dim fastest == ascending old flat index
+    int d = a.nd - 1;
+    for (; d >= 0; --d) {
+      if (a.csr[d] < 0) continue;
+      if (++cur[d] < hi[d]) break;
+      cur[d] = lo[d];
+    }
+    if (d < 0) break;
+  }
+  agg.finish(def_nan);
+  T ov;
+  int32_t os;
+  emit_cell<T>(agg.acc, agg.has, def_nan, ov, os);
+  out[t] = ov;
+  if (st_out) st_out[t] = os;
+}
+
+// ======================================================================= K2: dice / load / reorder
+// All three are index-remapped copies.  `Remap` describes, for each collapsed destination
+// dimension, how a destination digit contributes to the source offset: either digit*stride
+// (untouched dims, no table) or a table entry (int64 offset, -1 = no source cell).
+struct Remap {
+  int nd;
+  uint32_t len[kMaxDims];      // extents of the iteration space (collapsed)
+  uint64_t stride[kMaxDims];   // arithmetic dims: offset = digit * stride
+  int32_t tab_off[kMaxDims];   // -1: arithmetic; else start of this dim's int64 table in `tab`
+  const int64_t *tab;          // device
+  uint64_t total;              // iteration space / VEC
+  int def_nan;
+  int src_def_nan;             // load: the other store's default kind
+};
+
+// dice (in-memory.js:213-263) and reorder (:178-211): iterate the DESTINATION, gather from the
+// source.  Destination cells without a source stay unset.  VEC > 1 only when the innermost
+// collapsed dim is contiguous in both (plan guarantees divisibility).
+template <typename T, bool HAS_STATUS, int VEC>
+__global__ __launch_bounds__(kBlock) void gather_kernel(const T *__restrict__ in,
+                                                        const int32_t *__restrict__ st_in,
+                                                        T *__restrict__ out,
+                                                        int32_t *__restrict__ st_out, const Remap r) {
+  const uint64_t t = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (t >= r.total) return;
+  const bool def_nan = r.def_nan != 0;
+  uint64_t c = t * VEC;
+  uint64_t src = 0;
+  bool ok = true;
+#pragma unroll
+  for (int d = kMaxDims - 1; d >= 0; --d) {
+    if (d < r.nd) {
+      const uint32_t digit = (uint32_t)(c % r.len[d]);
+      c /= r.len[d];
+      if (r.tab_off[d] < 0) {
+        src += (uint64_t)digit * r.stride[d];
+      } else {
+        const int64_t o = r.tab[r.tab_off[d] + digit];
+        if (o < 0) ok = false;
+        else src += (uint64_t)o;
+      }
+    }
+  }
+  Vec<T, VEC> ov;
+  Vec<int32_t, VEC> os;
+  if (ok) {
+    const Vec<T, VEC> v = load_vec<T, VEC>(in + src);
+    Vec<int32_t, VEC> s;
+    if constexpr (HAS_STATUS) s = load_vec<int32_t, VEC>(st_in + src);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      const bool set = cell_is_set<T>(v.v[e], HAS_STATUS ? s.v[e] : OLAP_STATUS_SET, HAS_STATUS, def_nan);
+      ov.v[e] = set ? v.v[e] : Cell<T>::default_value(def_nan);
+      os.v[e] = set ? OLAP_STATUS_SET : 0;
+    }
+  } else {
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      ov.v[e] = Cell<T>::default_value(def_nan);
+      os.v[e] = 0;
+    }
+  }
+  store_vec<T, VEC>(out + t * VEC, ov);
+  if (st_out) store_vec<int32_t, VEC>(st_out + t * VEC, os);
+}
+
+// load (in-memory.js:139-176): iterate the SOURCE (the other store, dense over all its cells,
+// see the comment at :152-158), scatter into this store with setValue semantics:
+// mine.setValue(myIdx, his.getValue(hisIdx)).
+template <typename T, bool HAS_STATUS>
+__global__ __launch_bounds__(kBlock) void load_scatter_kernel(const T *__restrict__ his,
+                                                              const int32_t *__restrict__ his_st,
+                                                              T *__restrict__ mine,
+                                                              int32_t *__restrict__ mine_st, const Remap r) {
+  const uint64_t t = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (t >= r.total) return;
+  const bool def_nan = r.def_nan != 0, his_nan = r.src_def_nan != 0;
+  uint64_t c = t, dst = 0;
+  bool ok = true;
+#pragma unroll
+  for (int d = kMaxDims - 1; d >= 0; --d) {
+    if (d < r.nd) {
+      const uint32_t digit = (uint32_t)(c % r.len[d]);
+      c /= r.len[d];
+      if (r.tab_off[d] < 0) {
+        dst += (uint64_t)digit * r.stride[d];
+      } else {
+        const int64_t o = r.tab[r.tab_off[d] + digit];
+        if (o < 0) ok = false;
+        else dst += (uint64_t)o;
+      }
+    }
+  }
+  if (!ok) return;
+  const T x = his[t];
+  const bool his_set = cell_is_set<T>(x, HAS_STATUS ? his_st[t] : OLAP_STATUS_SET, HAS_STATUS, his_nan);
+  // getValue: the stored value or HIS default; then setValue against MY default.  For integer
+  // cells a NaN default has no typed representation: an unset source cell unsets the target.
+  bool set;
+  T v;
+  if (his_set) {
+    v = x;
+    set = !Cell<T>::is_default(v, def_nan);
+  } else {
+    v = Cell<T>::default_value(his_nan);
+    constexpr bool is_float = (Cell<T>::dtype == OLAP_FLOAT32 || Cell<T>::dtype == OLAP_FLOAT64);
+    set = is_float && his_nan && !def_nan;  // NaN is storable under a zero default
+  }
+  mine[dst] = set ? v : Cell<T>::default_value(def_nan);
+  if (mine_st) mine_st[dst] = set ? OLAP_STATUS_SET : 0;
+}
+
+// ======================================================================= K3: drillDown
+// in-memory.js:336-430.  One lane per NEW cell: parent offset, sibling count n and this child's
+// ordinal c (its rank among the parent's children in ascending new index) come from per-dim
+// tables; the integer remainder spreading (:403-417) is replayed in float64 exactly.
+struct DrillDown {
+  int nd;
+  uint32_t new_len[kMaxDims];
+  uint64_t old_stride[kMaxDims];
+  int32_t tab_off[kMaxDims];  // -1: identity dim (parent digit = digit, 1 child); else offset into tab
+  const uint32_t *tab;        // per table dim: parent[len], count[len], rank[len]
+  uint64_t total;             // new cells
+  int def_nan;
+  int method;
+  int use_rounding;
+  const double *dist;  // device, or nullptr
+  uint64_t n_dist;
+  double added_len;    // newSize / oldSize            (:392)
+  double chunk;        // newSize / sharedDimSize      (:395)
+  unsigned long long *err;  // device: smallest failing new index (init ~0ull)
+};
+
+template <typename T, bool HAS_STATUS>
+__global__ __launch_bounds__(kBlock) void drilldown_kernel(const T *__restrict__ in,
+                                                           const int32_t *__restrict__ st_in,
+                                                           T *__restrict__ out,
+                                                           int32_t *__restrict__ st_out,
+                                                           const DrillDown a) {
+  const uint64_t t = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (t >= a.total) return;
+  const bool def_nan = a.def_nan != 0;
+  uint64_t c = t, parent = 0, n = 1, ordinal = 0;
+#pragma unroll
+  for (int d = kMaxDims - 1; d >= 0; --d) {
+    if (d < a.nd) {
+      const uint32_t L = a.new_len[d];
+      const uint32_t digit = (uint32_t)(c % L);
+      c /= L;
+      if (a.tab_off[d] < 0) {
+        parent += (uint64_t)digit * a.old_stride[d];
+      } else {
+        const uint32_t *tb = a.tab + a.tab_off[d];
+        parent += (uint64_t)tb[digit] * a.old_stride[d];
+        const uint64_t cnt = tb[L + digit];
+        ordinal += (uint64_t)tb[2 * L + digit] * n;  // dims to the right vary fastest
+        n *= cnt;
+      }
+    }
+  }
+  const T x = in[parent];
+  const int32_t sx = HAS_STATUS ? st_in[parent] : OLAP_STATUS_SET;
+  const double old_value = Cell<T>::to_f64(x);
+  // `if (!oldValue) continue` (:386-387): unset, 0, -0 and NaN are all skipped
+  bool has = cell_is_set<T>(x, sx, HAS_STATUS, def_nan) && old_value == old_value && old_value != 0.0;
+  double r = 0.0;
+  if (has) {
+    const double nn = (double)n;
+    if (a.dist) {  // :391-400
+      const double di = floor((double)t / a.chunk) * a.added_len + fmod((double)t, a.added_len);
+      const bool okay = di >= 0.0 && di < (double)a.n_dist && di == floor(di) && a.dist[(uint64_t)di] == a.dist[(uint64_t)di];
+      if (!okay) {
+        atomicMin(a.err, (unsigned long long)t);
+        has = false;
+      } else {
+        r = old_value * a.dist[(uint64_t)di];
+      }
+    } else if (a.method == OLAP_SUM) {
+      if (a.use_rounding) {  // :403-417
+        const double value = floor(old_value / nn);
+        const double remainder = fmod(old_value, nn);
+        const double cid = (double)ordinal;
+        const double one_over = remainder / nn;
+        const bool last_is_same = floor(cid * one_over) == floor((cid - 1.0) * one_over);
+        r = last_is_same ? floor(value) : floor(value) + 1.0;
+      } else {
+        r = old_value / nn;  // :419
+      }
+    } else {
+      r = old_value;  // :422
+    }
+    if (has && is_default_f64(r, def_nan)) has = false;  // setValue
+  }
+  T ov;
+  int32_t os;
+  emit_cell<T>(r, has, def_nan, ov, os);
+  out[t] = ov;
+  if (st_out) st_out[t] = os;
+}
+
+// ======================================================================= element-wise helpers
+template <typename T>
+__global__ __launch_bounds__(kBlock) void canonicalize_kernel(T *values, int32_t *status, uint64_t n, int def_nan_i,
+                                                              int use_status) {
+  const bool def_nan = def_nan_i != 0;
+  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kBlock) {
+    const T v = values[i];
+    const bool set = cell_is_set<T>(v, use_status ? status[i] : OLAP_STATUS_SET, use_status != 0, def_nan);
+    if (!set) values[i] = Cell<T>::default_value(def_nan);
+    if (status) status[i] = set ? OLAP_STATUS_SET : 0;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void from_f64_kernel(const double *src, T *values, int32_t *status, uint64_t n,
+                                                          int def_nan_i) {
+  const bool def_nan = def_nan_i != 0;
+  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kBlock) {
+    const double d = src[i];
+    // setValue on the JS number first (a NaN under a NaN default is "unset" even for integer types)
+    const bool has = !is_default_f64(d, def_nan);
+    T ov;
+    int32_t os;
+    emit_cell<T>(d, has, def_nan, ov, os);
+    values[i] = ov;
+    if (status) status[i] = os;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void to_f64_kernel(const T *values, double *dst, uint64_t n) {
+  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kBlock)
+    dst[i] = Cell<T>::to_f64(values[i]);
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void fill_seeded_kernel(T *values, int32_t *status, uint64_t n, uint64_t first,
+                                                             uint32_t seed, double frac) {
+  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kBlock) {
+    const uint64_t cell = first + i;
+    const double v = (double)(float)(0.5 + mulberry32_at(seed, 2 * cell + 1));
+    const bool keep = mulberry32_at(seed, 2 * cell + 2) < frac;
+    T ov;
+    int32_t os;
+    emit_cell<T>(v, keep, false, ov, os);
+    values[i] = ov;
+    if (status) status[i] = os;
+  }
+}
+
+// float64 total + count of set cells: wave shuffle -> LDS -> one atomic pair per workgroup
+template <typename T>
+__global__ __launch_bounds__(kBlock) void total_kernel(const T *values, const int32_t *status, uint64_t n, int def_nan_i,
+                                                       double *total, unsigned long long *count) {
+  const bool def_nan = def_nan_i != 0;
+  double acc = 0.0;
+  unsigned long long cnt = 0;
+  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kBlock) {
+    const T v = values[i];
+    if (cell_is_set<T>(v, status ? status[i] : OLAP_STATUS_SET, status != nullptr, def_nan)) {
+      acc += Cell<T>::to_f64(v);
+      ++cnt;
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    acc += __shfl_down(acc, off, 64);
+    cnt += __shfl_down(cnt, off, 64);
+  }
+  __shared__ double s_acc[kBlock / 64];
+  __shared__ unsigned long long s_cnt[kBlock / 64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) {
+    s_acc[wave] = acc;
+    s_cnt[wave] = cnt;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double a = 0.0;
+    unsigned long long c = 0;
+    for (int w = 0; w < kBlock / 64; ++w) {
+      a += s_acc[w];
+      c += s_cnt[w];
+    }
+    atomicAdd(total, a);
+    atomicAdd(count, c);
+  }
+}
+
+// single-cell access for getValue / setValue on a handle store
+template <typename T>
+__global__ void set_cell_kernel(T *values, int32_t *status, uint64_t index, double value, int is_null, int def_nan_i) {
+  const bool def_nan = def_nan_i != 0;
+  const bool has = !is_null && !is_default_f64(value, def_nan);
+  T ov;
+  int32_t os;
+  emit_cell<T>(value, has, def_nan, ov, os);
+  values[index] = ov;
+  if (status) status[index] = os;
+}
+
+// ======================================================================= launchers
+template <typename T>
+struct Launch {
+  static hipError_t drillup_axis(int method, bool has_status, int vec, const T *in, const int32_t *st_in, T *out,
+                                 int32_t *st_out, const DrillUpAxis &a, hipStream_t stream);
+  static hipError_t drillup_generic(int method, bool has_status, const T *in, const int32_t *st_in, T *out,
+                                    int32_t *st_out, const DrillUpGeneric &a, hipStream_t stream);
+  static hipError_t gather(bool has_status, int vec, const T *in, const int32_t *st_in, T *out, int32_t *st_out,
+                           const Remap &r, hipStream_t stream);
+  static hipError_t load_scatter(bool has_status, const T *his, const int32_t *his_st, T *mine, int32_t *mine_st,
+                                 const Remap &r, hipStream_t stream);
+  static hipError_t drilldown(bool has_status, const T *in, const int32_t *st_in, T *out, int32_t *st_out,
+                              const DrillDown &a, hipStream_t stream);
+  static hipError_t canonicalize(T *values, int32_t *status, uint64_t n, int def_nan, int use_status,
+                                 hipStream_t stream);
+  static hipError_t from_f64(const double *src, T *values, int32_t *status, uint64_t n, int def_nan,
+                             hipStream_t stream);
+  static hipError_t to_f64(const T *values, double *dst, uint64_t n, hipStream_t stream);
+  static hipError_t fill_seeded(T *values, int32_t *status, uint64_t n, uint64_t first, uint32_t seed, double frac,
+                                hipStream_t stream);
+  static hipError_t total(const T *values, const int32_t *status, uint64_t n, int def_nan, double *total,
+                          unsigned long long *count, hipStream_t stream);
+  static hipError_t set_cell(T *values, int32_t *status, uint64_t index, double value, int is_null, int def_nan,
+                             hipStream_t stream);
+};
+
+inline unsigned grid_for(uint64_t threads) { return (unsigned)((threads + kBlock - 1) / kBlock); }
+inline unsigned grid_stride_for(uint64_t n) {
+  const uint64_t want = (n + kBlock - 1) / kBlock;
+  const uint64_t cap = 256ull * 8ull;  // 256 CUs x 8 resident workgroups
+  return (unsigned)(want < 1 ? 1 : (want < cap ? want : cap));
+}
+
+#ifdef OLAP_KERNELS_IMPL
+
+template <typename T, int METHOD, bool HS>
+static hipError_t drillup_axis_vec(int vec, const T *in, const int32_t *st_in, T *out, int32_t *st_out,
+                                   const DrillUpAxis &a, hipStream_t stream) {
+  const unsigned grid = grid_for(a.total);
+  constexpr int U = 8;
+  if (vec == 4) hipLaunchKernelGGL((drillup_direct_kernel<T, METHOD, HS, 4, U>), grid, kBlock, 0, stream, in, st_in, out, st_out, a);
+  else if (vec == 2) hipLaunchKernelGGL((drillup_direct_kernel<T, METHOD, HS, 2, U>), grid, kBlock, 0, stream, in, st_in, out, st_out, a);
+  else hipLaunchKernelGGL((drillup_direct_kernel<T, METHOD, HS, 1, U>), grid, kBlock, 0, stream, in, st_in, out, st_out, a);
+  return hipGetLastError();
+}
+
+template <typename T, bool HS>
+static hipError_t drillup_axis_method(int method, int vec, const T *in, const int32_t *st_in, T *out, int32_t *st_out,
+                                      const DrillUpAxis &a, hipStream_t stream) {
+  switch (method) {
+    case OLAP_SUM: return drillup_axis_vec<T, OLAP_SUM, HS>(vec, in, st_in, out, st_out, a, stream);
+    case OLAP_AVERAGE: return drillup_axis_vec<T, OLAP_AVERAGE, HS>(vec, in, st_in, out, st_out, a, stream);
+    case OLAP_HIGHEST: return drillup_axis_vec<T, OLAP_HIGHEST, HS>(vec, in, st_in, out, st_out, a, stream);
+    case OLAP_LOWEST: return drillup_axis_vec<T, OLAP_LOWEST, HS>(vec, in, st_in, out, st_out, a, stream);
+    case OLAP_FIRST: return drillup_axis_vec<T, OLAP_FIRST, HS>(vec, in, st_in, out, st_out, a, stream);
+    case OLAP_LAST: return drillup_axis_vec<T, OLAP_LAST, HS>(vec, in, st_in, out, st_out, a, stream);
+    default: return drillup_axis_vec<T, OLAP_PRODUCT, HS>(vec, in, st_in, out, st_out, a, stream);
+  }
+}
+
+template <typename T>
+hipError_t Launch<T>::drillup_axis(int method, bool has_status, int vec, const T *in, const int32_t *st_in, T *out,
+                                   int32_t *st_out, const DrillUpAxis &a, hipStream_t stream) {
+  if (a.total == 0) return hipSuccess;
+  return has_status ? drillup_axis_method<T, true>(method, vec, in, st_in, out, st_out, a, stream)
+                    : drillup_axis_method<T, false>(method, vec, in, st_in, out, st_out, a, stream);
+}
+
+template <typename T, bool HS>
+static hipError_t drillup_generic_method(int method, const T *in, const int32_t *st_in, T *out, int32_t *st_out,
+                                         const DrillUpGeneric &a, hipStream_t stream) {
+  const unsigned grid = grid_for(a.total);
+#define OLAP_GEN(M) hipLaunchKernelGGL((drillup_generic_kernel<T, M, HS>), grid, kBlock, 0, stream, in, st_in, out, st_out, a)
+  switch (method) {
+    case OLAP_SUM: OLAP_GEN(OLAP_SUM); break;
+    case OLAP_AVERAGE: OLAP_GEN(OLAP_AVERAGE); break;
+    case OLAP_HIGHEST: OLAP_GEN(OLAP_HIGHEST); break;
+    case OLAP_LOWEST: OLAP_GEN(OLAP_LOWEST); break;
+    case OLAP_FIRST: OLAP_GEN(OLAP_FIRST); break;
+    case OLAP_LAST: OLAP_GEN(OLAP_LAST); break;
+    default: OLAP_GEN(OLAP_PRODUCT); break;
+  }
+#undef OLAP_GEN
+  return hipGetLastError();
+}
+
+template <typename T>
+hipError_t Launch<T>::drillup_generic(int method, bool has_status, const T *in, const int32_t *st_in, T *out,
+                                      int32_t *st_out, const DrillUpGeneric &a, hipStream_t stream) {
+  if (a.total == 0) return hipSuccess;
+  return has_status ? drillup_generic_method<T, true>(method, in, st_in, out, st_out, a, stream)
+                    : drillup_generic_method<T, false>(method, in, st_in, out, st_out, a, stream);
+}
+
+template <typename T>
+hipError_t Launch<T>::gather(bool has_status, int vec, const T *in, const int32_t *st_in, T *out, int32_t *st_out,
+                             const Remap &r, hipStream_t stream) {
+  if (r.total == 0) return hipSuccess;
+  const unsigned grid = grid_for(r.total);
+#define OLAP_G(HS, V) hipLaunchKernelGGL((gather_kernel<T, HS, V>), grid, kBlock, 0, stream, in, st_in, out, st_out, r)
+  if (has_status) {
+    if (vec == 4) OLAP_G(true, 4); else if (vec == 2) OLAP_G(true, 2); else OLAP_G(true, 1);
+  } else {
+    if (vec == 4) OLAP_G(false, 4); else if (vec == 2) OLAP_G(false, 2); else OLAP_G(false, 1);
+  }
+#undef OLAP_G
+  return hipGetLastError();
+}
+
+template <typename T>
+hipError_t Launch<T>::load_scatter(bool has_status, const T *his, const int32_t *his_st, T *mine, int32_t *mine_st,
+                                   const Remap &r, hipStream_t stream) {
+  if (r.total == 0) return hipSuccess;
+  const unsigned grid = grid_for(r.total);
+  if (has_status) hipLaunchKernelGGL((load_scatter_kernel<T, true>), grid, kBlock, 0, stream, his, his_st, mine, mine_st, r);
+  else hipLaunchKernelGGL((load_scatter_kernel<T, false>), grid, kBlock, 0, stream, his, his_st, mine, mine_st, r);
+  return hipGetLastError();
+}
+
+template <typename T>
+hipError_t Launch<T>::drilldown(bool has_status, const T *in, const int32_t *st_in, T *out, int32_t *st_out,
+                                const DrillDown &a, hipStream_t stream) {
+  if (a.total == 0) return hipSuccess;
+  const unsigned grid = grid_for(a.total);
+  if (has_status) hipLaunchKernelGGL((drilldown_kernel<T, true>), grid, kBlock, 0, stream, in, st_in, out, st_out, a);
+  else hipLaunchKernelGGL((drilldown_kernel<T, false>), grid, kBlock, 0, stream, in, st_in, out, st_out, a);
+  return hipGetLastError();
+}
+
+template <typename T>
+hipError_t Launch<T>::canonicalize(T *values, int32_t *status, uint64_t n, int def_nan, int use_status,
+                                   hipStream_t stream) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL((canonicalize_kernel<T>), grid_stride_for(n), kBlock, 0, stream, values, status, n, def_nan, use_status);
+  return hipGetLastError();
+}
+
+template <typename T>
+hipError_t Launch<T>::from_f64(const double *src, T *values, int32_t *status, uint64_t n, int def_nan,
+                               hipStream_t stream) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL((from_f64_kernel<T>), grid_stride_for(n), kBlock, 0, stream, src, values, status, n, def_nan);
+  return hipGetLastError();
+}
+
+template <typename T>
+hipError_t Launch<T>::to_f64(const T *values, double *dst, uint64_t n, hipStream_t stream) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL((to_f64_kernel<T>), grid_stride_for(n), kBlock, 0, stream, values, dst, n);
+  return hipGetLastError();
+}
+
+template <typename T>
+hipError_t Launch<T>::fill_seeded(T *values, int32_t *status, uint64_t n, uint64_t first, uint32_t seed, double frac,
+                                  hipStream_t stream) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL((fill_seeded_kernel<T>), grid_stride_for(n), kBlock, 0, stream, values, status, n, first, seed, frac);
+  return hipGetLastError();
+}
+
+template <typename T>
+hipError_t Launch<T>::total(const T *values, const int32_t *status, uint64_t n, int def_nan, double *total,
+                            unsigned long long *count, hipStream_t stream) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL((total_kernel<T>), grid_stride_for(n), kBlock, 0, stream, values, status, n, def_nan, total, count);
+  return hipGetLastError();
+}
+
+template <typename T>
+hipError_t Launch<T>::set_cell(T *values, int32_t *status, uint64_t index, double value, int is_null, int def_nan,
+                               hipStream_t stream) {
+  hipLaunchKernelGGL((set_cell_kernel<T>), 1, 1, 0, stream, values, status, index, value, is_null, def_nan);
+  return hipGetLastError();
+}
+
+#endif  // OLAP_KERNELS_IMPL
+
+}  // namespace olap

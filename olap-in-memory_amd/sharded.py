@@ -1,0 +1,196 @@
+"""Multi-GPU host: one process per GPU, the cube partitioned along its outermost dimension.
+
+Row-major layout makes a dim0 partition a set of contiguous slabs (src/cube.js:709-728: last
+dimension fastest): rank r owns rows [row_lo, row_hi) of dimension 0, i.e. the flat range
+[row_lo*inner0, row_hi*inner0).  Every store operation that leaves dimension 0 alone runs per
+shard with no communication.  drillUp ON dimension 0 (in-memory.js:265-334 with a non-identity
+map on the sharded axis) reduces each rank's own rows into a partial [G, inner0] cube with the
+same kernel and a row sub-map, then ONE collective combines the partials:
+
+  sum      -> reduce-scatter (all-reduce when the output does not divide) with ncclSum over xGMI
+  other    -> all-gather of (value, status) partials, then the same drillUp kernel over the rank
+              axis: highest / lowest / first / last / product are associative in rank order
+
+torch.distributed provides the process group only (backend "nccl" is RCCL on ROCm; with "gloo"
+device tensors are staged through host memory, for rehearsals).  All cell arithmetic goes through
+an engine object; the package ships exactly one, HipEngine (libolapgpu).  CPU tests inject their
+own engine to rehearse the partition/collective logic without a GPU.
+"""
+import numpy as np
+
+from . import capi
+from .hipstore import Plan
+
+
+def partition_rows(n_rows, world):
+    """Contiguous, balanced split of dimension 0: the first (n_rows % world) ranks get one more."""
+    base, extra = divmod(int(n_rows), int(world))
+    bounds = [0]
+    for r in range(world):
+        bounds.append(bounds[-1] + base + (1 if r < extra else 0))
+    return bounds
+
+
+class _HipDrillUp:
+    def __init__(self, engine, plan):
+        self.engine, self.plan = engine, plan
+
+    def run(self, values, status, out_values, out_status):
+        self.plan.run(values.data_ptr(), status.data_ptr() if status is not None else None, out_values.data_ptr(),
+                      out_status.data_ptr() if out_status is not None else None, self.engine.stream())
+
+
+class HipEngine:
+    """Cell arithmetic on the current HIP device; torch tensors are the device-memory plumbing."""
+
+    name = "hip"
+
+    def __init__(self, device):
+        import torch
+
+        self.torch = torch
+        self.device = torch.device(device)
+        if capi.lib().olap_device_count() < 1:
+            raise capi.OlapError(capi.ERR_NO_DEVICE, "no HIP device available: libolapgpu has no CPU fallback")
+        torch.cuda.set_device(self.device)
+
+    def empty(self, n, dtype):
+        t = self.torch
+        td = {"float32": t.float32, "float64": t.float64, "int32": t.int32, "uint32": t.int32}[dtype]
+        return t.empty(max(int(n), 1), dtype=td, device=self.device)[: int(n)]
+
+    def stream(self):
+        return self.torch.cuda.current_stream().cuda_stream
+
+    def make_drillup(self, dtype, default, method, old_len, new_len, maps):
+        return _HipDrillUp(self, Plan.drillup(dtype, default, method, old_len, new_len, maps))
+
+    def fill_seeded(self, values, status, n, first_cell, dtype, seed, frac):
+        capi.check(capi.lib().olap_fill_seeded(values.data_ptr(), status.data_ptr(), int(n), int(first_cell),
+                                               capi.DTYPES[dtype], int(seed), float(frac), self.stream()))
+
+
+class ShardedStore:
+    """One measure of a cube whose dimension 0 is split across the ranks of a process group."""
+
+    def __init__(self, lens, dtype="float32", default=0.0, rank=0, world=1, engine=None, group=None):
+        if engine is None:
+            raise ValueError("an engine is required (HipEngine on a GPU box)")
+        self.lens = [int(x) for x in lens]
+        self.dtype, self.default = dtype, default
+        self.rank, self.world, self.group = int(rank), int(world), group
+        self.engine = engine
+        self.bounds = partition_rows(self.lens[0], self.world)
+        self.row_lo, self.row_hi = self.bounds[self.rank], self.bounds[self.rank + 1]
+        self.inner0 = int(np.prod(self.lens[1:])) if len(self.lens) > 1 else 1
+        self.local_cells = (self.row_hi - self.row_lo) * self.inner0
+        self.values = engine.empty(self.local_cells, dtype)
+        self.status = engine.empty(self.local_cells, "int32")
+
+    @property
+    def local_lens(self):
+        return [self.row_hi - self.row_lo] + self.lens[1:]
+
+    def fill_seeded(self, seed=20240807, frac=1.0):
+        """SURVEY §8(d) synthetic measure; each rank generates its own slab of the global stream."""
+        self.engine.fill_seeded(self.values, self.status, self.local_cells, self.row_lo * self.inner0, self.dtype,
+                                seed, frac)
+        return self
+
+    def drillup_other_axis(self, axis, axis_map, n_groups, method="sum"):
+        """drillUp on a non-sharded axis: per shard, no communication; the partition is kept."""
+        if axis < 1:
+            raise ValueError("use plan_drillup_dim0 for the sharded axis")
+        old_len = self.local_lens
+        new_len = list(old_len)
+        new_len[axis] = int(n_groups)
+        maps = [np.arange(l, dtype=np.uint32) for l in old_len]
+        maps[axis] = np.asarray(axis_map, dtype=np.uint32)
+        out = ShardedStore([self.lens[0]] + new_len[1:], self.dtype, self.default, self.rank, self.world, self.engine,
+                           self.group)
+        op = self.engine.make_drillup(self.dtype, self.default, method, old_len, new_len, maps)
+        op.run(self.values, None, out.values, out.status)
+        out._keepalive = op
+        return out
+
+    def plan_drillup_dim0(self, row_map, n_groups, method="sum"):
+        """Prepares drillUp of the sharded axis: row_map[global row] -> group (< n_groups)."""
+        return Dim0DrillUp(self, row_map, n_groups, method)
+
+
+class Dim0DrillUp:
+    """Reusable step: local partial + one collective.  `step()` is what bench.py times at N > 1."""
+
+    def __init__(self, store, row_map, n_groups, method="sum"):
+        import torch.distributed as dist
+
+        self.dist = dist
+        self.s = s = store
+        self.method = method
+        if method == "average":
+            raise NotImplementedError("sharded average needs (sum, count) partials; not in this round")
+        row_map = np.asarray(row_map, dtype=np.uint32)
+        if row_map.size != s.lens[0]:
+            raise ValueError("row_map must have one entry per row of dimension 0")
+        n_groups = int(n_groups)
+        old_len = s.local_lens
+        new_len = [n_groups] + s.lens[1:]
+        maps = [row_map[s.row_lo:s.row_hi]] + [np.arange(l, dtype=np.uint32) for l in s.lens[1:]]
+        eng = s.engine
+        self.n_out = n_groups * s.inner0
+        self.local = eng.make_drillup(s.dtype, s.default, method, old_len, new_len, maps)
+        self.partial = eng.empty(self.n_out, s.dtype)
+        self.partial_status = eng.empty(self.n_out, "int32")
+        w = s.world
+        self.additive = method == "sum"
+        self.scatter = self.additive and w > 1 and self.n_out % w == 0
+        self.staged = w > 1 and dist.get_backend(s.group) == "gloo" and getattr(self.partial, "is_cuda", False)
+        if w == 1:
+            self.result, self.result_status = self.partial, self.partial_status
+        elif self.additive:
+            self.result = eng.empty(self.n_out // w if self.scatter else self.n_out, s.dtype)
+            self.result_status = None  # sum over a 0 default: set <=> value != 0
+        else:
+            self.gathered = eng.empty(self.n_out * w, s.dtype)
+            self.gathered_status = eng.empty(self.n_out * w, "int32")
+            self.result = eng.empty(self.n_out, s.dtype)
+            self.result_status = eng.empty(self.n_out, "int32")
+            self.combine = eng.make_drillup(s.dtype, s.default, method, [w, self.n_out], [1, self.n_out],
+                                            [np.zeros(w, np.uint32), np.arange(self.n_out, dtype=np.uint32)])
+
+    @property
+    def result_range(self):
+        """Flat range of the global output held in `result` on this rank."""
+        if self.scatter:
+            per = self.n_out // self.s.world
+            return self.s.rank * per, (self.s.rank + 1) * per
+        return 0, self.n_out
+
+    def step(self):
+        s, dist = self.s, self.dist
+        self.local.run(s.values, None, self.partial, self.partial_status)
+        if s.world == 1:
+            return self.result
+        if self.additive:
+            src = self.partial.cpu() if self.staged else self.partial
+            dst = src.new_empty(self.result.numel()) if self.staged else self.result
+            if self.scatter:
+                dist.reduce_scatter_tensor(dst, src, op=dist.ReduceOp.SUM, group=s.group)
+            else:
+                dst.copy_(src)
+                dist.all_reduce(dst, op=dist.ReduceOp.SUM, group=s.group)
+            if self.staged:
+                self.result.copy_(dst)
+            return self.result
+        if self.staged:
+            g = self.partial.cpu().new_empty(self.n_out * s.world)
+            g_st = self.partial_status.cpu().new_empty(self.n_out * s.world)
+            dist.all_gather_into_tensor(g, self.partial.cpu(), group=s.group)
+            dist.all_gather_into_tensor(g_st, self.partial_status.cpu(), group=s.group)
+            self.gathered.copy_(g)
+            self.gathered_status.copy_(g_st)
+        else:
+            dist.all_gather_into_tensor(self.gathered, self.partial, group=s.group)
+            dist.all_gather_into_tensor(self.gathered_status, self.partial_status, group=s.group)
+        self.combine.run(self.gathered, self.gathered_status, self.result, self.result_status)
+        return self.result

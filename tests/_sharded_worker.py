@@ -1,0 +1,88 @@
+"""Worker for tests/test_sharded_gloo.py: one rank of a gloo process group on CPU.
+
+The local cell arithmetic is played by the CPU oracle (test stand-in, injected as the engine) so
+that the partition + collective logic of olap-in-memory_amd/sharded.py can be rehearsed without a
+GPU; with --engine hip (GPU box) the real kernels run and gloo carries the partials."""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(HERE))
+from conftest import load_package  # noqa: E402
+from golden_util import config_cube  # noqa: E402
+from oracle.oracle import OracleStore  # noqa: E402
+
+pkg = load_package()
+from olap_in_memory_amd.sharded import HipEngine, ShardedStore  # noqa: E402
+
+
+class _OracleDrillUp:
+    def __init__(self, dtype, default, method, old_len, new_len, maps):
+        self.a = (dtype, default, method, list(old_len), list(new_len), [np.asarray(m) for m in maps])
+
+    def run(self, values, status, out_values, out_status):
+        dtype, default, method, old_len, new_len, maps = self.a
+        v = values.numpy().astype(np.float64)
+        if status is not None:
+            v = np.where(status.numpy() == 2, v, default)
+        o = OracleStore(v.size, dtype, default)
+        o.set_data(v)
+        tv, ts = o.drill_up(old_len, new_len, maps, method).typed()
+        out_values.copy_(torch.from_numpy(tv.astype(np.float32)))
+        if out_status is not None:
+            out_status.copy_(torch.from_numpy(ts))
+
+
+class OracleEngine:
+    name = "oracle-standin"
+
+    def empty(self, n, dtype):
+        td = {"float32": torch.float32, "int32": torch.int32}[dtype]
+        return torch.empty(int(n), dtype=td)
+
+    def make_drillup(self, *a):
+        return _OracleDrillUp(*a)
+
+    def fill_seeded(self, values, status, n, first_cell, dtype, seed, frac):
+        v, keep = config_cube(first_cell + n, seed, frac)
+        values.copy_(torch.from_numpy(v[first_cell:]))
+        status.copy_(torch.from_numpy(np.where(keep[first_cell:], 2, 0).astype(np.int32)))
+
+
+def main():
+    engine_name, out_path = sys.argv[1], sys.argv[2]
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group(backend="gloo")
+    engine = OracleEngine() if engine_name == "oracle" else HipEngine("cuda:0")
+    results = {}
+    lens = [7, 6, 10]  # 7 rows over 2 ranks: 4 + 3 (ragged split)
+    row_map = np.array([0, 1, 0, 2, 1, 0, 2], np.uint32)
+    for frac in (1.0, 0.4):
+        s = ShardedStore(lens, "float32", 0.0, rank, world, engine).fill_seeded(77, frac)
+        for method in ("sum", "highest", "lowest", "first", "last", "product"):
+            op = s.plan_drillup_dim0(row_map, 3, method)
+            res = op.step()
+            lo, hi = op.result_range
+            if hasattr(res, "is_cuda") and res.is_cuda:
+                torch.cuda.synchronize()
+            results["%s_%s" % (method, frac)] = {"range": [lo, hi], "values": res.cpu().numpy().astype(np.float64).tolist()}
+        # a non-sharded axis: no communication, partition kept
+        o = s.drillup_other_axis(2, np.arange(10) % 2, 2, "sum")
+        if getattr(o.values, "is_cuda", False):
+            torch.cuda.synchronize()
+        results["axis2_%s" % frac] = {"range": [o.row_lo * o.inner0, o.row_hi * o.inner0],
+                                      "values": o.values.cpu().numpy().astype(np.float64).tolist()}
+    with open("%s.%d" % (out_path, rank), "w") as f:
+        json.dump(results, f)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

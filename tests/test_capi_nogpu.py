@@ -1,0 +1,91 @@
+"""CPU-side checks of the C ABI: the library loads, exports every symbol include/olap_hip.h
+declares, and validates arguments before it touches a device (same errors with and without a GPU)."""
+import os
+import re
+
+import pytest
+
+from conftest import ROOT, load_package
+
+pkg = load_package()
+capi = pkg.capi
+
+
+def header_functions():
+    text = open(os.path.join(ROOT, "include", "olap_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    names = re.findall(r"\b(olap_[a-z0-9_]+)\s*\(", text)
+    return sorted(set(names))
+
+
+def test_header_and_binding_agree():
+    declared = header_functions()
+    assert declared, "no declarations found in include/olap_hip.h"
+    assert sorted(capi.SIGNATURES) == declared
+
+
+def test_library_exports_every_declared_symbol():
+    L = capi.lib()
+    for name in header_functions():
+        assert hasattr(L, name), name
+    assert L.olap_abi_version() == 1
+
+
+def test_names_and_sizes():
+    L = capi.lib()
+    for name, code in capi.METHODS.items():
+        assert L.olap_method_from_name(name.encode()) == code
+    assert L.olap_method_from_name(None) == capi.METHODS["sum"]
+    assert L.olap_method_from_name(b"median") == capi.ERR_UNSUPPORTED_METHOD
+    assert capi.last_error() == "Unsupported aggregation method: median"
+    for name, code in capi.DTYPES.items():
+        assert L.olap_dtype_from_name(name.encode()) == code
+        assert L.olap_dtype_size(code) == capi.DTYPE_SIZE[code]
+    assert L.olap_dtype_from_name(b"float16") == capi.ERR_INVALID_TYPE
+    assert capi.last_error() == "Invalid type"
+
+
+def expect(code, message, fn, *args, **kw):
+    with pytest.raises(pkg.OlapError) as ei:
+        fn(*args, **kw)
+    assert ei.value.code == code, (ei.value.code, str(ei.value))
+    if message is not None:
+        assert message in str(ei.value)
+
+
+def test_argument_errors_precede_device_use():
+    """These must be identical on the GPU box: validation happens before any HIP call."""
+    expect(capi.ERR_INVALID_DEFAULT, "Invalid default value, only NaN and 0 are supported", pkg.HipStore, 4, "float32", 1.0)
+    expect(capi.ERR_INVALID_TYPE, "Invalid type", pkg.HipStore, 4, "float16", 0.0)
+    expect(capi.ERR_UNSUPPORTED_METHOD, "Unsupported aggregation method: median", pkg.Plan.drillup,
+           "float32", 0.0, "median", [3], [1], [[0, 0, 0]])
+    expect(capi.ERR_INDEX_RANGE, "outside the new dimension", pkg.Plan.drillup,
+           "float32", 0.0, "sum", [3], [1], [[0, 0, 1]])
+    expect(capi.ERR_INDEX_RANGE, "outside the old dimension", pkg.Plan.dice,
+           "float32", 0.0, [3], [2], [[0, 3]])
+    expect(capi.ERR_INVALID_ARGUMENT, "not a permutation", pkg.Plan.reorder, "float32", 0.0, [3, 2], [0, 0])
+    expect(capi.ERR_INDEX_RANGE, "outside the old dimension", pkg.Plan.drilldown,
+           "float32", 0.0, "sum", [1], [3], [[0, 0, 1]])
+    expect(capi.ERR_INDEX_RANGE, "outside this store's dimension", pkg.Plan.load,
+           "float32", 0.0, 0.0, [2], [2], [[0, 2]])
+
+
+def test_no_cpu_fallback_without_device():
+    if capi.lib().olap_device_count() > 0:
+        pytest.skip("a GPU is present")
+    expect(capi.ERR_NO_DEVICE, "no CPU fallback", pkg.HipStore, 4, "float32", 0.0)
+    expect(capi.ERR_NO_DEVICE, "no CPU fallback", pkg.Plan.drillup, "float32", 0.0, "sum", [3], [1], [[0, 0, 0]])
+
+
+def test_product_does_not_reference_the_oracle():
+    """The product tree must not import, link or open anything under oracle/."""
+    bad = []
+    for base, _dirs, files in os.walk(os.path.join(ROOT, "olap-in-memory_amd")):
+        if os.sep + "build" in base or os.sep + "lib" in base or "__pycache__" in base:
+            continue
+        for f in files:
+            if f.endswith((".py", ".js", ".cc", ".cpp", ".hpp", ".hip", ".h")):
+                text = open(os.path.join(base, f), errors="replace").read()
+                if re.search(r"oracle", text, flags=re.I):
+                    bad.append(os.path.join(base, f))
+    assert not bad, bad

@@ -1,0 +1,232 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle and the golden vectors.
+
+Bit-exact for status masks and integer cells; float cells are compared bit-exactly too, because
+the kernels accumulate in float64 in the reference's order (ascending flat index) and round once.
+Where a golden input was inserted in a shuffled order (the reference's first/last follow Map
+insertion order, which a dense buffer cannot represent), the expectation is the oracle run on the
+same cells inserted ascending; this is stated per assertion below.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import load_package
+from golden_util import GOLDEN, config_cube, dec_num, dec_store, default_of, load_cases
+from oracle.oracle import OracleStore, to_typed
+
+pytestmark = pytest.mark.gpu
+
+pkg = load_package()
+KAT = load_cases("store_kat.json")
+RND = load_cases("store_random.json")
+CFG = load_cases("configs.json")
+
+
+def is_default_typed(vals, type_name, default_is_nan):
+    if type_name in ("float32", "float64"):
+        return np.isnan(vals) if default_is_nan else (vals == 0)
+    return np.zeros(vals.shape, dtype=bool) if default_is_nan else (vals == 0)
+
+
+def expected_typed(ostore):
+    """Oracle store -> (typed values with the default in unset cells, Int32 status mask)."""
+    vals, pres = ostore.dense()
+    t = to_typed(vals, ostore.type)
+    nan = ostore.default_is_nan
+    pres = pres & ~is_default_typed(t, ostore.type, nan)
+    if ostore.type in ("float32", "float64"):
+        dflt = np.nan if nan else 0.0
+    else:
+        dflt = 0
+    t = np.where(pres, t, np.asarray(dflt, dtype=t.dtype))
+    return t, np.where(pres, 2, 0).astype(np.int32)
+
+
+def same_typed(a, b):
+    if a.dtype.kind == "f":
+        u = {4: np.uint32, 8: np.uint64}[a.dtype.itemsize]
+        nan = np.isnan(a) & np.isnan(b)
+        return bool(np.all(nan | (a.view(u) == b.view(u))))
+    return bool(np.array_equal(a, b))
+
+
+def dense_input(case, key="in", default_key="default"):
+    """Golden store dump -> float64 dense array with NaN/0 default in unset cells, ascending."""
+    size, keys, vals = dec_store(case[key])
+    d = default_of(case, default_key)
+    dense = np.full(size, d, dtype=np.float64)
+    dense[keys.astype(np.int64)] = vals
+    ascending = bool(np.all(np.diff(keys.astype(np.int64)) > 0)) if len(keys) > 1 else True
+    return dense, ascending
+
+
+def both_stores(case, key="in", default_key="default"):
+    dense, ascending = dense_input(case, key, default_key)
+    d = default_of(case, default_key)
+    # the typed store holds TypedArray-converted cells; the oracle gets the same cells
+    typed = to_typed(dense, case["type"]).astype(np.float64)
+    if case["type"] in ("int32", "uint32") and d != d:
+        typed = np.where(np.isnan(dense), np.nan, typed)
+    o = OracleStore(len(dense), case["type"], d)
+    o.set_data(typed)
+    g = pkg.HipStore(len(dense), case["type"], d)
+    g.set_data_f64(dense)
+    return o, g, ascending
+
+
+def run_both(case):
+    o, g, ascending = both_stores(case)
+    op = case["op"]
+    if op == "drillUp":
+        args = (case["oldLen"], case["newLen"], case["maps"], case["method"])
+        return o.drill_up(*args), g.drill_up(*args), ascending
+    if op == "drillDown":
+        dist = [dec_num(x) for x in case["distributions"]] if case.get("distributions") is not None else None
+        args = (case["oldLen"], case["newLen"], case["maps"], case["method"], dist)
+        return o.drill_down(*args), g.drill_down(*args), ascending
+    if op == "dice":
+        args = (case["oldLen"], case["newLen"], case["sel"])
+        return o.dice(*args), g.dice(*args), ascending
+    if op == "reorder":
+        args = (case["oldLen"], case["perm"])
+        return o.reorder(*args), g.reorder(*args), ascending
+    if op == "load":
+        ho, hg, _ = both_stores(case, "his", "hisDefault")
+        o.load(ho, case["myLen"], case["hisLen"], case["hisToMine"])
+        g.load(hg, case["myLen"], case["hisLen"], case["hisToMine"])
+        return o, g, ascending
+    raise AssertionError(op)
+
+
+@pytest.mark.parametrize("case", KAT + RND, ids=lambda c: c["name"])
+def test_hip_matches_oracle_and_golden(case):
+    if "throws" in case:
+        with pytest.raises(pkg.OlapError, match=case["throws"]):
+            run_both(case)
+        return
+    o, g, ascending = run_both(case)
+    ev, es = expected_typed(o)
+    gv, gs = g.get_data(), g.get_status()
+    assert g.size == o.size
+    assert np.array_equal(gs, es), "status mask differs from the oracle"
+    assert same_typed(gv, ev), f"values differ from the oracle: {gv[:8]} vs {ev[:8]}"
+    assert np.array_equal(g.keys(), np.nonzero(es)[0])
+    # direct comparison with the reference's own output (no oracle in between) whenever the
+    # reference's Map was filled in ascending order and the case does not hinge on values the
+    # typed store cannot hold
+    if ascending and case["op"] != "load":
+        size, keys, vals = dec_store(case["out"])
+        ref = OracleStore(size, case["type"], default_of(case))
+        for k, v in zip(keys, vals):
+            ref.set(int(k), float(v))
+        rv, rs = expected_typed(ref)
+        assert np.array_equal(gs, rs) and same_typed(gv, rv), "differs from the reference's golden output"
+
+
+def test_store_accessors():
+    s = pkg.HipStore(6, "float32", 0.0)
+    assert s.size == 6 and s.byte_length == 24 and s.type == "float32"
+    assert np.array_equal(s.get_data(), np.zeros(6, np.float32)) and s.count_set() == 0
+    s.set_data(np.array([1, 2, 0, 8, 16, 32], np.float32))
+    assert s.count_set() == 5 and s.total == 59
+    assert s.get_value(3) == (8.0, True) and s.get_value(2) == (0.0, False)
+    s.set_value(2, 4)
+    s.set_value(0, None)
+    assert np.array_equal(s.get_data(), np.array([0, 2, 4, 8, 16, 32], np.float32))
+    assert np.array_equal(s.keys(), [1, 2, 3, 4, 5])
+    c = s.clone()
+    s.fill(7)
+    assert np.array_equal(s.get_data(), np.full(6, 7, np.float32)) and s.count_set() == 6
+    assert np.array_equal(c.get_data(), np.array([0, 2, 4, 8, 16, 32], np.float32))
+    with pytest.raises(pkg.OlapError, match="value length is invalid: 6 !== 5"):
+        s.set_data(np.zeros(5, np.float32))
+    n = pkg.HipStore(3, "float32", float("nan"))
+    assert np.all(np.isnan(n.get_data())) and n.count_set() == 0
+    n.set_value(1, 0.0)
+    assert n.get_value(1) == (0.0, True) and np.isnan(n.get_value(0)[0])
+    u = pkg.HipStore(3, "uint32", float("nan"))
+    u.set_data_f64([5, float("nan"), 0])
+    assert np.array_equal(u.get_status(), [2, 0, 2])
+    assert np.array_equal(u.get_data(), np.array([5, 0, 0], np.uint32))
+    f = u.get_data_f64()
+    assert f[0] == 5 and np.isnan(f[1]) and f[2] == 0
+
+
+@pytest.mark.parametrize("case", CFG, ids=lambda c: c["name"])
+def test_configs_against_reference_output(case):
+    """BASELINE.json configs 1 (10^3) and 2 (10^6): device-generated cube, drillUp(sum) to 'all' on
+    one axis, compared with the output of the reference itself (tests/golden/config*.f32)."""
+    lens, axis = case["lens"], case["axis"]
+    n = int(np.prod(lens))
+    vals, keep = config_cube(n, case["seed"], case["frac"])
+    s = pkg.HipStore(n, "float32", 0.0)
+    # the on-device generator must produce the same cube as the golden generator
+    pkg.capi.check(pkg.lib().olap_fill_seeded(s.values_ptr, s.status_ptr, n, 0, 2, case["seed"], case["frac"], None))
+    pkg.capi.check(pkg.lib().olap_device_synchronize())
+    assert np.array_equal(s.get_data(), vals) and np.array_equal(s.get_status() == 2, keep)
+    new_len = list(lens)
+    new_len[axis] = 1
+    maps = [np.zeros(l, np.uint32) if i == axis else np.arange(l, dtype=np.uint32) for i, l in enumerate(lens)]
+    out = s.drill_up(lens, new_len, maps, "sum")
+    assert out.count_set() == case["outKeys"]
+    if "out" in case:
+        ref32 = np.asarray([dec_num(x) for x in case["out"]], dtype=np.float64).astype(np.float32)
+        refp = ref32 != 0
+    else:
+        ref32 = np.fromfile(os.path.join(GOLDEN, case["name"] + ".f32"), dtype=np.float32)
+        refp = np.fromfile(os.path.join(GOLDEN, case["name"] + ".present.u8"), dtype=np.uint8).astype(bool)
+    assert np.array_equal(out.get_status() == 2, refp)
+    assert np.array_equal(out.get_data(), ref32)  # bit-exact vs Math.fround(reference)
+
+
+def test_plan_on_raw_pointers_and_mask_paths():
+    """The plan API on raw device pointers, with and without an input mask, gives the same cells."""
+    lens = [7, 12, 20]
+    n = int(np.prod(lens))
+    vals, keep = config_cube(n, 99, 0.5)
+    s = pkg.HipStore(n, "float32", 0.0)
+    s.set_data(vals)
+    gmap = (np.arange(12) % 5).astype(np.uint32)
+    maps = [np.arange(7, dtype=np.uint32), gmap, np.arange(20, dtype=np.uint32)]
+    for method in ("sum", "average", "highest", "lowest", "first", "last", "product"):
+        plan = pkg.Plan.drillup("float32", 0.0, method, lens, [7, 5, 20], maps)
+        a = pkg.HipStore(plan.out_cells, "float32", 0.0)
+        b = pkg.HipStore(plan.out_cells, "float32", 0.0)
+        plan.run(s.values_ptr, None, a.values_ptr, a.status_ptr)
+        plan.run(s.values_ptr, s.status_ptr, b.values_ptr, b.status_ptr)
+        pkg.capi.check(pkg.lib().olap_device_synchronize())
+        assert same_typed(a.get_data(), b.get_data()) and np.array_equal(a.get_status(), b.get_status())
+        o = OracleStore(n, "float32", 0.0)
+        o.set_data(vals.astype(np.float64))
+        ev, es = expected_typed(o.drill_up(lens, [7, 5, 20], maps, method))
+        assert same_typed(a.get_data(), ev) and np.array_equal(a.get_status(), es), method
+
+
+@pytest.mark.parametrize("shape,axis", [([10] * 8, 0), ([10] * 8, 4), ([10] * 8, 7), ([3652, 100, 274], 0), ([120, 100, 274], 1)])
+def test_full_size_properties(shape, axis):
+    """BASELINE.json's full sizes (10^8 cells): independent float64 recomputation with numpy in the
+    same accumulation order (bit-exact), plus total preservation."""
+    n = int(np.prod(shape))
+    s = pkg.HipStore(n, "float32", 0.0)
+    pkg.capi.check(pkg.lib().olap_fill_seeded(s.values_ptr, s.status_ptr, n, 0, 2, 20240807, 1.0, None))
+    K = shape[axis]
+    if shape[0] == 3652 and axis == 0:  # day -> month style contiguous runs of ~30
+        gmap = (np.arange(K) // 31).astype(np.uint32)
+    elif K == 100:
+        gmap = (np.arange(K) % 10).astype(np.uint32)  # interleaved groups
+    else:
+        gmap = np.zeros(K, np.uint32)
+    G = int(gmap.max()) + 1
+    new_len = list(shape)
+    new_len[axis] = G
+    maps = [gmap if i == axis else np.arange(l, dtype=np.uint32) for i, l in enumerate(shape)]
+    out = s.drill_up(shape, new_len, maps, "sum")
+    got = out.get_data()
+    x = s.get_data().reshape(int(np.prod(shape[:axis])), K, int(np.prod(shape[axis + 1:])))
+    ref = np.zeros((x.shape[0], G, x.shape[2]), dtype=np.float64)
+    for k in range(K):  # ascending k == the reference's accumulation order
+        ref[:, gmap[k], :] += x[:, k, :]
+    assert np.array_equal(got, ref.astype(np.float32).ravel())
+    assert np.all(out.get_status() == 2)
+    assert abs(out.total - s.total) <= 1e-6 * s.total
