@@ -268,7 +268,7 @@ extern "C" int olap_drillup_plan(olap_plan **out, int dtype, int default_kind, i
     }
     a.gstart = (const uint32_t *)p->dev_tab;
     a.order = contiguous ? nullptr : (const uint32_t *)p->dev_tab + order_off;
-    p->kernel_name = "drillup_direct";
+    p->kernel_name = (a.inner / (uint64_t)p->vec >= 128) ? "drillup_rows_kernel" : "drillup_flat_kernel";
   } else {
     p->kind = PLAN_DRILLUP_GENERIC;
     DrillUpGeneric &g = p->gen;
@@ -318,7 +318,7 @@ extern "C" int olap_drillup_plan(olap_plan **out, int dtype, int default_kind, i
       return rc;
     }
     g.tab = (const uint32_t *)p->dev_tab;
-    p->kernel_name = "drillup_generic";
+    p->kernel_name = "drillup_generic_kernel";
   }
   *out = p;
   return OLAP_OK;
@@ -639,6 +639,7 @@ static int run_typed(olap_plan *p, const void *in_v, const int32_t *in_s, void *
       if (!(aligned16(in) && aligned16(out) && (!in_s || aligned16(in_s)) && (!out_s || aligned16(out_s)))) vec = 1;
       a.n_vec = a.inner / (uint64_t)vec;
       a.total = a.outer * a.G * a.n_vec;
+      a.blocks_per_row = (a.n_vec + kBlock - 1) / kBlock;
       e = Launch<T>::drillup_axis(p->method, hs, vec, in, in_s, out, out_s, a, stream);
       break;
     }
@@ -781,13 +782,22 @@ extern "C" int olap_total(const void *values, const int32_t *status, uint64_t n,
 }
 
 // ------------------------------------------------------------------ store handles
+// values are always resident.  The Int32 mask is materialised lazily: for float cells and for a
+// zero default it is a pure function of the values (set <=> value != default, in-memory.js:122-133),
+// so bulk operations neither read nor write it and it is built on first request
+// (olap_store_get_status / _status_ptr / _get_keys).  Integer cells under a NaN default are the one
+// case where the mask carries information of its own; such stores always hold it.
 struct olap_store {
   uint64_t size;
   int dtype;
   int default_kind;
   void *values;
-  int32_t *status;
+  mutable int32_t *status;  // nullptr until needed (see above)
 };
+
+static bool mask_is_primary(const olap_store *s) {
+  return s->default_kind == OLAP_DEFAULT_NAN && (s->dtype == OLAP_INT32 || s->dtype == OLAP_UINT32);
+}
 
 static int store_alloc(olap_store **out, uint64_t size, int dtype, int default_kind) {
   olap_store *s = new (std::nothrow) olap_store();
@@ -799,7 +809,7 @@ static int store_alloc(olap_store **out, uint64_t size, int dtype, int default_k
   s->status = nullptr;
   const size_t vb = (size ? size : 1) * olap_dtype_size(dtype), sb = (size ? size : 1) * sizeof(int32_t);
   hipError_t e = hipMalloc(&s->values, vb);
-  if (e == hipSuccess) e = hipMalloc((void **)&s->status, sb);
+  if (e == hipSuccess && mask_is_primary(s)) e = hipMalloc((void **)&s->status, sb);
   if (e != hipSuccess) {
     if (s->values) (void)hipFree(s->values);
     delete s;
@@ -809,17 +819,29 @@ static int store_alloc(olap_store **out, uint64_t size, int dtype, int default_k
   return OLAP_OK;
 }
 
-// every cell unset: status 0, values = default
+// builds the mask from the values when it has not been materialised yet
+static int ensure_status(const olap_store *s) {
+  if (s->status) return OLAP_OK;
+  int32_t *st = nullptr;
+  HIP_TRY(hipMalloc((void **)&st, (s->size ? s->size : 1) * sizeof(int32_t)));
+  s->status = st;
+  int rc = olap_canonicalize(s->values, s->status, s->size, s->dtype, s->default_kind, 0, nullptr);
+  if (rc) return rc;
+  HIP_TRY(hipStreamSynchronize(nullptr));
+  return OLAP_OK;
+}
+
+// every cell unset: values = default (and an all-zero mask where the mask is primary)
 static int store_clear(olap_store *s) {
-  HIP_TRY(hipMemsetAsync(s->status, 0, (s->size ? s->size : 1) * sizeof(int32_t), nullptr));
+  const size_t n1 = s->size ? s->size : 1;
+  if (s->status) HIP_TRY(hipMemsetAsync(s->status, 0, n1 * sizeof(int32_t), nullptr));
   const bool fnan = s->default_kind == OLAP_DEFAULT_NAN && (s->dtype == OLAP_FLOAT32 || s->dtype == OLAP_FLOAT64);
   if (!fnan) {
-    HIP_TRY(hipMemsetAsync(s->values, 0, (s->size ? s->size : 1) * olap_dtype_size(s->dtype), nullptr));
-  } else {
-    // canonicalize with an all-zero mask writes the NaN default everywhere
-    hipError_t e = hipSuccess;
-    DISPATCH_DTYPE(s->dtype, e = Launch<T>::canonicalize((T *)s->values, s->status, s->size, 1, 1, nullptr));
-    if (e != hipSuccess) return hip_fail(e, "store_clear");
+    HIP_TRY(hipMemsetAsync(s->values, 0, n1 * olap_dtype_size(s->dtype), nullptr));
+  } else if (s->size) {
+    // one NaN cell, then doubling device-to-device copies
+    int rc = olap_store_fill(s, NAN);
+    if (rc) return rc;
   }
   HIP_TRY(hipStreamSynchronize(nullptr));
   return OLAP_OK;
@@ -856,7 +878,7 @@ extern "C" int olap_store_clone(const olap_store *s, olap_store **out) {
   int rc = store_alloc(&c, s->size, s->dtype, s->default_kind);
   if (rc) return rc;
   hipError_t e = hipMemcpy(c->values, s->values, s->size * olap_dtype_size(s->dtype), hipMemcpyDeviceToDevice);
-  if (e == hipSuccess) e = hipMemcpy(c->status, s->status, s->size * sizeof(int32_t), hipMemcpyDeviceToDevice);
+  if (e == hipSuccess && c->status) e = hipMemcpy(c->status, s->status, s->size * sizeof(int32_t), hipMemcpyDeviceToDevice);
   if (e != hipSuccess) {
     olap_store_destroy(c);
     return hip_fail(e, "store_clone");
@@ -870,7 +892,10 @@ extern "C" int olap_store_dtype(const olap_store *s) { return s ? s->dtype : -1;
 extern "C" int olap_store_default(const olap_store *s) { return s ? s->default_kind : -1; }
 extern "C" uint64_t olap_store_byte_length(const olap_store *s) { return s ? s->size * olap_dtype_size(s->dtype) : 0; }
 extern "C" void *olap_store_values_ptr(const olap_store *s) { return s ? s->values : nullptr; }
-extern "C" int32_t *olap_store_status_ptr(const olap_store *s) { return s ? s->status : nullptr; }
+extern "C" int32_t *olap_store_status_ptr(const olap_store *s) {
+  if (!s || ensure_status(s)) return nullptr;
+  return s->status;
+}
 
 static int check_length(const olap_store *s, uint64_t n) {
   if (!s) return fail(OLAP_ERR_INVALID_ARGUMENT, "store is NULL");
@@ -879,11 +904,20 @@ static int check_length(const olap_store *s, uint64_t n) {
   return OLAP_OK;
 }
 
+// a bulk write replaces every cell: a lazily built mask is dropped, a primary one is rewritten
+static void drop_lazy_status(olap_store *s) {
+  if (s->status && !mask_is_primary(s)) {
+    (void)hipFree(s->status);
+    s->status = nullptr;
+  }
+}
+
 extern "C" int olap_store_set_data(olap_store *s, const void *host_values, uint64_t n) {
   int rc = check_length(s, n);
   if (rc) return rc;
   if (n && !host_values) return fail(OLAP_ERR_INVALID_ARGUMENT, "values is NULL");
   if (n == 0) return OLAP_OK;
+  drop_lazy_status(s);
   HIP_TRY(hipMemcpy(s->values, host_values, n * olap_dtype_size(s->dtype), hipMemcpyHostToDevice));
   if ((rc = olap_canonicalize(s->values, s->status, n, s->dtype, s->default_kind, 0, nullptr))) return rc;
   HIP_TRY(hipStreamSynchronize(nullptr));
@@ -895,6 +929,7 @@ extern "C" int olap_store_set_data_f64(olap_store *s, const double *host_values,
   if (rc) return rc;
   if (n && !host_values) return fail(OLAP_ERR_INVALID_ARGUMENT, "values is NULL");
   if (n == 0) return OLAP_OK;
+  drop_lazy_status(s);
   double *tmp = nullptr;
   HIP_TRY(hipMalloc((void **)&tmp, n * sizeof(double)));
   hipError_t e = hipMemcpy(tmp, host_values, n * sizeof(double), hipMemcpyHostToDevice);
@@ -938,6 +973,8 @@ extern "C" int olap_store_get_data_f64(const olap_store *s, double *host_values)
 
 extern "C" int olap_store_get_status(const olap_store *s, int32_t *host_status) {
   if (!s || (s->size && !host_status)) return fail(OLAP_ERR_INVALID_ARGUMENT, "store/status is NULL");
+  int rc = ensure_status(s);
+  if (rc) return rc;
   if (s->size) HIP_TRY(hipMemcpy(host_status, s->status, s->size * sizeof(int32_t), hipMemcpyDeviceToHost));
   return OLAP_OK;
 }
@@ -949,6 +986,8 @@ extern "C" int olap_store_count_set(const olap_store *s, uint64_t *n_set) {
 
 extern "C" int olap_store_get_keys(const olap_store *s, uint64_t *host_keys, uint64_t cap, uint64_t *n_keys) {
   if (!s || !n_keys) return fail(OLAP_ERR_INVALID_ARGUMENT, "store is NULL");
+  int rc = ensure_status(s);
+  if (rc) return rc;
   std::vector<int32_t> st(s->size ? s->size : 1);
   if (s->size) HIP_TRY(hipMemcpy(st.data(), s->status, s->size * sizeof(int32_t), hipMemcpyDeviceToHost));
   uint64_t n = 0;
@@ -968,8 +1007,8 @@ extern "C" int olap_store_get_value(const olap_store *s, uint64_t index, double 
     if (is_set) *is_set = 0;
     return OLAP_OK;
   }
-  int32_t st = 0;
-  HIP_TRY(hipMemcpy(&st, s->status + index, sizeof(st), hipMemcpyDeviceToHost));
+  int32_t st = OLAP_STATUS_SET;
+  if (s->status) HIP_TRY(hipMemcpy(&st, s->status + index, sizeof(st), hipMemcpyDeviceToHost));
   double v = 0;
   const size_t es = olap_dtype_size(s->dtype);
   unsigned char raw[8];
@@ -980,7 +1019,11 @@ extern "C" int olap_store_get_value(const olap_store *s, uint64_t index, double 
     case OLAP_FLOAT32: { float x; memcpy(&x, raw, 4); v = x; break; }
     default: memcpy(&v, raw, 8);
   }
-  const bool set = (st & OLAP_STATUS_SET) != 0;
+  bool set = (st & OLAP_STATUS_SET) != 0;
+  if (!mask_is_primary(s)) {  // set <=> value != default
+    const bool is_float = s->dtype == OLAP_FLOAT32 || s->dtype == OLAP_FLOAT64;
+    set = set && (s->default_kind == OLAP_DEFAULT_NAN ? !(is_float && v != v) : v != 0.0);
+  }
   if (value) *value = set ? v : (s->default_kind == OLAP_DEFAULT_NAN ? NAN : 0.0);
   if (is_set) *is_set = set;
   return OLAP_OK;
@@ -1000,6 +1043,7 @@ extern "C" int olap_store_fill(olap_store *s, double value) {
   if (!s) return fail(OLAP_ERR_INVALID_ARGUMENT, "store is NULL");
   if (!s->size) return OLAP_OK;
   // fill = setValue(i, value) for every i (:135-137): one converted cell, broadcast
+  drop_lazy_status(s);
   std::vector<double> one(1, value);
   double *tmp = nullptr;
   HIP_TRY(hipMalloc((void **)&tmp, sizeof(double)));
@@ -1016,7 +1060,7 @@ extern "C" int olap_store_fill(olap_store *s, double value) {
   while (done < s->size) {
     const uint64_t n = std::min(done, s->size - done);
     HIP_TRY(hipMemcpyAsync((char *)s->values + done * es, s->values, n * es, hipMemcpyDeviceToDevice, nullptr));
-    HIP_TRY(hipMemcpyAsync(s->status + done, s->status, n * sizeof(int32_t), hipMemcpyDeviceToDevice, nullptr));
+    if (s->status) HIP_TRY(hipMemcpyAsync(s->status + done, s->status, n * sizeof(int32_t), hipMemcpyDeviceToDevice, nullptr));
     done += n;
   }
   HIP_TRY(hipStreamSynchronize(nullptr));
@@ -1030,10 +1074,7 @@ extern "C" int olap_store_total(const olap_store *s, double *total) {
 
 // Integer cells under a NaN default are the one case where the mask carries information the
 // values cannot; everywhere else the kernels derive "set" from the value and skip the mask read.
-static const int32_t *mask_needed(const olap_store *s) {
-  const bool int_nan = s->default_kind == OLAP_DEFAULT_NAN && (s->dtype == OLAP_INT32 || s->dtype == OLAP_UINT32);
-  return int_nan ? s->status : nullptr;
-}
+static const int32_t *mask_needed(const olap_store *s) { return mask_is_primary(s) ? s->status : nullptr; }
 
 static int run_to_new_store(olap_plan *plan, const olap_store *in, olap_store **out) {
   olap_store *o = nullptr;
@@ -1127,6 +1168,7 @@ extern "C" int olap_store_load(olap_store *s, const olap_store *other, int ndim,
     olap_plan_destroy(plan);
     return fail(OLAP_ERR_LENGTH_MISMATCH, "load: store sizes do not match the dimensions");
   }
+  drop_lazy_status(s);
   rc = olap_plan_run(plan, other->values, mask_needed(other), s->values, s->status, nullptr);
   if (!rc) {
     hipError_t e = hipStreamSynchronize(nullptr);

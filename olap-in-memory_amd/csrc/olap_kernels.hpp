@@ -21,22 +21,125 @@ constexpr int kMaxDims = 12;  // collapsed dimensions a plan may keep (see plan.
 struct DrillUpAxis {
   uint64_t outer, K, inner, G;
   uint64_t n_vec;         // inner / VEC
-  uint64_t total;         // outer * G * n_vec  (threads needed)
+  uint64_t total;         // outer * G * n_vec  (threads needed, flat regime)
+  uint64_t blocks_per_row;// ceil(n_vec / kBlock)     (row regime)
   const uint32_t *order;  // device
   const uint32_t *gstart; // device
   int def_nan;
 };
 
-// Direct regime: lanes run along `inner` (contiguous), each lane owns VEC adjacent output
-// cells of one (outer, group) pair and walks that group's rows in ascending order, which is the
-// reference's accumulation order, so float64 sums are bit-identical.  Loads of one wave are
-// VEC*4*64 contiguous bytes; U rows are kept in flight per lane.
-template <typename T, int METHOD, bool HAS_STATUS, int VEC, int U>
-__global__ __launch_bounds__(kBlock) void drillup_direct_kernel(const T *__restrict__ in,
-                                                                const int32_t *__restrict__ st_in,
-                                                                T *__restrict__ out,
-                                                                int32_t *__restrict__ st_out,
-                                                                const DrillUpAxis a) {
+// Accumulates one loaded row vector into the per-lane aggregates.
+template <typename T, int METHOD, bool HAS_STATUS, int VEC, bool FAST>
+__device__ __forceinline__ void accumulate_row(Agg<METHOD> (&agg)[VEC], const Vec<T, VEC> &v,
+                                               const Vec<int32_t, VEC> &s, bool def_nan) {
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) {
+    const T x = v.v[e];
+    if constexpr (FAST) {
+      // sum/average over a zero default without a mask: an unset cell holds 0 and adding it
+      // changes nothing; the reference's "restart when the running sum hits 0" is invisible
+      // for addition, so the plain float64 running sum is exact.
+      agg[e].acc += Cell<T>::to_f64(x);
+      if constexpr (METHOD == OLAP_AVERAGE) agg[e].count += Cell<T>::is_default(x, false) ? 0u : 1u;
+    } else {
+      const int32_t sx = HAS_STATUS ? s.v[e] : OLAP_STATUS_SET;
+      if (cell_is_set<T>(x, sx, HAS_STATUS, def_nan)) agg[e].add(Cell<T>::to_f64(x), def_nan);
+    }
+  }
+}
+
+template <typename T, int METHOD, int VEC, bool FAST, bool NT = false>
+__device__ __forceinline__ void finish_and_store(Agg<METHOD> (&agg)[VEC], bool def_nan, T *out, int32_t *st_out,
+                                                 uint64_t oidx) {
+  Vec<T, VEC> ov;
+  Vec<int32_t, VEC> os;
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) {
+    if constexpr (FAST) {
+      // presence for the fast form: any contribution <=> sum of positive counts; for `sum` the
+      // output is set iff the sum is not the default (0), which also covers "nothing contributed"
+      agg[e].has = agg[e].acc != 0.0;
+      if constexpr (METHOD == OLAP_AVERAGE) agg[e].has = agg[e].has && agg[e].count != 0;
+    }
+    agg[e].finish(def_nan);
+    emit_cell<T>(agg[e].acc, agg[e].has, def_nan, ov.v[e], os.v[e]);
+  }
+  if constexpr (NT) {
+    store_stream<T, VEC>(out + oidx, ov);
+    if (st_out) store_stream<int32_t, VEC>(st_out + oidx, os);
+  } else {
+    store_vec<T, VEC>(out + oidx, ov);
+    if (st_out) store_vec<int32_t, VEC>(st_out + oidx, os);
+  }
+}
+
+// Row regime (inner large): a workgroup owns kBlock adjacent VEC-wide slots of ONE (outer, group)
+// pair, so the group bounds, the member list and every loop condition are wave-uniform (scalar
+// loads and branches) and each wave-instruction reads VEC*sizeof(T)*64 contiguous bytes.  A lane
+// walks its group's rows in ascending order — the reference's accumulation order, so the float64
+// running sums are bit-identical — with U independent row loads in flight.
+template <typename T, int METHOD, bool HAS_STATUS, int VEC, int U, bool CONTIG, bool FAST, bool NT = true>
+__global__ __launch_bounds__(kBlock) void drillup_rows_kernel(const T *__restrict__ in,
+                                                              const int32_t *__restrict__ st_in,
+                                                              T *__restrict__ out,
+                                                              int32_t *__restrict__ st_out,
+                                                              const DrillUpAxis a) {
+  // blocks_per_row = ceil(n_vec / kBlock); blockIdx.x = og * blocks_per_row + chunk  (uniform math)
+  const uint32_t bpr = (uint32_t)a.blocks_per_row;
+  const uint64_t og = blockIdx.x / bpr;
+  const uint32_t chunk = blockIdx.x - (uint32_t)og * bpr;
+  const uint64_t g = og % a.G;
+  const uint64_t o = og / a.G;
+  const uint64_t iv = (uint64_t)chunk * kBlock + threadIdx.x;
+  if (iv >= a.n_vec) return;
+  const uint64_t i0 = iv * VEC;
+  const bool def_nan = a.def_nan != 0;
+
+  const T *base = in + (o * a.K) * a.inner + i0;
+  const int32_t *sbase = HAS_STATUS ? st_in + (o * a.K) * a.inner + i0 : nullptr;
+  uint32_t j = a.gstart[g];
+  const uint32_t jend = a.gstart[g + 1];
+
+  Agg<METHOD> agg[VEC];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) agg[e].init();
+
+  Vec<T, VEC> v[U];
+  Vec<int32_t, VEC> s[U];
+  for (; j + U <= jend; j += U) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint64_t k = CONTIG ? (uint64_t)(j + u) : (uint64_t)a.order[j + u];
+      v[u] = NT ? load_stream<T, VEC>(base + k * a.inner) : load_vec<T, VEC>(base + k * a.inner);
+      if constexpr (HAS_STATUS) s[u] = NT ? load_stream<int32_t, VEC>(sbase + k * a.inner) : load_vec<int32_t, VEC>(sbase + k * a.inner);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) accumulate_row<T, METHOD, HAS_STATUS, VEC, FAST>(agg, v[u], s[u], def_nan);
+  }
+  const uint32_t rest = jend - j;  // < U, wave-uniform
+  if (rest) {
+#pragma unroll
+    for (int u = 0; u < U - 1; ++u) {
+      if ((uint32_t)u < rest) {
+        const uint64_t k = CONTIG ? (uint64_t)(j + u) : (uint64_t)a.order[j + u];
+        v[u] = NT ? load_stream<T, VEC>(base + k * a.inner) : load_vec<T, VEC>(base + k * a.inner);
+        if constexpr (HAS_STATUS) s[u] = NT ? load_stream<int32_t, VEC>(sbase + k * a.inner) : load_vec<int32_t, VEC>(sbase + k * a.inner);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U - 1; ++u)
+      if ((uint32_t)u < rest) accumulate_row<T, METHOD, HAS_STATUS, VEC, FAST>(agg, v[u], s[u], def_nan);
+  }
+  finish_and_store<T, METHOD, VEC, FAST, NT>(agg, def_nan, out, st_out, (o * a.G + g) * a.inner + i0);
+}
+
+// Flat regime (inner small): one lane per VEC output cells, (outer, group) decoded per lane.
+template <typename T, int METHOD, bool HAS_STATUS, int VEC, bool FAST>
+__global__ __launch_bounds__(kBlock) void drillup_flat_kernel(const T *__restrict__ in,
+                                                              const int32_t *__restrict__ st_in,
+                                                              T *__restrict__ out,
+                                                              int32_t *__restrict__ st_out,
+                                                              const DrillUpAxis a) {
   const uint64_t t = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
   if (t >= a.total) return;
   const uint64_t iv = t % a.n_vec;
@@ -51,57 +154,30 @@ __global__ __launch_bounds__(kBlock) void drillup_direct_kernel(const T *__restr
   uint32_t j = a.gstart[g];
   const uint32_t jend = a.gstart[g + 1];
 
-  // Fast form for sum/average over a zero default without a mask: an unset cell holds 0, adding
-  // it changes nothing, and the "restart after the running sum hits 0" of the reference is
-  // invisible for addition.  Otherwise the exact state machine of Agg<> runs.
-  constexpr bool kAdditive = (METHOD == OLAP_SUM || METHOD == OLAP_AVERAGE);
-  const bool fast = kAdditive && !HAS_STATUS && !def_nan;
-
   Agg<METHOD> agg[VEC];
 #pragma unroll
   for (int e = 0; e < VEC; ++e) agg[e].init();
-
+  constexpr int U = 4;
   for (; j < jend; j += U) {
     const uint32_t n = (jend - j) < (uint32_t)U ? (jend - j) : (uint32_t)U;
+    uint64_t k[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint32_t jj = (uint32_t)u < n ? j + u : j;  // clamp: re-reads a valid row, result unused
+      k[u] = a.order ? (uint64_t)a.order[jj] : (uint64_t)jj;
+    }
     Vec<T, VEC> v[U];
     Vec<int32_t, VEC> s[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      if ((uint32_t)u < n) {
-        const uint64_t k = a.order ? a.order[j + u] : (uint64_t)(j + u);
-        v[u] = load_vec<T, VEC>(base + k * a.inner);
-        if constexpr (HAS_STATUS) s[u] = load_vec<int32_t, VEC>(sbase + k * a.inner);
-      }
+      v[u] = load_vec<T, VEC>(base + k[u] * a.inner);
+      if constexpr (HAS_STATUS) s[u] = load_vec<int32_t, VEC>(sbase + k[u] * a.inner);
     }
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      if ((uint32_t)u < n) {
-#pragma unroll
-        for (int e = 0; e < VEC; ++e) {
-          const T x = v[u].v[e];
-          if (fast) {
-            agg[e].acc += Cell<T>::to_f64(x);
-            agg[e].count += Cell<T>::is_default(x, false) ? 0u : 1u;
-          } else {
-            const int32_t sx = HAS_STATUS ? s[u].v[e] : OLAP_STATUS_SET;
-            if (cell_is_set<T>(x, sx, HAS_STATUS, def_nan)) agg[e].add(Cell<T>::to_f64(x), def_nan);
-          }
-        }
-      }
-    }
+    for (int u = 0; u < U; ++u)
+      if ((uint32_t)u < n) accumulate_row<T, METHOD, HAS_STATUS, VEC, FAST>(agg, v[u], s[u], def_nan);
   }
-
-  Vec<T, VEC> ov;
-  Vec<int32_t, VEC> os;
-#pragma unroll
-  for (int e = 0; e < VEC; ++e) {
-    if (fast) agg[e].has = agg[e].count != 0 && agg[e].acc != 0.0;
-    agg[e].finish(def_nan);
-    emit_cell<T>(agg[e].acc, agg[e].has, def_nan, ov.v[e], os.v[e]);
-  }
-  const uint64_t oidx = (o * a.G + g) * a.inner + i0;
-  store_vec<T, VEC>(out + oidx, ov);
-  if (st_out) store_vec<int32_t, VEC>(st_out + oidx, os);
+  finish_and_store<T, METHOD, VEC, FAST>(agg, def_nan, out, st_out, (o * a.G + g) * a.inner + i0);
 }
 
 // ======================================================================= K1g: drillUp, any maps
@@ -510,15 +586,42 @@ inline unsigned grid_stride_for(uint64_t n) {
 
 #ifdef OLAP_KERNELS_IMPL
 
+// Row regime when a row of VEC-slots fills at least one wavefront-sized piece of a workgroup
+// reasonably (>= 128 slots); otherwise the flat regime.  FAST = additive method, zero default, no
+// mask read.  The grid of the row regime is outer*G*blocks_per_row workgroups.
+template <typename T, int METHOD, bool HS, int VEC>
+static hipError_t drillup_axis_launch(const T *in, const int32_t *st_in, T *out, int32_t *st_out,
+                                      const DrillUpAxis &a, hipStream_t stream) {
+  constexpr bool kAdditive = (METHOD == OLAP_SUM || METHOD == OLAP_AVERAGE);
+  const bool fast = kAdditive && !HS && !a.def_nan;
+  const bool contig = a.order == nullptr;
+  const uint64_t row_blocks = a.outer * a.G * a.blocks_per_row;
+  const bool rows = a.n_vec >= 128 && row_blocks < 0x7FFFFFFFull;
+  constexpr int U = 4;  // rows in flight per lane (tools/microbench.hip: U=2..10 within 2 %)
+#define OLAP_ROWS(C, F) hipLaunchKernelGGL((drillup_rows_kernel<T, METHOD, HS, VEC, U, C, F>), (unsigned)row_blocks, kBlock, 0, stream, in, st_in, out, st_out, a)
+#define OLAP_FLAT(F) hipLaunchKernelGGL((drillup_flat_kernel<T, METHOD, HS, VEC, F>), grid_for(a.total), kBlock, 0, stream, in, st_in, out, st_out, a)
+  if (rows) {
+    if constexpr (kAdditive && !HS) {
+      if (fast) { if (contig) OLAP_ROWS(true, true); else OLAP_ROWS(false, true); return hipGetLastError(); }
+    }
+    if (contig) OLAP_ROWS(true, false); else OLAP_ROWS(false, false);
+  } else {
+    if constexpr (kAdditive && !HS) {
+      if (fast) { OLAP_FLAT(true); return hipGetLastError(); }
+    }
+    OLAP_FLAT(false);
+  }
+#undef OLAP_ROWS
+#undef OLAP_FLAT
+  return hipGetLastError();
+}
+
 template <typename T, int METHOD, bool HS>
 static hipError_t drillup_axis_vec(int vec, const T *in, const int32_t *st_in, T *out, int32_t *st_out,
                                    const DrillUpAxis &a, hipStream_t stream) {
-  const unsigned grid = grid_for(a.total);
-  constexpr int U = 8;
-  if (vec == 4) hipLaunchKernelGGL((drillup_direct_kernel<T, METHOD, HS, 4, U>), grid, kBlock, 0, stream, in, st_in, out, st_out, a);
-  else if (vec == 2) hipLaunchKernelGGL((drillup_direct_kernel<T, METHOD, HS, 2, U>), grid, kBlock, 0, stream, in, st_in, out, st_out, a);
-  else hipLaunchKernelGGL((drillup_direct_kernel<T, METHOD, HS, 1, U>), grid, kBlock, 0, stream, in, st_in, out, st_out, a);
-  return hipGetLastError();
+  if (vec == 4) return drillup_axis_launch<T, METHOD, HS, 4>(in, st_in, out, st_out, a, stream);
+  if (vec == 2) return drillup_axis_launch<T, METHOD, HS, 2>(in, st_in, out, st_out, a, stream);
+  return drillup_axis_launch<T, METHOD, HS, 1>(in, st_in, out, st_out, a, stream);
 }
 
 template <typename T, bool HS>

@@ -139,10 +139,12 @@ class Dim0DrillUp:
         eng = s.engine
         self.n_out = n_groups * s.inner0
         self.local = eng.make_drillup(s.dtype, s.default, method, old_len, new_len, maps)
-        self.partial = eng.empty(self.n_out, s.dtype)
-        self.partial_status = eng.empty(self.n_out, "int32")
-        w = s.world
         self.additive = method == "sum"
+        self.partial = eng.empty(self.n_out, s.dtype)
+        # sum over a zero default: the mask is a function of the value (set <=> value != 0), so the
+        # additive path neither writes nor ships it
+        self.partial_status = None if (self.additive and not (s.default != s.default)) else eng.empty(self.n_out, "int32")
+        w = s.world
         self.scatter = self.additive and w > 1 and self.n_out % w == 0
         self.staged = w > 1 and dist.get_backend(s.group) == "gloo" and getattr(self.partial, "is_cuda", False)
         if w == 1:

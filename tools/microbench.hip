@@ -1,0 +1,162 @@
+// tools/microbench.hip — developer tool (not part of the product): HBM ceilings on this box and
+// A/B of drillUp kernel variants, interleaved rounds in one process (guide §5.4 rule 24).
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I include -I olap-in-memory_amd/csrc tools/microbench.hip -o build/microbench
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <functional>
+#include <string>
+#include <vector>
+
+#include "olap_kernels.hpp"
+
+using namespace olap;
+
+#define CK(x)                                                                        \
+  do {                                                                               \
+    hipError_t e = (x);                                                              \
+    if (e != hipSuccess) {                                                           \
+      fprintf(stderr, "%s:%d %s: %s\n", __FILE__, __LINE__, #x, hipGetErrorString(e)); \
+      exit(1);                                                                       \
+    }                                                                                \
+  } while (0)
+
+// read ceiling: grid-stride float4 loads, UNR independent loads in flight per lane
+template <int UNR>
+__global__ __launch_bounds__(256) void read_sum_kernel(const float4 *__restrict__ in, uint64_t n4, float *sink) {
+  float acc = 0.f;
+  const uint64_t stride = (uint64_t)gridDim.x * 256;
+  uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  for (; i + (UNR - 1) * stride < n4; i += UNR * stride) {
+    float4 v[UNR];
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) v[u] = in[i + u * stride];
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) acc += v[u].x + v[u].y + v[u].z + v[u].w;
+  }
+  for (; i < n4; i += stride) {
+    float4 v = in[i];
+    acc += v.x + v.y + v.z + v.w;
+  }
+  if (acc == 12345.678f) sink[0] = acc;  // never true: keeps the loads alive
+}
+
+__global__ __launch_bounds__(256) void copy_kernel(const float4 *__restrict__ in, float4 *__restrict__ out, uint64_t n4) {
+  const uint64_t stride = (uint64_t)gridDim.x * 256;
+  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) out[i] = in[i];
+}
+
+// the cheapest possible column sum: K rows of float4, f32 adds, value-only output
+template <int K>
+__global__ __launch_bounds__(256) void colsum_f32_kernel(const float4 *__restrict__ in, float4 *__restrict__ out, uint64_t inner4) {
+  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= inner4) return;
+  float4 v[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) v[k] = in[i + (uint64_t)k * inner4];
+  float4 a = v[0];
+#pragma unroll
+  for (int k = 1; k < K; ++k) {
+    a.x += v[k].x;
+    a.y += v[k].y;
+    a.z += v[k].z;
+    a.w += v[k].w;
+  }
+  out[i] = a;
+}
+
+struct Timer {
+  hipEvent_t a, b;
+  Timer() {
+    CK(hipEventCreate(&a));
+    CK(hipEventCreate(&b));
+  }
+  template <typename F>
+  float run(F f, int iters) {
+    CK(hipEventRecord(a));
+    for (int i = 0; i < iters; ++i) f();
+    CK(hipEventRecord(b));
+    CK(hipEventSynchronize(b));
+    float ms;
+    CK(hipEventElapsedTime(&ms, a, b));
+    return ms / iters;
+  }
+};
+
+struct Variant {
+  std::string name;
+  std::function<void()> fn;
+  double bytes;
+  std::vector<float> ms;
+};
+
+int main(int argc, char **argv) {
+  const uint64_t N = 100000000ull, K = 10, inner = N / K;
+  float *in, *out, *sink;
+  int32_t *st_out;
+  CK(hipMalloc(&in, N * 4));
+  CK(hipMalloc(&out, N * 4));  // big enough for the copy test
+  CK(hipMalloc(&st_out, inner * 4));
+  CK(hipMalloc(&sink, 4));
+  {
+    std::vector<float> h(N);
+    uint32_t s = 12345;
+    for (uint64_t i = 0; i < N; ++i) {
+      s = s * 1664525u + 1013904223u;
+      h[i] = 0.5f + (s >> 8) * (1.0f / 16777216.0f);
+    }
+    CK(hipMemcpy(in, h.data(), N * 4, hipMemcpyHostToDevice));
+  }
+  uint32_t h_gstart[2] = {0, (uint32_t)K};
+  uint32_t *gstart;
+  CK(hipMalloc(&gstart, 8));
+  CK(hipMemcpy(gstart, h_gstart, 8, hipMemcpyHostToDevice));
+  DrillUpAxis a{};
+  a.outer = 1;
+  a.K = K;
+  a.inner = inner;
+  a.G = 1;
+  a.n_vec = inner / 4;
+  a.total = a.n_vec;
+  a.blocks_per_row = (a.n_vec + 255) / 256;
+  a.order = nullptr;
+  a.gstart = gstart;
+  a.def_nan = 0;
+  const unsigned rows_grid = (unsigned)a.blocks_per_row;
+
+  std::vector<Variant> vs;
+  const double alg = N * 4.0 + inner * 8.0;
+  vs.push_back({"read_sum<4> 2048 blocks", [&] { hipLaunchKernelGGL(read_sum_kernel<4>, 2048, 256, 0, 0, (const float4 *)in, N / 4, sink); }, N * 4.0, {}});
+  vs.push_back({"read_sum<8> 2048 blocks", [&] { hipLaunchKernelGGL(read_sum_kernel<8>, 2048, 256, 0, 0, (const float4 *)in, N / 4, sink); }, N * 4.0, {}});
+  vs.push_back({"read_sum<8> 4096 blocks", [&] { hipLaunchKernelGGL(read_sum_kernel<8>, 4096, 256, 0, 0, (const float4 *)in, N / 4, sink); }, N * 4.0, {}});
+  vs.push_back({"read_sum<2> 8192 blocks", [&] { hipLaunchKernelGGL(read_sum_kernel<2>, 8192, 256, 0, 0, (const float4 *)in, N / 4, sink); }, N * 4.0, {}});
+  vs.push_back({"copy 2048 blocks (r+w)", [&] { hipLaunchKernelGGL(copy_kernel, 2048, 256, 0, 0, (const float4 *)in, (float4 *)out, N / 4); }, N * 8.0, {}});
+  vs.push_back({"colsum_f32<10> value-only", [&] { hipLaunchKernelGGL(colsum_f32_kernel<10>, rows_grid, 256, 0, 0, (const float4 *)in, (float4 *)out, inner / 4); }, N * 4.0 + inner * 4.0, {}});
+#define ROWS(U, FAST, NT, ST, NAME) vs.push_back({NAME, [&] { hipLaunchKernelGGL((drillup_rows_kernel<float, OLAP_SUM, false, 4, U, true, FAST, NT>), rows_grid, 256, 0, 0, in, nullptr, out, ST, a); }, (ST) ? alg : N * 4.0 + inner * 4.0, {}})
+  ROWS(8, true, false, st_out, "rows U=8 fast plain");
+  ROWS(8, true, true, st_out, "rows U=8 fast nt");
+  ROWS(4, true, true, st_out, "rows U=4 fast nt");
+  ROWS(2, true, true, st_out, "rows U=2 fast nt");
+  ROWS(10, true, true, st_out, "rows U=10 fast nt");
+  ROWS(8, false, true, st_out, "rows U=8 exact nt");
+  ROWS(8, true, true, (int32_t *)nullptr, "rows U=8 fast nt, values only");
+  ROWS(4, true, true, (int32_t *)nullptr, "rows U=4 fast nt, values only");
+  ROWS(2, true, true, (int32_t *)nullptr, "rows U=2 fast nt, values only");
+  ROWS(10, true, true, (int32_t *)nullptr, "rows U=10 fast nt, values only");
+  vs.push_back({"flat U=4 fast", [&] { hipLaunchKernelGGL((drillup_flat_kernel<float, OLAP_SUM, false, 4, true>), grid_for(a.total), 256, 0, 0, in, nullptr, out, st_out, a); }, alg, {}});
+
+  Timer t;
+  for (auto &v : vs) t.run(v.fn, 3);  // warm-up
+  const int rounds = 7, iters = 20;
+  for (int r = 0; r < rounds; ++r)
+    for (auto &v : vs) v.ms.push_back(t.run(v.fn, iters));
+  printf("%-36s %10s %10s %12s %12s\n", "variant", "med us", "min us", "GB/s(med)", "frac of 8TB/s");
+  for (auto &v : vs) {
+    std::sort(v.ms.begin(), v.ms.end());
+    const float med = v.ms[v.ms.size() / 2], mn = v.ms[0];
+    printf("%-36s %10.2f %10.2f %12.1f %12.3f\n", v.name.c_str(), med * 1e3, mn * 1e3, v.bytes / (med * 1e-3) / 1e9, v.bytes / (med * 1e-3) / 1e9 / 8000.0);
+  }
+  return 0;
+}
