@@ -89,7 +89,7 @@ def build_addon(force=False):
     target = addon_path()
     if force or _newer(target, [src, os.path.join(ROOT, "include", "olap_hip.h")]):
         cxx = shutil.which("g++") or "g++"
-        _run([cxx, "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-DNAPI_VERSION=6", "-I", inc, "-I",
+        _run([cxx, "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-DNAPI_VERSION=6", "-DNODE_GYP_MODULE_NAME=olapgpu", "-I", inc, "-I",
               os.path.join(ROOT, "include"), src, "-o", target, "-L", LIB, "-lolapgpu", "-Wl,-rpath,$ORIGIN"])
     return target
 

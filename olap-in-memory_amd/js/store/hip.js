@@ -1,0 +1,166 @@
+'use strict';
+/*
+ * HipStore — drop-in for the reference's InMemoryStore (/root/reference/src/store/in-memory.js)
+ * whose cells live in MI355X HBM.  Same constructor, members and error messages as the members
+ * `Cube` touches (SURVEY.md §8(b)): size, byteLength, total, data (get/set), clone, getValue,
+ * setValue, fill, drillUp, drillDown, dice, reorder, load, _type, _defaultValue, _dataMap.
+ *
+ * This class only turns dimension objects into the small integer tables the C ABI takes
+ * (include/olap_hip.h) and forwards; all cell work happens in the HIP kernels.
+ */
+const backend = require('../backend');
+
+const TYPE_CODE = { int32: 0, uint32: 1, float32: 2, float64: 3 };
+const BYTES = { int32: 4, uint32: 4, float32: 4, float64: 8 };
+
+const lengthsOf = (dimensions) => Uint32Array.from(dimensions, (d) => d.numItems);
+
+/** Read-only view with the Map methods the reference's callers use on `_dataMap`. */
+class CellMapView {
+  constructor(store) {
+    this._store = store;
+  }
+
+  get size() {
+    return this._store._native.countSet();
+  }
+
+  has(index) {
+    return this._store._native.getValue(index) !== undefined;
+  }
+
+  get(index) {
+    return this._store._native.getValue(index);
+  }
+
+  *keys() {
+    for (const k of this._store._native.getKeys()) yield k;
+  }
+
+  *values() {
+    const data = this._store._native.getDataF64();
+    for (const k of this._store._native.getKeys()) yield data[k];
+  }
+
+  *entries() {
+    const data = this._store._native.getDataF64();
+    for (const k of this._store._native.getKeys()) yield [k, data[k]];
+  }
+
+  [Symbol.iterator]() {
+    return this.entries();
+  }
+}
+
+class HipStore {
+  constructor(size, type = 'float32', defaultValue = Number.NaN, native = undefined) {
+    // same checks, order and messages as in-memory.js:56-60
+    if (!Number.isNaN(defaultValue) && defaultValue !== 0) throw new Error('Invalid default value, only NaN and 0 are supported');
+    if (!Object.prototype.hasOwnProperty.call(TYPE_CODE, type)) throw new Error('Invalid type');
+    this._size = size;
+    this._type = type;
+    this._defaultValue = defaultValue;
+    this._native = native || new (backend.load().Store)(size, TYPE_CODE[type], Number.isNaN(defaultValue) ? 1 : 0);
+    this._dataMap = new CellMapView(this);
+  }
+
+  _wrap(native) {
+    return new HipStore(native.size, this._type, this._defaultValue, native);
+  }
+
+  get size() {
+    return this._size;
+  }
+
+  get byteLength() {
+    return this._size * (BYTES[this._type] || 1);
+  }
+
+  get total() {
+    return this._native.total();
+  }
+
+  /** Dense plain Array, default value in unset cells (in-memory.js:30-37). */
+  get data() {
+    return Array.from(this._native.getDataF64());
+  }
+
+  set data(values) {
+    if (this._size !== values.length) throw new Error(`value length is invalid: ${this._size} !== ${values.length}`);
+    if (ArrayBuffer.isView(values) && !(values instanceof Float64Array) && values.constructor.name.toLowerCase().startsWith(this._type)) {
+      this._native.setData(values); // a typed array of the store's own element type: no conversion
+      return;
+    }
+    const d = this._defaultValue;
+    // undefined / null unset the cell, exactly like the default value does (in-memory.js:122-133)
+    this._native.setData(Float64Array.from(values, (v) => (v === undefined || v === null ? d : Number(v))));
+  }
+
+  clone() {
+    return this._wrap(this._native.clone());
+  }
+
+  getValue(index) {
+    const v = this._native.getValue(index);
+    return v === undefined ? this._defaultValue : v;
+  }
+
+  setValue(index, value) {
+    this._native.setValue(index, value);
+  }
+
+  fill(value) {
+    if (value === undefined || value === null) this._native.fill(this._defaultValue);
+    else this._native.fill(value);
+  }
+
+  /** in-memory.js:265-334 */
+  drillUp(oldDimensions, newDimensions, method = 'sum') {
+    const code = backend.load().methodFromName(method); // throws 'Unsupported aggregation method: <m>'
+    const maps = newDimensions.map((dim, i) => Uint32Array.from(oldDimensions[i].getGroupIndexFromRootIndexMap(dim.rootAttribute)));
+    return this._wrap(this._native.drillUp(lengthsOf(oldDimensions), lengthsOf(newDimensions), maps, code));
+  }
+
+  /** in-memory.js:336-430 — any method other than 'sum' copies the parent value (:421-423) */
+  drillDown(oldDimensions, newDimensions, method = 'sum', distributions = null) {
+    const maps = oldDimensions.map((dim, i) => Uint32Array.from(newDimensions[i].getGroupIndexFromRootIndexMap(dim.rootAttribute)));
+    const weights = distributions ? Float64Array.from(distributions, (w) => (w === undefined || w === null ? Number.NaN : Number(w))) : null;
+    return this._wrap(this._native.drillDown(lengthsOf(oldDimensions), lengthsOf(newDimensions), maps, method === 'sum' ? 0 : 4, weights));
+  }
+
+  /** in-memory.js:213-263 — the new dimensions' item ORDER decides where cells land */
+  dice(oldDimensions, newDimensions) {
+    const sel = newDimensions.map((dim, i) => {
+      const position = oldDimensions[i].getItemsToIdx();
+      return Int32Array.from(dim.getItems(), (item) => (position[item] === undefined ? -1 : position[item]));
+    });
+    return this._wrap(this._native.dice(lengthsOf(oldDimensions), lengthsOf(newDimensions), sel));
+  }
+
+  /** in-memory.js:178-211 */
+  reorder(oldDimensions, newDimensions) {
+    const perm = Int32Array.from(newDimensions, (dim) => oldDimensions.indexOf(dim));
+    return this._wrap(this._native.reorder(lengthsOf(oldDimensions), perm));
+  }
+
+  /** in-memory.js:139-176 — mutates this store */
+  load(otherStore, myDimensions, hisDimensions) {
+    const hisToMine = hisDimensions.map((dim, i) => {
+      const position = myDimensions[i].getItemsToIdx();
+      return Int32Array.from(dim.getItems(), (item) => (position[item] === undefined ? -1 : position[item]));
+    });
+    if (otherStore._type !== this._type) {
+      // the kernels copy cells of one element type; re-type the source through float64 first
+      const retyped = new HipStore(otherStore._size, this._type, otherStore._defaultValue);
+      retyped.data = otherStore.data;
+      otherStore = retyped;
+    }
+    this._native.load(otherStore._native, lengthsOf(myDimensions), lengthsOf(hisDimensions), hisToMine);
+  }
+
+  serialize() {
+    throw new Error('Serialisation is outside the accelerated path (see DESIGN.md §7)');
+  }
+}
+
+module.exports = HipStore;

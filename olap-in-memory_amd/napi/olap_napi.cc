@@ -1,0 +1,474 @@
+// olap_napi.cc — thin N-API binding of include/olap_hip.h for the Node.js host.
+//
+// Exposes one class, `Store`, wrapping an `olap_store*` (a device-resident measure, the
+// replacement of the reference's InMemoryStore, /root/reference/src/store/in-memory.js), plus a few
+// module functions.  No arithmetic happens here: every method forwards to the C ABI and turns a
+// non-zero return into a JS Error carrying olap_last_error() (the reference's own messages).
+// Handles are freed by the GC finalizer (the reference API has no explicit free).
+#include <node_api.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "olap_hip.h"
+
+#define NAPI_OK(call)                                            \
+  do {                                                           \
+    if ((call) != napi_ok) {                                     \
+      napi_throw_error(env, nullptr, "N-API call failed: " #call); \
+      return nullptr;                                            \
+    }                                                            \
+  } while (0)
+
+static napi_ref g_store_ctor = nullptr;
+
+static napi_value throw_olap(napi_env env, int code) {
+  char codebuf[16];
+  snprintf(codebuf, sizeof codebuf, "OLAP%d", code);
+  napi_throw_error(env, codebuf, olap_last_error());
+  return nullptr;
+}
+
+static void finalize_store(napi_env, void *data, void *) { olap_store_destroy((olap_store *)data); }
+
+static olap_store *unwrap(napi_env env, napi_value v) {
+  void *p = nullptr;
+  if (napi_unwrap(env, v, &p) != napi_ok || !p) {
+    napi_throw_type_error(env, nullptr, "not a Store");
+    return nullptr;
+  }
+  return (olap_store *)p;
+}
+
+static napi_value wrap_new_store(napi_env env, olap_store *s) {
+  napi_value ctor, obj, ext;
+  NAPI_OK(napi_get_reference_value(env, g_store_ctor, &ctor));
+  NAPI_OK(napi_create_external(env, s, nullptr, nullptr, &ext));
+  if (napi_new_instance(env, ctor, 1, &ext, &obj) != napi_ok) {
+    olap_store_destroy(s);
+    return nullptr;
+  }
+  return obj;
+}
+
+// new Store(size, dtypeCode, defaultKind)  |  new Store(external) [internal]
+static napi_value StoreNew(napi_env env, napi_callback_info info) {
+  size_t argc = 3;
+  napi_value argv[3], self;
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, &self, nullptr));
+  napi_valuetype t;
+  NAPI_OK(napi_typeof(env, argv[0], &t));
+  olap_store *s = nullptr;
+  if (argc == 1 && t == napi_external) {
+    void *p;
+    NAPI_OK(napi_get_value_external(env, argv[0], &p));
+    s = (olap_store *)p;
+  } else {
+    double size = 0;
+    int32_t dtype = 0, def = 0;
+    NAPI_OK(napi_get_value_double(env, argv[0], &size));
+    NAPI_OK(napi_get_value_int32(env, argv[1], &dtype));
+    NAPI_OK(napi_get_value_int32(env, argv[2], &def));
+    int rc = olap_store_create(&s, (uint64_t)size, dtype, def);
+    if (rc) return throw_olap(env, rc);
+  }
+  if (napi_wrap(env, self, s, finalize_store, nullptr, nullptr) != napi_ok) {
+    olap_store_destroy(s);
+    napi_throw_error(env, nullptr, "napi_wrap failed");
+    return nullptr;
+  }
+  // let the GC know how much device memory hangs off this small object
+  int64_t adj;
+  napi_adjust_external_memory(env, (int64_t)olap_store_byte_length(s), &adj);
+  return self;
+}
+
+#define STORE_METHOD_PROLOGUE(MAXARGS)                                     \
+  size_t argc = MAXARGS;                                                   \
+  napi_value argv[MAXARGS > 0 ? MAXARGS : 1], self;                        \
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, &self, nullptr));       \
+  olap_store *s = unwrap(env, self);                                       \
+  if (!s) return nullptr;
+
+static napi_value num(napi_env env, double v) {
+  napi_value r;
+  napi_create_double(env, v, &r);
+  return r;
+}
+
+static napi_value StoreSize(napi_env env, napi_callback_info info) {
+  STORE_METHOD_PROLOGUE(0)
+  return num(env, (double)olap_store_size(s));
+}
+static napi_value StoreByteLength(napi_env env, napi_callback_info info) {
+  STORE_METHOD_PROLOGUE(0)
+  return num(env, (double)olap_store_byte_length(s));
+}
+static napi_value StoreDtype(napi_env env, napi_callback_info info) {
+  STORE_METHOD_PROLOGUE(0)
+  return num(env, olap_store_dtype(s));
+}
+static napi_value StoreDefault(napi_env env, napi_callback_info info) {
+  STORE_METHOD_PROLOGUE(0)
+  return num(env, olap_store_default(s));
+}
+
+static napi_typedarray_type ta_of(int dtype) {
+  switch (dtype) {
+    case OLAP_INT32: return napi_int32_array;
+    case OLAP_UINT32: return napi_uint32_array;
+    case OLAP_FLOAT32: return napi_float32_array;
+    default: return napi_float64_array;
+  }
+}
+
+// setData(typedArray): Float64Array = JS numbers (converted on the device like a TypedArray
+// store would); otherwise a typed array of the store's own element type
+static napi_value StoreSetData(napi_env env, napi_callback_info info) {
+  STORE_METHOD_PROLOGUE(1)
+  bool is_ta = false;
+  NAPI_OK(napi_is_typedarray(env, argv[0], &is_ta));
+  if (!is_ta) {
+    napi_throw_type_error(env, nullptr, "setData expects a TypedArray");
+    return nullptr;
+  }
+  napi_typedarray_type type;
+  size_t len;
+  void *data;
+  NAPI_OK(napi_get_typedarray_info(env, argv[0], &type, &len, &data, nullptr, nullptr));
+  int rc;
+  if (type == napi_float64_array && olap_store_dtype(s) != OLAP_FLOAT64) rc = olap_store_set_data_f64(s, (const double *)data, len);
+  else if (type == ta_of(olap_store_dtype(s))) rc = olap_store_set_data(s, data, len);
+  else {
+    napi_throw_type_error(env, nullptr, "setData: typed array does not match the store's element type");
+    return nullptr;
+  }
+  if (rc) return throw_olap(env, rc);
+  return nullptr;
+}
+
+static napi_value make_ta(napi_env env, napi_typedarray_type type, size_t elem, size_t n, void **data) {
+  napi_value ab, ta;
+  NAPI_OK(napi_create_arraybuffer(env, n * elem, data, &ab));
+  NAPI_OK(napi_create_typedarray(env, type, n, ab, 0, &ta));
+  return ta;
+}
+
+static napi_value StoreGetData(napi_env env, napi_callback_info info) {
+  STORE_METHOD_PROLOGUE(0)
+  void *data;
+  const int dt = olap_store_dtype(s);
+  napi_value ta = make_ta(env, ta_of(dt), olap_dtype_size(dt), olap_store_size(s), &data);
+  if (!ta) return nullptr;
+  int rc = olap_store_get_data(s, data);
+  if (rc) return throw_olap(env, rc);
+  return ta;
+}
+
+static napi_value StoreGetDataF64(napi_env env, napi_callback_info info) {
+  STORE_METHOD_PROLOGUE(0)
+  void *data;
+  napi_value ta = make_ta(env, napi_float64_array, 8, olap_store_size(s), &data);
+  if (!ta) return nullptr;
+  int rc = olap_store_get_data_f64(s, (double *)data);
+  if (rc) return throw_olap(env, rc);
+  return ta;
+}
+
+static napi_value StoreGetStatus(napi_env env, napi_callback_info info) {
+  STORE_METHOD_PROLOGUE(0)
+  void *data;
+  napi_value ta = make_ta(env, napi_int32_array, 4, olap_store_size(s), &data);
+  if (!ta) return nullptr;
+  int rc = olap_store_get_status(s, (int32_t *)data);
+  if (rc) return throw_olap(env, rc);
+  return ta;
+}
+
+// ascending indices of the set cells, as a Float64Array (indices < 2^53)
+static napi_value StoreGetKeys(napi_env env, napi_callback_info info) {
+  STORE_METHOD_PROLOGUE(0)
+  uint64_t n = 0;
+  int rc = olap_store_get_keys(s, nullptr, 0, &n);
+  if (rc) return throw_olap(env, rc);
+  std::vector<uint64_t> keys(n ? n : 1);
+  rc = olap_store_get_keys(s, keys.data(), n, &n);
+  if (rc) return throw_olap(env, rc);
+  void *data;
+  napi_value ta = make_ta(env, napi_float64_array, 8, n, &data);
+  if (!ta) return nullptr;
+  for (uint64_t i = 0; i < n; ++i) ((double *)data)[i] = (double)keys[i];
+  return ta;
+}
+
+static napi_value StoreCountSet(napi_env env, napi_callback_info info) {
+  STORE_METHOD_PROLOGUE(0)
+  uint64_t n = 0;
+  int rc = olap_store_count_set(s, &n);
+  if (rc) return throw_olap(env, rc);
+  return num(env, (double)n);
+}
+
+// getValue(i) -> number, or undefined when the cell is unset (Map.get of an absent key)
+static napi_value StoreGetValue(napi_env env, napi_callback_info info) {
+  STORE_METHOD_PROLOGUE(1)
+  double idx = 0;
+  NAPI_OK(napi_get_value_double(env, argv[0], &idx));
+  napi_value undef;
+  napi_get_undefined(env, &undef);
+  if (!(idx >= 0) || idx != std::floor(idx)) return undef;
+  double v = 0;
+  int is_set = 0;
+  int rc = olap_store_get_value(s, (uint64_t)idx, &v, &is_set);
+  if (rc) return throw_olap(env, rc);
+  return is_set ? num(env, v) : undef;
+}
+
+// setValue(i, v): undefined / null unset the cell (in-memory.js:122-133)
+static napi_value StoreSetValue(napi_env env, napi_callback_info info) {
+  STORE_METHOD_PROLOGUE(2)
+  double idx = 0, v = 0;
+  NAPI_OK(napi_get_value_double(env, argv[0], &idx));
+  napi_valuetype t = napi_undefined;
+  if (argc > 1) NAPI_OK(napi_typeof(env, argv[1], &t));
+  int is_null = (t == napi_undefined || t == napi_null);
+  if (!is_null) {
+    napi_value coerced;
+    NAPI_OK(napi_coerce_to_number(env, argv[1], &coerced));
+    NAPI_OK(napi_get_value_double(env, coerced, &v));
+  }
+  int rc = olap_store_set_value(s, (uint64_t)idx, v, is_null);
+  if (rc) return throw_olap(env, rc);
+  return nullptr;
+}
+
+static napi_value StoreFill(napi_env env, napi_callback_info info) {
+  STORE_METHOD_PROLOGUE(1)
+  double v = 0;
+  napi_value coerced;
+  NAPI_OK(napi_coerce_to_number(env, argv[0], &coerced));
+  NAPI_OK(napi_get_value_double(env, coerced, &v));
+  int rc = olap_store_fill(s, v);
+  if (rc) return throw_olap(env, rc);
+  return nullptr;
+}
+
+static napi_value StoreTotal(napi_env env, napi_callback_info info) {
+  STORE_METHOD_PROLOGUE(0)
+  double t = 0;
+  int rc = olap_store_total(s, &t);
+  if (rc) return throw_olap(env, rc);
+  return num(env, t);
+}
+
+static napi_value StoreClone(napi_env env, napi_callback_info info) {
+  STORE_METHOD_PROLOGUE(0)
+  olap_store *c = nullptr;
+  int rc = olap_store_clone(s, &c);
+  if (rc) return throw_olap(env, rc);
+  return wrap_new_store(env, c);
+}
+
+// ---- argument decoding for the bulk operations -----------------------------------------------
+static bool get_u32_vec(napi_env env, napi_value v, std::vector<uint32_t> &out) {
+  bool is_ta = false;
+  if (napi_is_typedarray(env, v, &is_ta) != napi_ok || !is_ta) return false;
+  napi_typedarray_type type;
+  size_t len;
+  void *data;
+  if (napi_get_typedarray_info(env, v, &type, &len, &data, nullptr, nullptr) != napi_ok) return false;
+  if (type != napi_uint32_array && type != napi_int32_array) return false;
+  out.assign((uint32_t *)data, (uint32_t *)data + len);
+  return true;
+}
+
+// array of Uint32Array / Int32Array, one per dimension
+static bool get_tables(napi_env env, napi_value v, std::vector<std::vector<uint32_t>> &out) {
+  bool is_arr = false;
+  if (napi_is_array(env, v, &is_arr) != napi_ok || !is_arr) return false;
+  uint32_t n = 0;
+  napi_get_array_length(env, v, &n);
+  out.resize(n);
+  for (uint32_t i = 0; i < n; ++i) {
+    napi_value e;
+    if (napi_get_element(env, v, i, &e) != napi_ok || !get_u32_vec(env, e, out[i])) return false;
+  }
+  return true;
+}
+
+struct OpArgs {
+  std::vector<uint32_t> a_len, b_len;
+  std::vector<std::vector<uint32_t>> tables;
+  std::vector<const uint32_t *> ptrs;
+  static uint32_t dummy;
+  bool decode(napi_env env, napi_value la, napi_value lb, napi_value tb) {
+    if (!get_u32_vec(env, la, a_len) || !get_u32_vec(env, lb, b_len) || !get_tables(env, tb, tables)) return false;
+    if (a_len.size() != b_len.size() || tables.size() != a_len.size()) return false;
+    for (auto &t : tables) ptrs.push_back(t.empty() ? &dummy : t.data());
+    return true;
+  }
+};
+uint32_t OpArgs::dummy = 0;
+
+static napi_value bad_args(napi_env env, const char *what) {
+  napi_throw_type_error(env, nullptr, what);
+  return nullptr;
+}
+
+// drillUp(oldLen, newLen, maps, methodCode)
+static napi_value StoreDrillUp(napi_env env, napi_callback_info info) {
+  STORE_METHOD_PROLOGUE(4)
+  OpArgs a;
+  int32_t method = 0;
+  if (argc < 4 || !a.decode(env, argv[0], argv[1], argv[2]) || napi_get_value_int32(env, argv[3], &method) != napi_ok)
+    return bad_args(env, "drillUp(oldLen: Uint32Array, newLen: Uint32Array, maps: Uint32Array[], method: number)");
+  olap_store *out = nullptr;
+  int rc = olap_store_drillup(s, &out, (int)a.a_len.size(), a.a_len.data(), a.b_len.data(), a.ptrs.data(), method);
+  if (rc) return throw_olap(env, rc);
+  return wrap_new_store(env, out);
+}
+
+// drillDown(oldLen, newLen, maps, methodCode, distributions: Float64Array | null)
+static napi_value StoreDrillDown(napi_env env, napi_callback_info info) {
+  STORE_METHOD_PROLOGUE(5)
+  OpArgs a;
+  int32_t method = 0;
+  if (argc < 4 || !a.decode(env, argv[0], argv[1], argv[2]) || napi_get_value_int32(env, argv[3], &method) != napi_ok)
+    return bad_args(env, "drillDown(oldLen, newLen, maps, method, distributions)");
+  const double *dist = nullptr;
+  size_t n_dist = 0;
+  if (argc > 4) {
+    bool is_ta = false;
+    napi_is_typedarray(env, argv[4], &is_ta);
+    if (is_ta) {
+      napi_typedarray_type type;
+      void *data;
+      NAPI_OK(napi_get_typedarray_info(env, argv[4], &type, &n_dist, &data, nullptr, nullptr));
+      if (type != napi_float64_array) return bad_args(env, "distributions must be a Float64Array");
+      dist = (const double *)data;
+      static const double none = 0;
+      if (!dist) dist = &none;
+    }
+  }
+  olap_store *out = nullptr;
+  int rc = olap_store_drilldown(s, &out, (int)a.a_len.size(), a.a_len.data(), a.b_len.data(), a.ptrs.data(), method, dist, n_dist);
+  if (rc) return throw_olap(env, rc);
+  return wrap_new_store(env, out);
+}
+
+// dice(oldLen, newLen, sel: Int32Array[])
+static napi_value StoreDice(napi_env env, napi_callback_info info) {
+  STORE_METHOD_PROLOGUE(3)
+  OpArgs a;
+  if (argc < 3 || !a.decode(env, argv[0], argv[1], argv[2])) return bad_args(env, "dice(oldLen, newLen, sel: Int32Array[])");
+  olap_store *out = nullptr;
+  int rc = olap_store_dice(s, &out, (int)a.a_len.size(), a.a_len.data(), a.b_len.data(), (const int32_t *const *)a.ptrs.data());
+  if (rc) return throw_olap(env, rc);
+  return wrap_new_store(env, out);
+}
+
+// reorder(oldLen, perm: Int32Array)
+static napi_value StoreReorder(napi_env env, napi_callback_info info) {
+  STORE_METHOD_PROLOGUE(2)
+  std::vector<uint32_t> len, perm;
+  if (argc < 2 || !get_u32_vec(env, argv[0], len) || !get_u32_vec(env, argv[1], perm) || len.size() != perm.size())
+    return bad_args(env, "reorder(oldLen: Uint32Array, perm: Int32Array)");
+  olap_store *out = nullptr;
+  int rc = olap_store_reorder(s, &out, (int)len.size(), len.data(), (const int32_t *)perm.data());
+  if (rc) return throw_olap(env, rc);
+  return wrap_new_store(env, out);
+}
+
+// load(other: Store, myLen, hisLen, hisToMine: Int32Array[])
+static napi_value StoreLoad(napi_env env, napi_callback_info info) {
+  STORE_METHOD_PROLOGUE(4)
+  if (argc < 4) return bad_args(env, "load(other, myLen, hisLen, hisToMine)");
+  olap_store *other = unwrap(env, argv[0]);
+  if (!other) return nullptr;
+  OpArgs a;
+  if (!a.decode(env, argv[1], argv[2], argv[3])) {
+    // tables are indexed by HIS dimensions: decode() only checks equal counts
+    return bad_args(env, "load(other: Store, myLen, hisLen, hisToMine: Int32Array[])");
+  }
+  int rc = olap_store_load(s, other, (int)a.a_len.size(), a.a_len.data(), a.b_len.data(), (const int32_t *const *)a.ptrs.data());
+  if (rc) return throw_olap(env, rc);
+  return nullptr;
+}
+
+// ---- module functions -------------------------------------------------------------------------
+static napi_value MethodFromName(napi_env env, napi_callback_info info) {
+  size_t argc = 1;
+  napi_value argv[1];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+  napi_valuetype t = napi_undefined;
+  if (argc) napi_typeof(env, argv[0], &t);
+  int code;
+  if (t == napi_undefined) {
+    code = olap_method_from_name(nullptr);
+  } else {
+    napi_value str;
+    NAPI_OK(napi_coerce_to_string(env, argv[0], &str));
+    char buf[128];
+    size_t n = 0;
+    NAPI_OK(napi_get_value_string_utf8(env, str, buf, sizeof buf, &n));
+    code = olap_method_from_name(buf);
+  }
+  if (code < 0) return throw_olap(env, code);
+  return num(env, code);
+}
+
+static napi_value DeviceCount(napi_env env, napi_callback_info) { return num(env, olap_device_count()); }
+static napi_value AbiVersion(napi_env env, napi_callback_info) { return num(env, olap_abi_version()); }
+
+static napi_value SetDevice(napi_env env, napi_callback_info info) {
+  size_t argc = 1;
+  napi_value argv[1];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+  int32_t d = 0;
+  NAPI_OK(napi_get_value_int32(env, argv[0], &d));
+  int rc = olap_set_device(d);
+  if (rc) return throw_olap(env, rc);
+  return nullptr;
+}
+
+static napi_value Init(napi_env env, napi_value exports) {
+  napi_property_descriptor props[] = {
+      {"size", nullptr, nullptr, StoreSize, nullptr, nullptr, napi_default, nullptr},
+      {"byteLength", nullptr, nullptr, StoreByteLength, nullptr, nullptr, napi_default, nullptr},
+      {"dtype", nullptr, nullptr, StoreDtype, nullptr, nullptr, napi_default, nullptr},
+      {"defaultKind", nullptr, nullptr, StoreDefault, nullptr, nullptr, napi_default, nullptr},
+      {"setData", nullptr, StoreSetData, nullptr, nullptr, nullptr, napi_default, nullptr},
+      {"getData", nullptr, StoreGetData, nullptr, nullptr, nullptr, napi_default, nullptr},
+      {"getDataF64", nullptr, StoreGetDataF64, nullptr, nullptr, nullptr, napi_default, nullptr},
+      {"getStatus", nullptr, StoreGetStatus, nullptr, nullptr, nullptr, napi_default, nullptr},
+      {"getKeys", nullptr, StoreGetKeys, nullptr, nullptr, nullptr, napi_default, nullptr},
+      {"countSet", nullptr, StoreCountSet, nullptr, nullptr, nullptr, napi_default, nullptr},
+      {"getValue", nullptr, StoreGetValue, nullptr, nullptr, nullptr, napi_default, nullptr},
+      {"setValue", nullptr, StoreSetValue, nullptr, nullptr, nullptr, napi_default, nullptr},
+      {"fill", nullptr, StoreFill, nullptr, nullptr, nullptr, napi_default, nullptr},
+      {"total", nullptr, StoreTotal, nullptr, nullptr, nullptr, napi_default, nullptr},
+      {"clone", nullptr, StoreClone, nullptr, nullptr, nullptr, napi_default, nullptr},
+      {"drillUp", nullptr, StoreDrillUp, nullptr, nullptr, nullptr, napi_default, nullptr},
+      {"drillDown", nullptr, StoreDrillDown, nullptr, nullptr, nullptr, napi_default, nullptr},
+      {"dice", nullptr, StoreDice, nullptr, nullptr, nullptr, napi_default, nullptr},
+      {"reorder", nullptr, StoreReorder, nullptr, nullptr, nullptr, napi_default, nullptr},
+      {"load", nullptr, StoreLoad, nullptr, nullptr, nullptr, napi_default, nullptr},
+  };
+  napi_value ctor;
+  if (napi_define_class(env, "Store", NAPI_AUTO_LENGTH, StoreNew, nullptr, sizeof(props) / sizeof(props[0]), props, &ctor) != napi_ok) return nullptr;
+  napi_create_reference(env, ctor, 1, &g_store_ctor);
+  napi_set_named_property(env, exports, "Store", ctor);
+  napi_property_descriptor fns[] = {
+      {"methodFromName", nullptr, MethodFromName, nullptr, nullptr, nullptr, napi_default, nullptr},
+      {"deviceCount", nullptr, DeviceCount, nullptr, nullptr, nullptr, napi_default, nullptr},
+      {"abiVersion", nullptr, AbiVersion, nullptr, nullptr, nullptr, napi_default, nullptr},
+      {"setDevice", nullptr, SetDevice, nullptr, nullptr, nullptr, napi_default, nullptr},
+  };
+  napi_define_properties(env, exports, sizeof(fns) / sizeof(fns[0]), fns);
+  return exports;
+}
+
+NAPI_MODULE(NODE_GYP_MODULE_NAME, Init)

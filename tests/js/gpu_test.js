@@ -1,0 +1,318 @@
+'use strict';
+/*
+ * Cube-level parity on the GPU through the Node.js host + N-API addon.  Inputs and expected
+ * values are the known-answer data of the reference's own tests (test/cube-accessors.js,
+ * cube-drilling.js, cube-filtering.js, cube-dimension.js, cube-to-cube.js:403-606, fixture
+ * test/helpers/create-test-cube.js:4-57), re-expressed for this harness, plus BASELINE config 1
+ * against the reference's recorded output (tests/golden/configs.json).
+ */
+const fs = require('fs');
+const path = require('path');
+const { describe, it, beforeEach, assert, run } = require('./harness');
+const { Cube, GenericDimension, TimeDimension } = require('../../olap-in-memory_amd/js');
+
+const NaN_ = Number.NaN;
+
+function testCube(fill = true) {
+  const period = new GenericDimension('period', 'season', ['summer', 'winter']);
+  const location = new GenericDimension('location', 'city', ['paris', 'toledo', 'tokyo']);
+  location.addAttribute('city', 'country', { paris: 'france', toledo: 'spain', tokyo: 'japan' });
+  location.addAttribute('city', 'continent', { paris: 'europe', toledo: 'europe', tokyo: 'asia' });
+  location.addAttribute('city', 'citySize', { paris: 'big', toledo: 'small', tokyo: 'big' });
+  const cube = new Cube([location, period]);
+  cube.createStoredMeasure('antennas', { period: 'sum', location: 'sum' }, 'uint32');
+  cube.createStoredMeasure('routers', { period: 'sum', location: 'sum' }, 'uint32');
+  if (fill) {
+    cube.setNestedArray('antennas', [[1, 2], [4, 8], [16, 32]]);
+    cube.setNestedArray('routers', [[3, 2], [4, 9], [16, 32]]);
+  }
+  return cube;
+}
+
+describe('accessors', () => {
+  let cube;
+  beforeEach(() => {
+    cube = testCube();
+  });
+  it('sizes', () => {
+    assert.equal(cube.storeSize, 6);
+    assert.equal(cube.byteLength, 48);
+  });
+  it('flat, nested array, nested object, totals', () => {
+    assert.deepEqual(cube.getData('antennas'), [1, 2, 4, 8, 16, 32]);
+    assert.deepEqual(cube.getNestedArray('antennas'), [[1, 2], [4, 8], [16, 32]]);
+    assert.deepEqual(cube.getNestedObject('antennas'), { paris: { summer: 1, winter: 2 }, toledo: { summer: 4, winter: 8 }, tokyo: { summer: 16, winter: 32 } });
+    assert.deepEqual(cube.getNestedObject('antennas', true), {
+      paris: { summer: 1, winter: 2, all: 3 },
+      toledo: { summer: 4, winter: 8, all: 12 },
+      tokyo: { summer: 16, winter: 32, all: 48 },
+      all: { summer: 21, winter: 42, all: 63 },
+    });
+    assert.equal(cube.getTotal('antennas'), 63);
+    assert.equal(cube.getSingleData('antennas', { location: 'toledo', period: 'winter' }), 8);
+  });
+  it('zero-dimension cube with totals', () => {
+    const c = new Cube([]);
+    c.createStoredMeasure('antennas');
+    c.setData('antennas', [32]);
+    assert.deepEqual(c.getNestedObject('antennas', true), 32);
+  });
+  it('setters', () => {
+    const c = testCube(false);
+    c.setData('antennas', [1, 2, 4, 8, 16, 32]);
+    assert.deepEqual(c.getData('antennas'), [1, 2, 4, 8, 16, 32]);
+    c.setNestedObject('routers', { paris: { summer: 1, winter: 2 }, toledo: { summer: 4, winter: 8 }, tokyo: { summer: 16, winter: 32 } });
+    assert.deepEqual(c.getData('routers'), [1, 2, 4, 8, 16, 32]);
+    assert.throws(() => c.setData('antennas', [1, 2, 3]), /value length is invalid: 6 !== 3/);
+  });
+  it('hydrateFromSparseNestedObject, null unsets', () => {
+    const c = new Cube([new GenericDimension('period', 'season', ['summer', 'winter']), new GenericDimension('location', 'city', ['paris', 'toledo', 'tokyo'])]);
+    c.createStoredMeasure('antennas', {}, 'float32', 0);
+    c.hydrateFromSparseNestedObject('antennas', { winter: { toledo: 1, losangeles: 2 } });
+    assert.deepEqual(c.getNestedObject('antennas'), { summer: { paris: 0, toledo: 0, tokyo: 0 }, winter: { paris: 0, toledo: 1, tokyo: 0 } });
+    cube.hydrateFromSparseNestedObject('antennas', { toledo: { summer: null } });
+    assert.equal(cube.getData('antennas')[2], 0);
+    assert.equal(cube.getStatusMap('antennas').get(2), undefined);
+    assert.deepEqual(Array.from(cube.getStatusMap('antennas').keys()), [0, 1, 3, 4, 5]);
+  });
+});
+
+describe('drillUp', () => {
+  it('no-op returns this', () => {
+    const cube = testCube();
+    assert.equal(cube.drillUp('location', 'city'), cube);
+  });
+  it('cities to continents', () => {
+    assert.deepEqual(testCube().drillUp('location', 'continent').getNestedArray('antennas'), [[5, 10], [16, 32]]);
+  });
+  it('incomplete time cube, NaN default: sum and average with totals', () => {
+    const cube = new Cube([new TimeDimension('time', 'month', '2010-01', '2010-06')]);
+    cube.createStoredMeasure('data_sum', {}, 'float32', NaN_);
+    cube.createStoredMeasure('data_avg', { time: 'average' }, 'float32', NaN_);
+    cube.hydrateFromSparseNestedObject('data_sum', { '2010-01': 1, '2010-03': 2 });
+    cube.hydrateFromSparseNestedObject('data_avg', { '2010-01': 10, '2010-02': 0, '2010-03': 20 });
+    const up = cube.drillUp('time', 'quarter');
+    assert.deepEqual(up.getNestedObject('data_sum', true), { '2010-Q1': 3, '2010-Q2': NaN_, all: 3 });
+    assert.deepEqual(up.getNestedObject('data_avg', true), { '2010-Q1': 10, '2010-Q2': NaN_, all: 10 });
+  });
+  it('unknown method', () => {
+    const cube = testCube();
+    cube.updateStoredMeasureRules('antennas', () => ({ location: 'median' }));
+    assert.throws(() => cube.drillUp('location', 'continent'), /Unsupported aggregation method: median/);
+  });
+});
+
+describe('drillDown', () => {
+  it('no-op returns this', () => {
+    const cube = new Cube([new TimeDimension('time', 'month', '2010-01', '2010-02')]);
+    cube.createStoredMeasure('measure1', { time: 'sum' }, 'float32');
+    cube.setNestedObject('measure1', { '2010-01': 100, '2010-02': 100 });
+    assert.equal(cube.drillDown('time', 'month'), cube);
+  });
+  for (const [root, start, end] of [['month', '2010-01', '2010-02'], ['month_week_mon', '2010-01-W1-mon', '2010-02-W1-mon']]) {
+    it(`${root} -> day -> ${root} round trip (uint32 sum and average)`, () => {
+      const cube = new Cube([new TimeDimension('time', root, start, end)]);
+      cube.createStoredMeasure('measure1', { time: 'sum' }, 'uint32');
+      cube.createStoredMeasure('measure2', { time: 'average' }, 'uint32');
+      cube.setNestedObject('measure1', { [start]: 100, [end]: 100 });
+      cube.setNestedObject('measure2', { [start]: 100, [end]: 100 });
+      const days = cube.drillDown('time', 'day');
+      assert.deepEqual(days.drillUp('time', root).getNestedObject('measure1'), cube.getNestedObject('measure1'));
+      assert.deepEqual(days.drillUp('time', root).getNestedObject('measure2'), cube.getNestedObject('measure2'));
+      if (root === 'month') {
+        // integer remainder spreading: 100 over 31 days -> 7 days get 4, the rest 3
+        const jan = days.getData('measure1').slice(0, 31);
+        assert.equal(jan.reduce((a, b) => a + b, 0), 100);
+        assert.deepEqual(Array.from(new Set(jan)).sort(), [3, 4]);
+      }
+    });
+  }
+  it('quarter to month, incomplete cube', () => {
+    const cube = new Cube([new TimeDimension('time', 'quarter', '2010-Q1', '2010-Q2')]);
+    cube.createStoredMeasure('measure1', { time: 'sum' }, 'float32', NaN_);
+    cube.hydrateFromSparseNestedObject('measure1', { '2010-Q1': 90 });
+    const months = cube.drillDown('time', 'month');
+    assert.deepEqual(cube.getData('measure1'), [90, NaN_]);
+    assert.deepEqual(months.drillUp('time', 'quarter').getData('measure1'), [90, NaN_]);
+    assert.deepEqual(months.getData('measure1'), [30, 30, 30, NaN_, NaN_, NaN_]);
+    assert.deepEqual(Array.from(months.getStatusMap('measure1').keys()), [0, 1, 2]);
+  });
+});
+
+describe('slice and dice', () => {
+  let cube;
+  beforeEach(() => {
+    cube = testCube();
+  });
+  it('slice', () => {
+    const paris = cube.slice('location', 'city', 'paris');
+    assert.deepEqual(paris.getNestedArray('antennas'), [1, 2]);
+    assert.equal(paris.dimensions.length, 1);
+    assert.equal(paris.dimensions[0].id, 'period');
+    const winter = cube.slice('period', 'season', 'winter');
+    assert.deepEqual(winter.getNestedArray('antennas'), [2, 8, 32]);
+    assert.equal(winter.dimensions[0].id, 'location');
+    assert.deepEqual(winter.slice('location', 'city', 'toledo').getNestedArray('antennas'), 8);
+    const none = cube.slice('period', 'all', 'all').slice('location', 'all', 'all');
+    assert.deepEqual(none.getNestedArray('antennas'), 63);
+    assert.equal(none.dimensions.length, 0);
+    assert.deepEqual(cube.collapse().getNestedArray('routers'), 66);
+  });
+  it('dice', () => {
+    assert.equal(cube.dice('location', 'city', ['paris', 'toledo', 'tokyo']), cube);
+    assert.deepEqual(cube.dice('location', 'city', ['paris', 'toledo']).getNestedArray('antennas'), [[1, 2], [4, 8]]);
+    assert.deepEqual(cube.dice('location', 'city', ['toledo', 'paris']).getNestedArray('antennas'), [[1, 2], [4, 8]]);
+    assert.deepEqual(cube.dice('location', 'continent', ['europe']).getNestedArray('antennas'), [[1, 2], [4, 8]]);
+    assert.deepEqual(cube.dice('period', 'season', ['winter']).getNestedArray('antennas'), [[2], [8], [32]]);
+    assert.equal(cube.dice('location', 'city', ['nonexisting', 'paris']).storeSize, cube.storeSize / 3);
+    assert.equal(cube.dice('location', 'city', []).storeSize, 0);
+    assert.deepEqual(cube.dice('location', 'city', ['toledo', 'paris'], true).getNestedArray('antennas'), [[4, 8], [1, 2]]);
+    assert.throws(() => cube.dice('location', 'continent', ['europe'], true));
+    assert.deepEqual(cube.diceByDimensionItems({ location: ['tokyo'], period: 'summer' }).getNestedArray('antennas'), [[16]]);
+  });
+});
+
+describe('dimensions', () => {
+  it('removeDimension with every aggregator', () => {
+    let cube = new Cube([new GenericDimension('location', 'city', ['paris', 'toledo', 'tokyo']), new GenericDimension('period', 'season', ['summer', 'winter'])]);
+    for (const agg of ['sum', 'average', 'highest', 'lowest', 'first', 'last', 'product']) {
+      cube.createStoredMeasure(`antennas_${agg}`, { period: agg, location: agg }, 'float32', 0);
+      cube.setNestedArray(`antennas_${agg}`, [[1, 2], [4, 8], [16, 32]]);
+    }
+    cube = cube.removeDimension('location');
+    assert.deepEqual(cube.getNestedArray('antennas_sum'), [21, 42]);
+    assert.deepEqual(cube.getNestedArray('antennas_average'), [21 / 3, 42 / 3]);
+    assert.deepEqual(cube.getNestedArray('antennas_highest'), [16, 32]);
+    assert.deepEqual(cube.getNestedArray('antennas_lowest'), [1, 2]);
+    assert.deepEqual(cube.getNestedArray('antennas_first'), [1, 2]);
+    assert.deepEqual(cube.getNestedArray('antennas_last'), [16, 32]);
+    assert.deepEqual(cube.getNestedArray('antennas_product'), [64, 512]);
+  });
+  it('removeDimension on empty and partially filled cubes', () => {
+    const make = () => {
+      const c = new Cube([new GenericDimension('location', 'root', ['paris', 'madrid', 'berlin']), new TimeDimension('time', 'month', '2010-01', '2010-02')]);
+      c.createStoredMeasure('measure1', {}, 'float32', 0);
+      return c;
+    };
+    assert.deepEqual(make().removeDimension('location').getNestedObject('measure1'), { '2010-01': 0, '2010-02': 0 });
+    const c = make();
+    c.hydrateFromSparseNestedObject('measure1', { paris: { '2010-01': 10, '2010-02': 0 }, madrid: { '2010-01': 0, '2010-02': 5 }, berlin: { '2010-01': 0, '2010-02': 10 } });
+    assert.deepEqual(c.removeDimension('location').getNestedObject('measure1'), { '2010-01': 10, '2010-02': 15 });
+  });
+  it('addDimension then removeDimension round trips (generic and time)', () => {
+    for (const added of [new GenericDimension('location', 'city', ['paris', 'madrid', 'berlin']), new TimeDimension('time2', 'week_mon', '2010-W01-mon', '2010-W08-mon')]) {
+      const cube = new Cube([new TimeDimension('time', 'month', '2010-01', '2010-02')]);
+      cube.createStoredMeasure('measure1', { time: 'sum' }, 'float32', 0);
+      cube.createStoredMeasure('measure2', { time: 'average' }, 'float32', 0);
+      cube.hydrateFromSparseNestedObject('measure1', { '2010-01': 100, '2010-02': 100 });
+      cube.hydrateFromSparseNestedObject('measure2', { '2010-01': 100, '2010-02': 100 });
+      const bigger = cube.addDimension(added, { measure1: 'sum', measure2: 'average' });
+      assert.equal(bigger.storeSize, 2 * added.numItems);
+      const back1 = bigger.removeDimension(added.id).getNestedObject('measure1');
+      // float32 storage: 100/3 is rounded per cell; the reference keeps float64 (1e-5 relative)
+      for (const k of Object.keys(back1)) assert.ok(Math.abs(back1[k] - 100) <= 1e-5 * 100, `measure1 ${k} ${back1[k]}`);
+      assert.deepEqual(bigger.removeDimension(added.id).getNestedObject('measure2'), cube.getNestedObject('measure2'));
+    }
+  });
+  it('reorderDimensions', () => {
+    assert.deepEqual(testCube().reorderDimensions(['period', 'location']).getNestedArray('antennas'), [[1, 4, 16], [2, 8, 32]]);
+    const cube = new Cube([new GenericDimension('dim1', 'item', ['11', '12']), new GenericDimension('dim2', 'item', ['21', '22']), new GenericDimension('dim3', 'item', ['31', '32'])]);
+    cube.createStoredMeasure('main');
+    cube.setData('main', [1, 2, 3, 4, 5, 6, 7, 8]);
+    assert.equal(cube.reorderDimensions(['dim1', 'dim2', 'dim3']), cube);
+    assert.deepEqual(cube.reorderDimensions(['dim1', 'dim3', 'dim2']).getNestedObject('main'), { 11: { 31: { 21: 1, 22: 3 }, 32: { 21: 2, 22: 4 } }, 12: { 31: { 21: 5, 22: 7 }, 32: { 21: 6, 22: 8 } } });
+    assert.deepEqual(cube.reorderDimensions(['dim3', 'dim2', 'dim1']).getNestedObject('main'), { 31: { 21: { 11: 1, 12: 5 }, 22: { 11: 3, 12: 7 } }, 32: { 21: { 11: 2, 12: 6 }, 22: { 11: 4, 12: 8 } } });
+    assert.deepEqual(cube.reorderDimensions(['dim3', 'dim1', 'dim2']).getNestedObject('main'), { 31: { 11: { 21: 1, 22: 3 }, 12: { 21: 5, 22: 7 } }, 32: { 11: { 21: 2, 22: 4 }, 12: { 21: 6, 22: 8 } } });
+  });
+});
+
+describe('hydrateFromCube', () => {
+  const big = () => {
+    const c = new Cube([new GenericDimension('period', 'season', ['summer', 'winter']), new GenericDimension('location', 'city', ['paris', 'toledo', 'tokyo'])]);
+    c.createStoredMeasure('antennas', {}, 'uint32', 0);
+    return c;
+  };
+  const zeros = { summer: { paris: 0, toledo: 0, tokyo: 0 } };
+  it('missing / extra measures, missing data', () => {
+    const cube = big();
+    const small = new Cube([new GenericDimension('period', 'season', ['winter']), new GenericDimension('location', 'city', ['paris', 'tokyo'])]);
+    small.createStoredMeasure('otherMeasure', {}, 'uint32', NaN_);
+    cube.hydrateFromCube(small);
+    assert.deepEqual(cube.getNestedObject('antennas'), Object.assign({}, zeros, { winter: { paris: 0, toledo: 0, tokyo: 0 } }));
+    small.createStoredMeasure('antennas', {}, 'uint32');
+    small.setNestedObject('antennas', { winter: { paris: 10, tokyo: 20 } });
+    cube.hydrateFromCube(small);
+    assert.deepEqual(cube.getNestedObject('antennas'), Object.assign({}, zeros, { winter: { paris: 10, toledo: 0, tokyo: 20 } }));
+  });
+  it('extra item in the small cube, item order differs', () => {
+    const cube = big();
+    const small = new Cube([new GenericDimension('period', 'season', ['winter']), new GenericDimension('location', 'city', ['tokyo', 'losangeles', 'paris'])]);
+    small.createStoredMeasure('antennas', {}, 'uint32', 0);
+    small.setNestedObject('antennas', { winter: { tokyo: 1, losangeles: 2, paris: 3 } });
+    cube.hydrateFromCube(small);
+    assert.deepEqual(cube.getNestedObject('antennas'), Object.assign({}, zeros, { winter: { paris: 3, toledo: 0, tokyo: 1 } }));
+  });
+  it('extra dimension in the small cube is summed away', () => {
+    const cube = big();
+    const small = new Cube([new GenericDimension('period', 'season', ['winter']), new GenericDimension('something', 'root', ['a', 'b', 'c']), new GenericDimension('location', 'city', ['paris', 'tokyo'])]);
+    small.createStoredMeasure('antennas', {}, 'uint32', 0);
+    small.setNestedObject('antennas', { winter: { a: { paris: 1, tokyo: 2 }, b: { paris: 3, tokyo: 4 }, c: { paris: 5, tokyo: 6 } } });
+    cube.hydrateFromCube(small);
+    assert.deepEqual(cube.getNestedObject('antennas'), Object.assign({}, zeros, { winter: { paris: 9, toledo: 0, tokyo: 12 } }));
+  });
+  it('missing dimension is spread with integer remainders (32 -> 11,10,11)', () => {
+    const cube = big();
+    const small = new Cube([new GenericDimension('period', 'season', ['winter'])]);
+    small.createStoredMeasure('antennas', {}, 'uint32', 0);
+    small.setNestedObject('antennas', { winter: 32 });
+    cube.hydrateFromCube(small);
+    assert.deepEqual(cube.getNestedObject('antennas'), Object.assign({}, zeros, { winter: { paris: 11, toledo: 10, tokyo: 11 } }));
+  });
+  it('drillUp and drillDown on the way (months <-> quarters)', () => {
+    const q = new Cube([new TimeDimension('time', 'quarter', '2010-Q1', '2010-Q3'), new GenericDimension('location', 'city', ['paris', 'toledo', 'tokyo'])]);
+    q.createStoredMeasure('antennas', {}, 'uint32', 0);
+    const m = new Cube([new TimeDimension('time', 'month', '2010-04', '2010-06'), new GenericDimension('location', 'city', ['toledo'])]);
+    m.createStoredMeasure('antennas', {}, 'uint32', 0);
+    m.setNestedObject('antennas', { '2010-04': { toledo: 1 }, '2010-05': { toledo: 2 }, '2010-06': { toledo: 3 } });
+    q.hydrateFromCube(m);
+    assert.deepEqual(q.getNestedObject('antennas'), { '2010-Q1': { paris: 0, toledo: 0, tokyo: 0 }, '2010-Q2': { paris: 0, toledo: 6, tokyo: 0 }, '2010-Q3': { paris: 0, toledo: 0, tokyo: 0 } });
+
+    const months = new Cube([new TimeDimension('time', 'month', '2010-01', '2010-06'), new GenericDimension('location', 'city', ['paris', 'toledo', 'tokyo'])]);
+    months.createStoredMeasure('antennas', {}, 'uint32', 0);
+    const quarter = new Cube([new TimeDimension('time', 'quarter', '2010-Q2', '2010-Q2'), new GenericDimension('location', 'city', ['toledo'])]);
+    quarter.createStoredMeasure('antennas', {}, 'uint32', 0);
+    quarter.setNestedObject('antennas', { '2010-Q2': { toledo: 100 } });
+    months.hydrateFromCube(quarter);
+    const z = { paris: 0, toledo: 0, tokyo: 0 };
+    assert.deepEqual(months.getNestedObject('antennas'), { '2010-01': z, '2010-02': z, '2010-03': z, '2010-04': { paris: 0, toledo: 34, tokyo: 0 }, '2010-05': { paris: 0, toledo: 33, tokyo: 0 }, '2010-06': { paris: 0, toledo: 33, tokyo: 0 } });
+  });
+});
+
+describe('BASELINE config 1 through the Cube API', () => {
+  it('[10,10,10] drillUp(dimension0, all) equals the reference output', () => {
+    const golden = JSON.parse(fs.readFileSync(path.join(__dirname, '..', 'golden', 'configs.json'), 'utf8')).cases.find((c) => c.name === 'config1_10x10x10_dim0');
+    const dims = [0, 1, 2].map((i) => new GenericDimension(`dimension${i}`, 'root', Array.from({ length: 10 }, (_x, j) => `dimension${i}-item${j}`)));
+    const cube = new Cube(dims);
+    cube.createStoredMeasure('measure0', {}, 'float32', 0);
+    // mulberry32, two draws per cell (value, Bernoulli mask), as oracle/gen_golden.js configCube()
+    let a = golden.seed | 0;
+    const rnd = () => {
+      a = (a + 0x6d2b79f5) | 0;
+      let t = Math.imul(a ^ (a >>> 15), 1 | a);
+      t = (t + Math.imul(t ^ (t >>> 7), 61 | t)) ^ t;
+      return ((t ^ (t >>> 14)) >>> 0) / 4294967296;
+    };
+    const values = [];
+    for (let i = 0; i < 1000; ++i) {
+      values.push(Math.fround(0.5 + rnd()));
+      rnd();
+    }
+    cube.setData('measure0', values);
+    const up = cube.drillUp('dimension0', 'all');
+    assert.equal(up.storeSize, 100);
+    assert.deepEqual(up.getData('measure0'), golden.out.map((v) => Math.fround(Number(v))));
+    assert.deepEqual(cube.slice('dimension0', 'all', 'all').getData('measure0'), up.getData('measure0'));
+  });
+});
+
+run();

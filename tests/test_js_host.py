@@ -1,0 +1,37 @@
+"""Runs the Node.js host's own test files (tests/js/*.js) under node.
+
+host_test.js needs no GPU (dimensions, calendar, formatters, argument errors);
+gpu_test.js drives the full Cube API through the N-API addon on the device."""
+import os
+import shutil
+import subprocess
+
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+NODE = shutil.which("node")
+ADDON = os.path.join(os.path.dirname(HERE), "olap-in-memory_amd", "lib", "olapgpu.node")
+
+
+def run_node(script):
+    r = subprocess.run([NODE, os.path.join(HERE, "js", script)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-6000:]
+    return r.stdout
+
+
+@pytest.mark.skipif(NODE is None, reason="node is not installed")
+def test_js_host_logic_without_gpu():
+    out = run_node("host_test.js")
+    assert "0 failed" in out
+
+
+@pytest.mark.skipif(NODE is None, reason="node is not installed")
+def test_addon_is_built():
+    assert os.path.exists(ADDON), "olapgpu.node missing: run __graft_entry__.build()"
+
+
+@pytest.mark.gpu
+def test_js_cube_api_on_gpu():
+    assert NODE is not None, "node is expected on the GPU box (same image)"
+    out = run_node("gpu_test.js")
+    assert "0 failed" in out
