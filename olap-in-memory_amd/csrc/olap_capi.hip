@@ -129,6 +129,10 @@ struct olap_plan {
   DrillUpGeneric gen{};
   Remap remap{};
   DrillDown dd{};
+  DrillDownScale dds{};
+  bool dd_two_pass = false;                // float cells, no distributions: scale + broadcast
+  void *dev_tab2 = nullptr;                // second table set (two-pass drillDown)
+  void *dev_tmp = nullptr;                 // quotients of the two-pass drillDown (old cells)
   void *dev_tab = nullptr;                 // index tables
   double *dev_dist = nullptr;              // drillDown distributions
   unsigned long long *dev_err = nullptr;   // drillDown deferred error word
@@ -174,6 +178,8 @@ static int vec_for(int dtype, uint64_t contiguous) {
 extern "C" void olap_plan_destroy(olap_plan *p) {
   if (!p) return;
   if (p->dev_tab) (void)hipFree(p->dev_tab);
+  if (p->dev_tab2) (void)hipFree(p->dev_tab2);
+  if (p->dev_tmp) (void)hipFree(p->dev_tmp);
   if (p->dev_dist) (void)hipFree(p->dev_dist);
   if (p->dev_err) (void)hipFree(p->dev_err);
   delete p;
@@ -268,7 +274,11 @@ extern "C" int olap_drillup_plan(olap_plan **out, int dtype, int default_kind, i
     }
     a.gstart = (const uint32_t *)p->dev_tab;
     a.order = contiguous ? nullptr : (const uint32_t *)p->dev_tab + order_off;
-    p->kernel_name = (a.inner / (uint64_t)p->vec >= 128) ? "drillup_rows_kernel" : "drillup_flat_kernel";
+    if (a.inner / (uint64_t)p->vec >= 128) p->kernel_name = "drillup_rows_kernel";
+    else if (a.inner < 16 && a.K * a.inner * 4 <= (16 * 1024) / olap_dtype_size(dtype) && a.K * a.inner > 0 &&
+             (a.G + 1 + a.K) * 4 <= 16 * 1024)
+      p->kernel_name = "drillup_tile_kernel";
+    else p->kernel_name = "drillup_flat_kernel";
   } else {
     p->kind = PLAN_DRILLUP_GENERIC;
     DrillUpGeneric &g = p->gen;
@@ -555,11 +565,17 @@ extern "C" int olap_drilldown_plan(olap_plan **out, int dtype, int default_kind,
   }
   int nd = 0;
   bool prev_ident = false;
+  DrillDownScale &sc = p->dds;
+  std::vector<uint32_t> tab2;            // child counts per old index (two-pass form)
+  std::vector<RemapDim> bcast;           // broadcast of the quotients (two-pass form)
   for (int d = 0; d < ndim; ++d) {
     const bool ident = is_identity_u32(maps[d], new_len[d], old_len[d]);
     if (ident && prev_ident && (uint64_t)a.new_len[nd - 1] * new_len[d] <= 0xFFFFFFFFull) {
       a.new_len[nd - 1] *= new_len[d];
       a.old_stride[nd - 1] = old_stride[d];
+      sc.old_len[nd - 1] *= old_len[d];
+      bcast.back().len *= new_len[d];
+      bcast.back().stride = old_stride[d];
       continue;
     }
     if (nd == kMaxDims) {
@@ -568,8 +584,14 @@ extern "C" int olap_drilldown_plan(olap_plan **out, int dtype, int default_kind,
     }
     a.new_len[nd] = new_len[d];
     a.old_stride[nd] = old_stride[d];
+    sc.old_len[nd] = old_len[d];
+    RemapDim rd;
+    rd.len = new_len[d];
+    rd.stride = old_stride[d];
+    rd.arithmetic = ident;
     if (ident) {
       a.tab_off[nd] = -1;
+      sc.tab_off[nd] = -1;
     } else {
       const uint32_t L = new_len[d];
       a.tab_off[nd] = (int32_t)tab.size();
@@ -578,11 +600,43 @@ extern "C" int olap_drilldown_plan(olap_plan **out, int dtype, int default_kind,
       for (uint32_t j = 0; j < L; ++j) tab.push_back(maps[d][j]);
       for (uint32_t j = 0; j < L; ++j) tab.push_back(count[maps[d][j]]);
       for (uint32_t j = 0; j < L; ++j) tab.push_back(rank[j]);
+      sc.tab_off[nd] = (int32_t)tab2.size();
+      tab2.insert(tab2.end(), count.begin(), count.begin() + old_len[d]);
+      rd.table.resize(L);
+      for (uint32_t j = 0; j < L; ++j) rd.table[j] = (int64_t)maps[d][j] * (int64_t)old_stride[d];
     }
+    bcast.push_back(rd);
     prev_ident = ident;
     ++nd;
   }
   a.nd = nd;
+  sc.nd = nd;
+  sc.total = p->in_cells;
+  sc.def_nan = p->def_nan;
+  sc.divide = method == OLAP_SUM;
+  p->dd_two_pass = !distributions && (dtype == OLAP_FLOAT32 || dtype == OLAP_FLOAT64);
+  if (p->dd_two_pass) {
+    if ((rc = finish_remap(p, bcast, p->out_cells, true))) {  // uploads p->dev_tab (int64 offsets)
+      olap_plan_destroy(p);
+      return rc;
+    }
+    p->dev_tab2 = p->dev_tab;  // keep: the per-cell tables below go to dev_tab
+    p->dev_tab = nullptr;
+    void *cnt = nullptr;
+    if ((rc = upload(&cnt, tab2.data(), tab2.size() * sizeof(uint32_t)))) {
+      olap_plan_destroy(p);
+      return rc;
+    }
+    sc.tab = (const uint32_t *)cnt;
+    p->dev_tmp = nullptr;
+    hipError_t e = hipMalloc(&p->dev_tmp, (p->in_cells ? p->in_cells : 1) * olap_dtype_size(dtype) + (size_t)16);
+    if (e != hipSuccess) {
+      (void)hipFree(cnt);
+      olap_plan_destroy(p);
+      return hip_fail(e, "hipMalloc(drillDown quotients)");
+    }
+    p->dev_dist = (double *)cnt;  // owned: freed with the plan (distributions are absent on this path)
+  }
   a.total = p->out_cells;
   a.def_nan = p->def_nan;
   a.method = method;
@@ -617,7 +671,7 @@ extern "C" int olap_drilldown_plan(olap_plan **out, int dtype, int default_kind,
     p->dev_err = (unsigned long long *)ev;
     a.err = p->dev_err;
   }
-  p->kernel_name = "drilldown";
+  p->kernel_name = p->dd_two_pass ? "drilldown_scale_kernel+gather_kernel" : "drilldown_kernel";
   *out = p;
   return OLAP_OK;
 }
@@ -636,7 +690,8 @@ static int run_typed(olap_plan *p, const void *in_v, const int32_t *in_s, void *
     case PLAN_DRILLUP_AXIS: {
       DrillUpAxis a = p->axis;
       int vec = p->vec;
-      if (!(aligned16(in) && aligned16(out) && (!in_s || aligned16(in_s)) && (!out_s || aligned16(out_s)))) vec = 1;
+      a.aligned16 = aligned16(in) && aligned16(out) && (!in_s || aligned16(in_s)) && (!out_s || aligned16(out_s));
+      if (!a.aligned16) vec = 1;
       a.n_vec = a.inner / (uint64_t)vec;
       a.total = a.outer * a.G * a.n_vec;
       a.blocks_per_row = (a.n_vec + kBlock - 1) / kBlock;
@@ -660,6 +715,19 @@ static int run_typed(olap_plan *p, const void *in_v, const int32_t *in_s, void *
       e = Launch<T>::load_scatter(hs, in, in_s, out, out_s, p->remap, stream);
       break;
     case PLAN_DRILLDOWN: {
+      if (p->dd_two_pass) {
+        T *q = (T *)p->dev_tmp;
+        e = Launch<T>::drilldown_scale(hs, in, in_s, q, p->dds, stream);
+        if (e != hipSuccess) break;
+        Remap r = p->remap;
+        int vec = p->vec;
+        if (vec > 1 && !(aligned16(out) && (!out_s || aligned16(out_s)))) {
+          r.total *= (uint64_t)vec;
+          vec = 1;
+        }
+        e = Launch<T>::gather(false, vec, q, nullptr, out, out_s, r, stream);
+        break;
+      }
       const unsigned long long init = ~0ull;
       e = hipMemcpyAsync(p->dev_err, &init, sizeof(init), hipMemcpyHostToDevice, stream);
       if (e == hipSuccess) e = Launch<T>::drilldown(hs, in, in_s, out, out_s, p->dd, stream);

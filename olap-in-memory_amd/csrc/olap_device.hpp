@@ -165,6 +165,50 @@ struct Agg {
   }
 };
 
+// highest / lowest / first / last never leave the cell type: the result is one of the inputs
+// (or NaN, Math.max/min propagate it), so no float64 round trip, no restart (a set cell never holds
+// the default, so the running value never equals it) and no typed re-conversion are needed.
+template <typename T> __device__ __forceinline__ T select_max(T a, T b) { return a > b ? a : b; }
+template <typename T> __device__ __forceinline__ T select_min(T a, T b) { return a < b ? a : b; }
+template <> __device__ __forceinline__ float select_max<float>(float a, float b) {
+  if (a != a) return a;
+  if (b != b) return b;
+  if (a == b) return __builtin_signbit(a) ? b : a;  // max(-0, +0) = +0
+  return a > b ? a : b;
+}
+template <> __device__ __forceinline__ float select_min<float>(float a, float b) {
+  if (a != a) return a;
+  if (b != b) return b;
+  if (a == b) return __builtin_signbit(a) ? a : b;
+  return a < b ? a : b;
+}
+template <> __device__ __forceinline__ double select_max<double>(double a, double b) { return js_max(a, b); }
+template <> __device__ __forceinline__ double select_min<double>(double a, double b) { return js_min(a, b); }
+
+template <typename T, int METHOD>
+struct Pick {
+  T cur;
+  bool has;
+  __device__ __forceinline__ void init() {
+    cur = T(0);
+    has = false;
+  }
+  __device__ __forceinline__ void add(T v) {
+    if (!has) {
+      cur = v;
+      has = true;
+    } else if constexpr (METHOD == OLAP_HIGHEST) {
+      cur = select_max<T>(cur, v);
+    } else if constexpr (METHOD == OLAP_LOWEST) {
+      cur = select_min<T>(cur, v);
+    } else if constexpr (METHOD == OLAP_LAST) {
+      cur = v;
+    }  // OLAP_FIRST keeps cur
+  }
+};
+
+template <int METHOD> struct IsPick { static constexpr bool value = (METHOD == OLAP_HIGHEST || METHOD == OLAP_LOWEST || METHOD == OLAP_FIRST || METHOD == OLAP_LAST); };
+
 // Writes one output cell: typed conversion, then the store invariant (set => value != default).
 template <typename T>
 __device__ __forceinline__ void emit_cell(double acc, bool has, bool def_nan, T &value, int32_t &status) {

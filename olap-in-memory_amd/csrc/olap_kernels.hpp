@@ -26,52 +26,77 @@ struct DrillUpAxis {
   const uint32_t *order;  // device
   const uint32_t *gstart; // device
   int def_nan;
+  int aligned16;          // every buffer of this launch is 16 B aligned
 };
 
-// Accumulates one loaded row vector into the per-lane aggregates.
+// Per-lane accumulator of VEC adjacent output cells.  Additive/product methods run Agg<> in
+// float64 (FAST = plain running sum, see below); highest/lowest/first/last run Pick<> in the cell
+// type.
 template <typename T, int METHOD, bool HAS_STATUS, int VEC, bool FAST>
-__device__ __forceinline__ void accumulate_row(Agg<METHOD> (&agg)[VEC], const Vec<T, VEC> &v,
-                                               const Vec<int32_t, VEC> &s, bool def_nan) {
-#pragma unroll
-  for (int e = 0; e < VEC; ++e) {
-    const T x = v.v[e];
-    if constexpr (FAST) {
-      // sum/average over a zero default without a mask: an unset cell holds 0 and adding it
-      // changes nothing; the reference's "restart when the running sum hits 0" is invisible
-      // for addition, so the plain float64 running sum is exact.
-      agg[e].acc += Cell<T>::to_f64(x);
-      if constexpr (METHOD == OLAP_AVERAGE) agg[e].count += Cell<T>::is_default(x, false) ? 0u : 1u;
-    } else {
-      const int32_t sx = HAS_STATUS ? s.v[e] : OLAP_STATUS_SET;
-      if (cell_is_set<T>(x, sx, HAS_STATUS, def_nan)) agg[e].add(Cell<T>::to_f64(x), def_nan);
-    }
-  }
-}
+struct Lane {
+  static constexpr bool kPick = IsPick<METHOD>::value;
+  Agg<METHOD> agg[kPick ? 1 : VEC];
+  Pick<T, METHOD> pick[kPick ? VEC : 1];
 
-template <typename T, int METHOD, int VEC, bool FAST, bool NT = false>
-__device__ __forceinline__ void finish_and_store(Agg<METHOD> (&agg)[VEC], bool def_nan, T *out, int32_t *st_out,
-                                                 uint64_t oidx) {
-  Vec<T, VEC> ov;
-  Vec<int32_t, VEC> os;
+  __device__ __forceinline__ void init() {
+    if constexpr (kPick) {
 #pragma unroll
-  for (int e = 0; e < VEC; ++e) {
-    if constexpr (FAST) {
-      // presence for the fast form: any contribution <=> sum of positive counts; for `sum` the
-      // output is set iff the sum is not the default (0), which also covers "nothing contributed"
-      agg[e].has = agg[e].acc != 0.0;
-      if constexpr (METHOD == OLAP_AVERAGE) agg[e].has = agg[e].has && agg[e].count != 0;
+      for (int e = 0; e < VEC; ++e) pick[e].init();
+    } else {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) agg[e].init();
     }
-    agg[e].finish(def_nan);
-    emit_cell<T>(agg[e].acc, agg[e].has, def_nan, ov.v[e], os.v[e]);
   }
-  if constexpr (NT) {
-    store_stream<T, VEC>(out + oidx, ov);
-    if (st_out) store_stream<int32_t, VEC>(st_out + oidx, os);
-  } else {
-    store_vec<T, VEC>(out + oidx, ov);
-    if (st_out) store_vec<int32_t, VEC>(st_out + oidx, os);
+
+  __device__ __forceinline__ void add_row(const Vec<T, VEC> &v, const Vec<int32_t, VEC> &s, bool def_nan) {
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      const T x = v.v[e];
+      if constexpr (FAST) {
+        // sum/average over a zero default without a mask: an unset cell holds 0 and adding it
+        // changes nothing; the reference's "restart when the running sum hits 0" is invisible
+        // for addition, so the plain float64 running sum is exact.
+        agg[e].acc += Cell<T>::to_f64(x);
+        if constexpr (METHOD == OLAP_AVERAGE) agg[e].count += Cell<T>::is_default(x, false) ? 0u : 1u;
+      } else {
+        const int32_t sx = HAS_STATUS ? s.v[e] : OLAP_STATUS_SET;
+        if (cell_is_set<T>(x, sx, HAS_STATUS, def_nan)) {
+          if constexpr (kPick) pick[e].add(x);
+          else agg[e].add(Cell<T>::to_f64(x), def_nan);
+        }
+      }
+    }
   }
-}
+
+  template <bool NT>
+  __device__ __forceinline__ void finish_and_store(bool def_nan, T *out, int32_t *st_out, uint64_t oidx) {
+    Vec<T, VEC> ov;
+    Vec<int32_t, VEC> os;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      if constexpr (kPick) {
+        ov.v[e] = pick[e].has ? pick[e].cur : Cell<T>::default_value(def_nan);
+        os.v[e] = pick[e].has ? OLAP_STATUS_SET : 0;
+      } else {
+        if constexpr (FAST) {
+          // `sum`: the output is set iff the sum is not the default (0), which also covers
+          // "nothing contributed"; `average` additionally needs one contribution
+          agg[e].has = agg[e].acc != 0.0;
+          if constexpr (METHOD == OLAP_AVERAGE) agg[e].has = agg[e].has && agg[e].count != 0;
+        }
+        agg[e].finish(def_nan);
+        emit_cell<T>(agg[e].acc, agg[e].has, def_nan, ov.v[e], os.v[e]);
+      }
+    }
+    if constexpr (NT) {
+      store_stream<T, VEC>(out + oidx, ov);
+      if (st_out) store_stream<int32_t, VEC>(st_out + oidx, os);
+    } else {
+      store_vec<T, VEC>(out + oidx, ov);
+      if (st_out) store_vec<int32_t, VEC>(st_out + oidx, os);
+    }
+  }
+};
 
 // Row regime (inner large): a workgroup owns kBlock adjacent VEC-wide slots of ONE (outer, group)
 // pair, so the group bounds, the member list and every loop condition are wave-uniform (scalar
@@ -100,9 +125,8 @@ __global__ __launch_bounds__(kBlock) void drillup_rows_kernel(const T *__restric
   uint32_t j = a.gstart[g];
   const uint32_t jend = a.gstart[g + 1];
 
-  Agg<METHOD> agg[VEC];
-#pragma unroll
-  for (int e = 0; e < VEC; ++e) agg[e].init();
+  Lane<T, METHOD, HAS_STATUS, VEC, FAST> lane;
+  lane.init();
 
   Vec<T, VEC> v[U];
   Vec<int32_t, VEC> s[U];
@@ -114,7 +138,7 @@ __global__ __launch_bounds__(kBlock) void drillup_rows_kernel(const T *__restric
       if constexpr (HAS_STATUS) s[u] = NT ? load_stream<int32_t, VEC>(sbase + k * a.inner) : load_vec<int32_t, VEC>(sbase + k * a.inner);
     }
 #pragma unroll
-    for (int u = 0; u < U; ++u) accumulate_row<T, METHOD, HAS_STATUS, VEC, FAST>(agg, v[u], s[u], def_nan);
+    for (int u = 0; u < U; ++u) lane.add_row(v[u], s[u], def_nan);
   }
   const uint32_t rest = jend - j;  // < U, wave-uniform
   if (rest) {
@@ -128,9 +152,9 @@ __global__ __launch_bounds__(kBlock) void drillup_rows_kernel(const T *__restric
     }
 #pragma unroll
     for (int u = 0; u < U - 1; ++u)
-      if ((uint32_t)u < rest) accumulate_row<T, METHOD, HAS_STATUS, VEC, FAST>(agg, v[u], s[u], def_nan);
+      if ((uint32_t)u < rest) lane.add_row(v[u], s[u], def_nan);
   }
-  finish_and_store<T, METHOD, VEC, FAST, NT>(agg, def_nan, out, st_out, (o * a.G + g) * a.inner + i0);
+  lane.template finish_and_store<NT>(def_nan, out, st_out, (o * a.G + g) * a.inner + i0);
 }
 
 // Flat regime (inner small): one lane per VEC output cells, (outer, group) decoded per lane.
@@ -154,9 +178,8 @@ __global__ __launch_bounds__(kBlock) void drillup_flat_kernel(const T *__restric
   uint32_t j = a.gstart[g];
   const uint32_t jend = a.gstart[g + 1];
 
-  Agg<METHOD> agg[VEC];
-#pragma unroll
-  for (int e = 0; e < VEC; ++e) agg[e].init();
+  Lane<T, METHOD, HAS_STATUS, VEC, FAST> lane;
+  lane.init();
   constexpr int U = 4;
   for (; j < jend; j += U) {
     const uint32_t n = (jend - j) < (uint32_t)U ? (jend - j) : (uint32_t)U;
@@ -175,9 +198,114 @@ __global__ __launch_bounds__(kBlock) void drillup_flat_kernel(const T *__restric
     }
 #pragma unroll
     for (int u = 0; u < U; ++u)
-      if ((uint32_t)u < n) accumulate_row<T, METHOD, HAS_STATUS, VEC, FAST>(agg, v[u], s[u], def_nan);
+      if ((uint32_t)u < n) lane.add_row(v[u], s[u], def_nan);
   }
-  finish_and_store<T, METHOD, VEC, FAST>(agg, def_nan, out, st_out, (o * a.G + g) * a.inner + i0);
+  lane.template finish_and_store<false>(def_nan, out, st_out, (o * a.G + g) * a.inner + i0);
+}
+
+// Tile regime (inner small, K*inner fits LDS): the LDS-staged segmented reduction.  A row of the
+// view is K*inner CONTIGUOUS cells, so a workgroup stages R whole rows with coalesced 16 B streaming
+// loads, then every lane reduces output cells (row, group, i) out of LDS walking the group's
+// members in ascending order (same float64 order as the other regimes) and the R*G*inner results
+// leave as one contiguous, coalesced store.  HBM sees each input cell once, in full lines.
+struct DrillUpTile {
+  uint32_t rows_per_tile;   // R (multiple of 4 so that every tile starts 16 B aligned)
+  uint32_t row_elems;       // K * inner
+  uint32_t out_row;         // G * inner
+  uint32_t inner;
+};
+
+constexpr uint32_t kTileBytes = 16 * 1024;  // cells staged per workgroup: 8 workgroups (32 waves) per CU
+
+// ALL: one group holding every member in order (the '-> all' roll-ups of slice / removeDimension /
+// collapse): no table reads at all.  Otherwise the CSR is copied to LDS once per workgroup.
+template <typename T, int METHOD, bool HAS_STATUS, bool FAST, bool ALL>
+__global__ __launch_bounds__(kBlock) void drillup_tile_kernel(const T *__restrict__ in,
+                                                              const int32_t *__restrict__ st_in,
+                                                              T *__restrict__ out,
+                                                              int32_t *__restrict__ st_out,
+                                                              const DrillUpAxis a, const DrillUpTile tl) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  constexpr int V = 16 / sizeof(T);                       // cells per 16 B access
+  constexpr uint32_t kCells = kTileBytes / sizeof(T);     // capacity of the staged tile
+  constexpr int NL = kCells / V / kBlock;                 // 16 B loads per lane (4)
+  T *tile = reinterpret_cast<T *>(lds_raw);
+  int32_t *stile = reinterpret_cast<int32_t *>(lds_raw + kTileBytes);
+  uint32_t *csr = reinterpret_cast<uint32_t *>(lds_raw + kTileBytes + (HAS_STATUS ? kCells * 4 : 0));
+  uint32_t *l_gstart = csr;                 // G + 1 entries
+  uint32_t *l_order = csr + a.G + 1;        // K entries (identity when a.order == nullptr)
+
+  const uint64_t row0 = (uint64_t)blockIdx.x * tl.rows_per_tile;
+  const uint32_t rows = (uint32_t)((a.outer - row0) < tl.rows_per_tile ? (a.outer - row0) : tl.rows_per_tile);
+  const uint32_t n_in = rows * tl.row_elems;
+  const T *src = in + row0 * tl.row_elems;
+  const int32_t *ssrc = HAS_STATUS ? st_in + row0 * tl.row_elems : nullptr;
+  const bool def_nan = a.def_nan != 0;
+
+  // stage: all global loads of the lane first, then the LDS writes
+  const uint32_t n_vec = n_in / V;
+  Vec<T, V> v[NL];
+  Vec<int32_t, V> sv[NL];
+#pragma unroll
+  for (int u = 0; u < NL; ++u) {
+    const uint32_t i = threadIdx.x + u * kBlock;
+    if (i < n_vec) {
+      v[u] = load_stream<T, V>(src + (uint64_t)i * V);
+      if constexpr (HAS_STATUS) sv[u] = load_stream<int32_t, V>(ssrc + (uint64_t)i * V);
+    }
+  }
+  if constexpr (!ALL) {
+    for (uint32_t i = threadIdx.x; i <= a.G; i += kBlock) l_gstart[i] = a.gstart[i];
+    for (uint32_t i = threadIdx.x; i < a.K; i += kBlock) l_order[i] = a.order ? a.order[i] : i;
+  }
+#pragma unroll
+  for (int u = 0; u < NL; ++u) {
+    const uint32_t i = threadIdx.x + u * kBlock;
+    if (i < n_vec) {
+      *reinterpret_cast<Vec<T, V> *>(tile + i * V) = v[u];
+      if constexpr (HAS_STATUS) *reinterpret_cast<Vec<int32_t, V> *>(stile + i * V) = sv[u];
+    }
+  }
+  for (uint32_t i = n_vec * V + threadIdx.x; i < n_in; i += kBlock) {  // < V leftover cells
+    tile[i] = src[i];
+    if constexpr (HAS_STATUS) stile[i] = ssrc[i];
+  }
+  __syncthreads();
+
+  const uint32_t n_out = rows * tl.out_row;
+  T *dst = out + row0 * tl.out_row;
+  int32_t *sdst = st_out ? st_out + row0 * tl.out_row : nullptr;
+  for (uint32_t idx = threadIdx.x; idx < n_out; idx += kBlock) {
+    const uint32_t r = idx / tl.out_row;
+    const uint32_t rem = idx - r * tl.out_row;
+    const uint32_t g = rem / tl.inner;
+    const uint32_t i = rem - g * tl.inner;
+    const uint32_t base = r * tl.row_elems + i;
+    Lane<T, METHOD, HAS_STATUS, 1, FAST> lane;
+    lane.init();
+    uint32_t j = ALL ? 0u : l_gstart[g];
+    const uint32_t jend = ALL ? (uint32_t)a.K : l_gstart[g + 1];
+    constexpr int UJ = 4;  // independent LDS reads in flight
+    Vec<T, 1> x[UJ];
+    Vec<int32_t, 1> sx[UJ];
+    for (; j + UJ <= jend; j += UJ) {
+#pragma unroll
+      for (int u = 0; u < UJ; ++u) {
+        const uint32_t k = ALL ? (j + u) : l_order[j + u];
+        x[u].v[0] = tile[base + k * tl.inner];
+        sx[u].v[0] = HAS_STATUS ? stile[base + k * tl.inner] : OLAP_STATUS_SET;
+      }
+#pragma unroll
+      for (int u = 0; u < UJ; ++u) lane.add_row(x[u], sx[u], def_nan);
+    }
+    for (; j < jend; ++j) {
+      const uint32_t k = ALL ? j : l_order[j];
+      x[0].v[0] = tile[base + k * tl.inner];
+      sx[0].v[0] = HAS_STATUS ? stile[base + k * tl.inner] : OLAP_STATUS_SET;
+      lane.add_row(x[0], sx[0], def_nan);
+    }
+    lane.template finish_and_store<false>(def_nan, dst, sdst, idx);
+  }
 }
 
 // ======================================================================= K1g: drillUp, any maps
@@ -450,6 +578,48 @@ __global__ __launch_bounds__(kBlock) void drilldown_kernel(const T *__restrict__
   if (st_out) st_out[t] = os;
 }
 
+// Float cells, no distributions: every child of a parent receives the SAME value (old / n, or a
+// copy), so drillDown is split into a tiny pass over the OLD cells (one float64 division per
+// parent instead of one per child) and a pure broadcast of the quotients with gather_kernel, which
+// runs at copy bandwidth with 16 B accesses.
+struct DrillDownScale {
+  int nd;
+  uint32_t old_len[kMaxDims];
+  int32_t tab_off[kMaxDims];  // -1: untouched dim (one child per cell); else child counts per old index
+  const uint32_t *tab;        // device
+  uint64_t total;             // old cells
+  int def_nan;
+  int divide;                 // method == 'sum'
+};
+
+template <typename T, bool HAS_STATUS>
+__global__ __launch_bounds__(kBlock) void drilldown_scale_kernel(const T *__restrict__ in,
+                                                                 const int32_t *__restrict__ st_in,
+                                                                 T *__restrict__ q, const DrillDownScale a) {
+  const uint64_t t = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (t >= a.total) return;
+  const bool def_nan = a.def_nan != 0;
+  uint64_t c = t, n = 1;
+#pragma unroll
+  for (int d = kMaxDims - 1; d >= 0; --d) {
+    if (d < a.nd) {
+      const uint32_t digit = (uint32_t)(c % a.old_len[d]);
+      c /= a.old_len[d];
+      if (a.tab_off[d] >= 0) n *= a.tab[a.tab_off[d] + digit];
+    }
+  }
+  const T x = in[t];
+  const double old_value = Cell<T>::to_f64(x);
+  // `if (!oldValue) continue` (in-memory.js:386-387): unset, 0, -0 and NaN are all skipped
+  const bool has = cell_is_set<T>(x, HAS_STATUS ? st_in[t] : OLAP_STATUS_SET, HAS_STATUS, def_nan) &&
+                   old_value == old_value && old_value != 0.0;
+  const double r = a.divide ? old_value / (double)n : old_value;  // :419 / :422
+  T ov;
+  int32_t os;
+  emit_cell<T>(r, has && !is_default_f64(r, def_nan), def_nan, ov, os);
+  q[t] = ov;
+}
+
 // ======================================================================= element-wise helpers
 template <typename T>
 __global__ __launch_bounds__(kBlock) void canonicalize_kernel(T *values, int32_t *status, uint64_t n, int def_nan_i,
@@ -564,6 +734,8 @@ struct Launch {
                                  const Remap &r, hipStream_t stream);
   static hipError_t drilldown(bool has_status, const T *in, const int32_t *st_in, T *out, int32_t *st_out,
                               const DrillDown &a, hipStream_t stream);
+  static hipError_t drilldown_scale(bool has_status, const T *in, const int32_t *st_in, T *q, const DrillDownScale &a,
+                                    hipStream_t stream);
   static hipError_t canonicalize(T *values, int32_t *status, uint64_t n, int def_nan, int use_status,
                                  hipStream_t stream);
   static hipError_t from_f64(const double *src, T *values, int32_t *status, uint64_t n, int def_nan,
@@ -598,6 +770,33 @@ static hipError_t drillup_axis_launch(const T *in, const int32_t *st_in, T *out,
   const uint64_t row_blocks = a.outer * a.G * a.blocks_per_row;
   const bool rows = a.n_vec >= 128 && row_blocks < 0x7FFFFFFFull;
   constexpr int U = 4;  // rows in flight per lane (tools/microbench.hip: U=2..10 within 2 %)
+  if (!rows) {
+    // LDS tile regime for small `inner` (below 16 B per lane the flat regime's accesses waste most
+    // of every cache line): whole rows of K*inner cells staged per workgroup, kTileBytes of cells
+    const uint64_t row_elems = a.K * a.inner;
+    const uint64_t budget = kTileBytes / sizeof(T);
+    const uint64_t csr_bytes = (a.G + 1 + a.K) * 4;
+    if (a.aligned16 && a.inner < 16 && row_elems > 0 && row_elems * 4 <= budget && csr_bytes <= 16 * 1024 &&
+        a.G * a.inner <= 0xFFFFFFFFull) {
+      DrillUpTile tl;
+      tl.rows_per_tile = (uint32_t)((budget / row_elems) & ~3ull);
+      tl.row_elems = (uint32_t)row_elems;
+      tl.out_row = (uint32_t)(a.G * a.inner);
+      tl.inner = (uint32_t)a.inner;
+      const uint64_t tiles = (a.outer + tl.rows_per_tile - 1) / tl.rows_per_tile;
+      const bool all = contig && a.G == 1;
+      const size_t lds = kTileBytes + (HS ? budget * 4 : 0) + (all ? 0 : csr_bytes);
+      if (tiles < 0x7FFFFFFFull) {
+#define OLAP_TILE(F, A) hipLaunchKernelGGL((drillup_tile_kernel<T, METHOD, HS, F, A>), (unsigned)tiles, kBlock, lds, stream, in, st_in, out, st_out, a, tl)
+        if constexpr (kAdditive && !HS) {
+          if (fast) { if (all) OLAP_TILE(true, true); else OLAP_TILE(true, false); return hipGetLastError(); }
+        }
+        if (all) OLAP_TILE(false, true); else OLAP_TILE(false, false);
+#undef OLAP_TILE
+        return hipGetLastError();
+      }
+    }
+  }
 #define OLAP_ROWS(C, F) hipLaunchKernelGGL((drillup_rows_kernel<T, METHOD, HS, VEC, U, C, F>), (unsigned)row_blocks, kBlock, 0, stream, in, st_in, out, st_out, a)
 #define OLAP_FLAT(F) hipLaunchKernelGGL((drillup_flat_kernel<T, METHOD, HS, VEC, F>), grid_for(a.total), kBlock, 0, stream, in, st_in, out, st_out, a)
   if (rows) {
@@ -704,6 +903,16 @@ hipError_t Launch<T>::drilldown(bool has_status, const T *in, const int32_t *st_
   const unsigned grid = grid_for(a.total);
   if (has_status) hipLaunchKernelGGL((drilldown_kernel<T, true>), grid, kBlock, 0, stream, in, st_in, out, st_out, a);
   else hipLaunchKernelGGL((drilldown_kernel<T, false>), grid, kBlock, 0, stream, in, st_in, out, st_out, a);
+  return hipGetLastError();
+}
+
+template <typename T>
+hipError_t Launch<T>::drilldown_scale(bool has_status, const T *in, const int32_t *st_in, T *q, const DrillDownScale &a,
+                                      hipStream_t stream) {
+  if (a.total == 0) return hipSuccess;
+  const unsigned grid = grid_for(a.total);
+  if (has_status) hipLaunchKernelGGL((drilldown_scale_kernel<T, true>), grid, kBlock, 0, stream, in, st_in, q, a);
+  else hipLaunchKernelGGL((drilldown_scale_kernel<T, false>), grid, kBlock, 0, stream, in, st_in, q, a);
   return hipGetLastError();
 }
 

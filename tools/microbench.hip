@@ -124,6 +124,7 @@ int main(int argc, char **argv) {
   a.order = nullptr;
   a.gstart = gstart;
   a.def_nan = 0;
+  a.aligned16 = 1;
   const unsigned rows_grid = (unsigned)a.blocks_per_row;
 
   std::vector<Variant> vs;

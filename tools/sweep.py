@@ -1,0 +1,94 @@
+#!/usr/bin/env python3
+"""Developer tool: times drillUp over shapes/axes/methods on one GPU (HIP events on torch's stream)
+and prints algorithmic GB/s, to find the shapes where a kernel is far from the HBM roofline.
+
+  python tools/sweep.py [--quick]
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from __graft_entry__ import load_package  # noqa: E402
+
+pkg = load_package()
+from olap_in_memory_amd.sharded import HipEngine  # noqa: E402
+
+eng = HipEngine("cuda:0")
+L = pkg.lib()
+
+
+def bench(plan_fn, n_in, n_out, elem=4, with_mask=False, iters=30):
+    vals = eng.empty(n_in, "float32")
+    st = eng.empty(n_in, "int32")
+    pkg.capi.check(L.olap_fill_seeded(vals.data_ptr(), st.data_ptr(), n_in, 0, 2, 1234, 0.9 if with_mask else 1.0, eng.stream()))
+    out = eng.empty(n_out, "float32")
+    ost = eng.empty(n_out, "int32")
+    plan = plan_fn()
+    args = (vals.data_ptr(), st.data_ptr() if with_mask else None, out.data_ptr(), ost.data_ptr() if with_mask else None, eng.stream())
+    for _ in range(3):
+        plan.run(*args)
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters):
+        plan.run(*args)
+    b.record()
+    torch.cuda.synchronize()
+    ms = a.elapsed_time(b) / iters
+    nbytes = (n_in + n_out) * elem * (2 if with_mask else 1)
+    return ms, nbytes / (ms * 1e-3) / 1e9, plan.kernel_name
+
+
+def ident(n):
+    return np.arange(n, dtype=np.uint32)
+
+
+rows = []
+quick = "--quick" in sys.argv
+shape = [10] * 8
+n = 10 ** 8
+for axis in range(8):
+    new = list(shape)
+    new[axis] = 1
+    maps = [np.zeros(10, np.uint32) if i == axis else ident(10) for i in range(8)]
+    for method in (["sum"] if quick else ["sum", "highest", "first"]):
+        ms, gbs, k = bench(lambda: pkg.Plan.drillup("float32", 0.0, method, shape, new, maps), n, n // 10)
+        rows.append(("[10]^8 axis%d->all %s" % (axis, method), ms, gbs, k))
+ms, gbs, k = bench(lambda: pkg.Plan.drillup("float32", 0.0, "sum", shape, [1] + shape[1:], [np.zeros(10, np.uint32)] + [ident(10)] * 7), n, n // 10, with_mask=True)
+rows.append(("[10]^8 axis0->all sum +mask", ms, gbs, k))
+# config 5 shapes
+s5 = [3652, 100, 274]
+n5 = int(np.prod(s5))
+day_to_month = (np.arange(3652) // 30.4375).astype(np.uint32)
+G = int(day_to_month.max()) + 1
+for method in ["sum", "average", "first", "last"]:
+    ms, gbs, k = bench(lambda: pkg.Plan.drillup("float32", 0.0, method, s5, [G, 100, 274], [day_to_month, ident(100), ident(274)]), n5, G * 27400)
+    rows.append(("C5 day->month %s" % method, ms, gbs, k))
+city_to_country = (np.arange(100) // 10).astype(np.uint32)
+ms, gbs, k = bench(lambda: pkg.Plan.drillup("float32", 0.0, "sum", s5, [3652, 10, 274], [ident(3652), city_to_country, ident(274)]), n5, 3652 * 10 * 274)
+rows.append(("C5 city->country sum (3652 outer)", ms, gbs, k))
+interleaved = (np.arange(100) % 10).astype(np.uint32)
+ms, gbs, k = bench(lambda: pkg.Plan.drillup("float32", 0.0, "sum", s5, [3652, 10, 274], [ident(3652), interleaved, ident(274)]), n5, 3652 * 10 * 274)
+rows.append(("C5 interleaved groups sum", ms, gbs, k))
+# dice / reorder / drilldown
+sel = [ident(10)] * 8
+sel4 = list(sel)
+sel4[4] = np.array([1, 4, 7], np.int32)
+ms, gbs, k = bench(lambda: pkg.Plan.dice("float32", 0.0, shape, [10, 10, 10, 10, 3, 10, 10, 10], sel4), n, 3 * 10 ** 7)
+rows.append(("dice dim4 3-of-10 (bytes=in+out)", ms, (2 * 3e7 * 4) / (ms * 1e-3) / 1e9, k))
+sel1 = list(sel)
+sel1[1] = np.array([3], np.int32)
+ms, gbs, k = bench(lambda: pkg.Plan.dice("float32", 0.0, shape, [10, 1, 10, 10, 10, 10, 10, 10], sel1), n, 10 ** 7)
+rows.append(("dice dim1 1-of-10", ms, (2 * 1e7 * 4) / (ms * 1e-3) / 1e9, k))
+ms, gbs, k = bench(lambda: pkg.Plan.reorder("float32", 0.0, shape, [7, 6, 5, 4, 3, 2, 1, 0]), n, n)
+rows.append(("reorder reverse [10]^8", ms, gbs, k))
+ms, gbs, k = bench(lambda: pkg.Plan.reorder("float32", 0.0, shape, [1, 0, 2, 3, 4, 5, 6, 7]), n, n)
+rows.append(("reorder swap dim0/1", ms, gbs, k))
+month_of_day = day_to_month
+ms, gbs, k = bench(lambda: pkg.Plan.drilldown("float32", 0.0, "sum", [G, 100, 274], s5, [month_of_day, ident(100), ident(274)]), G * 27400, n5)
+rows.append(("drillDown month->day", ms, gbs, k))
+for r in rows:
+    print("%-40s %9.1f us %9.1f GB/s  %.3f  %s" % (r[0], r[1] * 1e3, r[2], r[2] / 8000.0, r[3]))
