@@ -78,6 +78,8 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--rehearse", action="store_true",
+                    help="developer aid: N ranks share cuda:0 and talk over gloo (exercises the N>1 code path on a 1-GPU box; numbers are meaningless)")
     args = ap.parse_args()
 
     import torch
@@ -97,10 +99,15 @@ def main():
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: libolapgpu has no CPU fallback")
+    if args.rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     pkg.capi.check(pkg.lib().olap_set_device(local_rank))
     if world > 1:
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if args.rehearse:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     engine = HipEngine(torch.device("cuda", local_rank))
 
     if world == 1:
@@ -131,7 +138,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if args.rehearse else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

@@ -52,7 +52,11 @@ typedef enum {
   OLAP_LOWEST = 3,
   OLAP_FIRST = 4,
   OLAP_LAST = 5,
-  OLAP_PRODUCT = 6
+  OLAP_PRODUCT = 6,
+  /* Not a reference method.  The shard-local half of `average` for a cube partitioned across
+   * GPUs: out_values receives the (undivided) float64 sum of the set cells, out_status receives
+   * the NUMBER of contributions (not a mask).  Ranks add both and call olap_average_finish(). */
+  OLAP_PARTIAL_AVERAGE = 7
 } olap_method;
 
 typedef enum {
@@ -162,6 +166,10 @@ int olap_convert_to_f64(const void *values, double *dst_f64, uint64_t n, int dty
  * generator); `first_cell` lets a shard generate its own slab. */
 int olap_fill_seeded(void *values, int32_t *status, uint64_t n, uint64_t first_cell, int dtype,
                      uint32_t seed, double frac, void *stream);
+/* Completes a sharded `average` (in-memory.js:323-331): values[i] = counts[i] mod 65536 ?
+ * values[i] / (counts[i] mod 65536) : values[i]; out_status (optional) gets the mask. */
+int olap_average_finish(void *values, const int32_t *counts, int32_t *out_status, uint64_t n,
+                        int dtype, int default_kind, void *stream);
 /* `total` getter (in-memory.js:22-28): float64 sum of the set cells, and their count.
  * Synchronises `stream`. */
 int olap_total(const void *values, const int32_t *status, uint64_t n, int dtype, int default_kind,

@@ -8,6 +8,7 @@ DTYPES = {"int32": 0, "uint32": 1, "float32": 2, "float64": 3}
 DTYPE_NAMES = {v: k for k, v in DTYPES.items()}
 DTYPE_SIZE = {0: 4, 1: 4, 2: 4, 3: 8}
 METHODS = {"sum": 0, "average": 1, "highest": 2, "lowest": 3, "first": 4, "last": 5, "product": 6}
+PARTIAL_AVERAGE = 7  # shard-local half of `average` (include/olap_hip.h)
 DEFAULT_ZERO, DEFAULT_NAN = 0, 1
 STATUS_SET = 0x2
 
@@ -64,6 +65,7 @@ SIGNATURES = {
     "olap_convert_from_f64": (_i32, [_vp, _vp, _vp, _u64, _i32, _i32, _vp]),
     "olap_convert_to_f64": (_i32, [_vp, _vp, _u64, _i32, _vp]),
     "olap_fill_seeded": (_i32, [_vp, _vp, _u64, _u64, _i32, C.c_uint32, _dbl, _vp]),
+    "olap_average_finish": (_i32, [_vp, _vp, _vp, _u64, _i32, _i32, _vp]),
     "olap_total": (_i32, [_vp, _vp, _u64, _i32, _i32, _pdbl, _pu64, _vp]),
     "olap_store_create": (_i32, [_pvp, _u64, _i32, _i32]),
     "olap_store_destroy": (None, [_vp]),

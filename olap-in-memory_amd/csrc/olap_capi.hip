@@ -11,6 +11,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -118,7 +119,7 @@ extern "C" int olap_device_synchronize(void) {
 }
 
 // ------------------------------------------------------------------ plans
-enum PlanKind { PLAN_DRILLUP_AXIS, PLAN_DRILLUP_GENERIC, PLAN_GATHER, PLAN_LOAD, PLAN_DRILLDOWN };
+enum PlanKind { PLAN_DRILLUP_AXIS, PLAN_DRILLUP_GENERIC, PLAN_GATHER, PLAN_LOAD, PLAN_DRILLDOWN, PLAN_BRICK };
 
 struct olap_plan {
   PlanKind kind;
@@ -130,6 +131,8 @@ struct olap_plan {
   Remap remap{};
   DrillDown dd{};
   DrillDownScale dds{};
+  Brick brick{};
+  uint64_t n_bricks = 0;
   bool dd_two_pass = false;                // float cells, no distributions: scale + broadcast
   void *dev_tab2 = nullptr;                // second table set (two-pass drillDown)
   void *dev_tmp = nullptr;                 // quotients of the two-pass drillDown (old cells)
@@ -204,7 +207,7 @@ extern "C" int olap_drillup_plan(olap_plan **out, int dtype, int default_kind, i
   *out = nullptr;
   int rc;
   if ((rc = check_dtype(dtype)) || (rc = check_default(default_kind))) return rc;
-  if (method < OLAP_SUM || method > OLAP_PRODUCT)
+  if (method < OLAP_SUM || method > OLAP_PARTIAL_AVERAGE)
     return fail(OLAP_ERR_UNSUPPORTED_METHOD, "Unsupported aggregation method: %d", method);
   if ((rc = check_dims(ndim, old_len, new_len))) return rc;
   if (ndim > 0 && !maps) return fail(OLAP_ERR_INVALID_ARGUMENT, "maps is NULL");
@@ -468,6 +471,155 @@ extern "C" int olap_reorder_plan(olap_plan **out, int dtype, int default_kind, i
     dims[d].arithmetic = true;
     dims[d].stride = old_stride[perm[d]];
   }
+  // merge new dims that are adjacent in the source too, and drop extent-1 dims
+  std::vector<RemapDim> m;
+  for (auto &d : dims) {
+    if (d.len == 1 && ndim > 1) continue;
+    if (!m.empty() && m.back().stride == d.stride * d.len && (uint64_t)m.back().len * d.len <= 0xFFFFFFFFull) {
+      m.back().len *= d.len;
+      m.back().stride = d.stride;
+    } else {
+      m.push_back(d);
+    }
+  }
+  const bool contiguous_tail = m.empty() || m.back().stride == 1;
+  if (!contiguous_tail && (int)m.size() <= kMaxDims && p->out_cells > 0) {
+    // brick transpose: pick chunk extents so that a brick is long in both orders
+    const int n = (int)m.size();
+    std::vector<uint64_t> out_stride(n);
+    uint64_t st = 1;
+    for (int d = n - 1; d >= 0; --d) {
+      out_stride[d] = st;
+      st *= m[d].len;
+    }
+    std::vector<int> by_in(n), by_out(n);
+    for (int d = 0; d < n; ++d) by_in[d] = by_out[d] = d;
+    std::sort(by_in.begin(), by_in.end(), [&](int x, int y) { return m[x].stride < m[y].stride; });
+    std::sort(by_out.begin(), by_out.end(), [&](int x, int y) { return out_stride[x] < out_stride[y]; });
+    // tuning knobs (developer use): OLAP_BRICK_TARGET = run length aimed at in both orders,
+    // OLAP_BRICK_CAP = cells per brick
+    uint64_t cap = (32 * 1024) / olap_dtype_size(dtype) / 2;  // 16 KiB of float32
+    uint32_t first_target = 64;
+    if (const char *e = getenv("OLAP_BRICK_TARGET")) first_target = (uint32_t)std::max(4, atoi(e));
+    if (const char *e = getenv("OLAP_BRICK_CAP")) cap = (uint64_t)std::max(64, atoi(e));
+    std::vector<uint32_t> chunk(n, 1);
+    for (uint32_t target = first_target; target >= 4; target /= 2) {
+      std::fill(chunk.begin(), chunk.end(), 1u);
+      auto grow = [&](const std::vector<int> &order) {
+        uint64_t prod = 1;
+        for (int d : order) {
+          if (prod >= target) break;
+          uint64_t want = (target + prod - 1) / prod;
+          // prefer an extent that divides the dimension (no ragged bricks) when one is close
+          for (uint64_t c2 = want; c2 <= 2 * want && c2 <= m[d].len; ++c2)
+            if (m[d].len % c2 == 0) {
+              want = c2;
+              break;
+            }
+          const uint32_t c = (uint32_t)std::min<uint64_t>(m[d].len, want);
+          chunk[d] = std::max(chunk[d], c);
+          prod *= c;
+        }
+      };
+      grow(by_in);
+      grow(by_out);
+      uint64_t e = 1;
+      for (int d = 0; d < n; ++d) e *= chunk[d];
+      if (e <= cap) break;
+    }
+    Brick &b = p->brick;
+    b.nd = n;
+    uint64_t elems = 1, bricks = 1;
+    bool ragged = false, small_chunks = true;
+    for (int d = 0; d < n; ++d) {
+      b.len[d] = m[d].len;
+      b.chunk[d] = chunk[d];
+      b.nblk[d] = (m[d].len + chunk[d] - 1) / chunk[d];
+      b.in_stride[d] = m[d].stride;
+      b.out_stride[d] = out_stride[d];
+      elems *= chunk[d];
+      bricks *= b.nblk[d];
+      ragged = ragged || (m[d].len % chunk[d]) != 0;
+      small_chunks = small_chunks && chunk[d] <= 127;
+    }
+    std::vector<int> act_rd, act_wr;  // active dims, fastest first in each order
+    for (int d : by_in)
+      if (chunk[d] > 1) act_rd.push_back(d);
+    for (int d : by_out)
+      if (chunk[d] > 1) act_wr.push_back(d);
+    // offsets inside a brick must fit 32 bits, digits one byte each
+    uint64_t span_in = 0, span_out = 0;
+    for (int d : act_rd) {
+      span_in += (uint64_t)(chunk[d] - 1) * m[d].stride;
+      span_out += (uint64_t)(chunk[d] - 1) * out_stride[d];
+    }
+    if (bricks < 0x7FFFFFFFull && elems <= cap && act_rd.size() <= 4 && small_chunks && span_in < 0xFFFFFFFFull &&
+        span_out < 0xFFFFFFFFull) {
+      b.n_act = (int)act_rd.size();
+      for (int k = 0; k < 4; ++k) b.act_dim[k] = k < b.n_act ? act_rd[k] : -1;
+      b.elems = (uint32_t)elems;
+      b.ragged = ragged;
+      b.def_nan = p->def_nan;
+      // tables: 5 arrays of `elems` uint32
+      std::vector<uint32_t> tabs(5 * elems);
+      uint32_t *rd_off = tabs.data(), *wr_off = rd_off + elems, *wr_lds = wr_off + elems, *rd_dig = wr_lds + elems,
+               *wr_dig = rd_dig + elems;
+      auto slot = [&](int d) {  // byte position of dim d in the packed digits
+        for (int k = 0; k < b.n_act; ++k)
+          if (act_rd[k] == d) return k;
+        return 0;
+      };
+      std::vector<uint32_t> lds_stride(n, 0);
+      {
+        uint32_t ls = 1;
+        for (int d : act_rd) {
+          lds_stride[d] = ls;
+          ls *= chunk[d];
+        }
+      }
+      for (uint64_t e = 0; e < elems; ++e) {
+        uint64_t c = e, off = 0;
+        uint32_t dig = 0;
+        for (int d : act_rd) {
+          const uint32_t g = (uint32_t)(c % chunk[d]);
+          c /= chunk[d];
+          off += (uint64_t)g * m[d].stride;
+          dig |= g << (8 * slot(d));
+        }
+        rd_off[e] = (uint32_t)off;
+        rd_dig[e] = dig;
+      }
+      for (uint64_t f = 0; f < elems; ++f) {
+        uint64_t c = f, off = 0;
+        uint32_t dig = 0, pos = 0;
+        for (int d : act_wr) {
+          const uint32_t g = (uint32_t)(c % chunk[d]);
+          c /= chunk[d];
+          off += (uint64_t)g * out_stride[d];
+          dig |= g << (8 * slot(d));
+          pos += g * lds_stride[d];
+        }
+        wr_off[f] = (uint32_t)off;
+        wr_dig[f] = dig;
+        wr_lds[f] = pos;
+      }
+      if ((rc = upload(&p->dev_tab, tabs.data(), tabs.size() * sizeof(uint32_t)))) {
+        olap_plan_destroy(p);
+        return rc;
+      }
+      const uint32_t *dev = (const uint32_t *)p->dev_tab;
+      b.rd_off = dev;
+      b.wr_off = dev + elems;
+      b.wr_lds = dev + 2 * elems;
+      b.rd_dig = dev + 3 * elems;
+      b.wr_dig = dev + 4 * elems;
+      p->kind = PLAN_BRICK;
+      p->n_bricks = bricks;
+      p->kernel_name = "reorder_brick_kernel";
+      *out = p;
+      return OLAP_OK;
+    }
+  }
   if ((rc = finish_remap(p, dims, p->out_cells, true))) {
     olap_plan_destroy(p);
     return rc;
@@ -714,6 +866,9 @@ static int run_typed(olap_plan *p, const void *in_v, const int32_t *in_s, void *
     case PLAN_LOAD:
       e = Launch<T>::load_scatter(hs, in, in_s, out, out_s, p->remap, stream);
       break;
+    case PLAN_BRICK:
+      e = Launch<T>::reorder_brick(hs, in, in_s, out, out_s, p->brick, p->n_bricks, stream);
+      break;
     case PLAN_DRILLDOWN: {
       if (p->dd_two_pass) {
         T *q = (T *)p->dev_tmp;
@@ -821,6 +976,18 @@ extern "C" int olap_fill_seeded(void *values, int32_t *status, uint64_t n, uint6
   hipError_t e = hipSuccess;
   DISPATCH_DTYPE(dtype, e = Launch<T>::fill_seeded((T *)values, status, n, first_cell, seed, frac, (hipStream_t)stream));
   if (e != hipSuccess) return hip_fail(e, "fill_seeded");
+  return OLAP_OK;
+}
+
+extern "C" int olap_average_finish(void *values, const int32_t *counts, int32_t *out_status, uint64_t n, int dtype,
+                                   int default_kind, void *stream) {
+  int rc;
+  if ((rc = check_dtype(dtype)) || (rc = check_default(default_kind))) return rc;
+  if (n && (!values || !counts)) return fail(OLAP_ERR_INVALID_ARGUMENT, "values/counts is NULL");
+  if ((rc = require_device())) return rc;
+  hipError_t e = hipSuccess;
+  DISPATCH_DTYPE(dtype, e = Launch<T>::average_finish((T *)values, counts, out_status, n, default_kind == OLAP_DEFAULT_NAN, (hipStream_t)stream));
+  if (e != hipSuccess) return hip_fail(e, "average_finish");
   return OLAP_OK;
 }
 

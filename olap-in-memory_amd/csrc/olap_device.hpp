@@ -140,7 +140,7 @@ struct Agg {
       has = true;
     } else {
       double r;
-      if constexpr (METHOD == OLAP_SUM || METHOD == OLAP_AVERAGE) r = acc + v;
+      if constexpr (METHOD == OLAP_SUM || METHOD == OLAP_AVERAGE || METHOD == OLAP_PARTIAL_AVERAGE) r = acc + v;
       else if constexpr (METHOD == OLAP_HIGHEST) r = js_max(acc, v);
       else if constexpr (METHOD == OLAP_LOWEST) r = js_min(acc, v);
       else if constexpr (METHOD == OLAP_FIRST) r = acc;

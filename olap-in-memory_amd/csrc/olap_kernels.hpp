@@ -57,7 +57,7 @@ struct Lane {
         // changes nothing; the reference's "restart when the running sum hits 0" is invisible
         // for addition, so the plain float64 running sum is exact.
         agg[e].acc += Cell<T>::to_f64(x);
-        if constexpr (METHOD == OLAP_AVERAGE) agg[e].count += Cell<T>::is_default(x, false) ? 0u : 1u;
+        if constexpr (METHOD == OLAP_AVERAGE || METHOD == OLAP_PARTIAL_AVERAGE) agg[e].count += Cell<T>::is_default(x, false) ? 0u : 1u;
       } else {
         const int32_t sx = HAS_STATUS ? s.v[e] : OLAP_STATUS_SET;
         if (cell_is_set<T>(x, sx, HAS_STATUS, def_nan)) {
@@ -82,10 +82,11 @@ struct Lane {
           // `sum`: the output is set iff the sum is not the default (0), which also covers
           // "nothing contributed"; `average` additionally needs one contribution
           agg[e].has = agg[e].acc != 0.0;
-          if constexpr (METHOD == OLAP_AVERAGE) agg[e].has = agg[e].has && agg[e].count != 0;
+          if constexpr (METHOD == OLAP_AVERAGE || METHOD == OLAP_PARTIAL_AVERAGE) agg[e].has = agg[e].has && agg[e].count != 0;
         }
         agg[e].finish(def_nan);
         emit_cell<T>(agg[e].acc, agg[e].has, def_nan, ov.v[e], os.v[e]);
+        if constexpr (METHOD == OLAP_PARTIAL_AVERAGE) os.v[e] = (int32_t)agg[e].count;  // count, not a mask
       }
     }
     if constexpr (NT) {
@@ -374,6 +375,7 @@ __global__ __launch_bounds__(kBlock) void drillup_generic_kernel(const T *__rest
   T ov;
   int32_t os;
   emit_cell<T>(agg.acc, agg.has, def_nan, ov, os);
+  if constexpr (METHOD == OLAP_PARTIAL_AVERAGE) os = (int32_t)agg.count;
   out[t] = ov;
   if (st_out) st_out[t] = os;
 }
@@ -488,6 +490,133 @@ __global__ __launch_bounds__(kBlock) void load_scatter_kernel(const T *__restric
   }
   mine[dst] = set ? v : Cell<T>::default_value(def_nan);
   if (mine_st) mine_st[dst] = set ? OLAP_STATUS_SET : 0;
+}
+
+// ======================================================================= K4: reorder as a brick transpose
+// in-memory.js:178-211.  When the output's fastest dimension is not the input's fastest one a plain
+// gather reads 4 B per cache line.  Here a workgroup owns a BRICK: a small range of every dimension
+// chosen so that the brick is >= 64 cells long both along the input's fastest dimensions and along
+// the output's fastest ones.  The brick is read in input order (coalesced), parked in LDS (padded
+// against bank conflicts) and written in output order (coalesced).
+struct Brick {
+  int nd;                        // collapsed dims, output (new) order
+  uint32_t len[kMaxDims];        // extent of each dim
+  uint32_t chunk[kMaxDims];      // brick extent of each dim (1 for dims outside the brick)
+  uint32_t nblk[kMaxDims];       // ceil(len / chunk)
+  uint64_t in_stride[kMaxDims];  // stride in the source
+  uint64_t out_stride[kMaxDims]; // stride in the destination
+  int n_act;                     // dims with chunk > 1 (<= 4: their digits are packed in 4 bytes)
+  int32_t act_dim[4];            // the active dims
+  uint32_t elems;                // cells per brick
+  int ragged;                    // some chunk does not divide its dim: edge bricks are partial
+  int def_nan;
+  // All bricks are congruent, so the offsets of a brick's cells relative to its origin are tables
+  // built once by the plan (L2-resident, read coalesced): e = position in read (source) order,
+  // f = position in write (destination) order.
+  const uint32_t *rd_off;   // [elems] source offset of cell e
+  const uint32_t *wr_off;   // [elems] destination offset of cell f
+  const uint32_t *wr_lds;   // [elems] read-order position e of cell f (where it sits in LDS)
+  const uint32_t *rd_dig;   // [elems] digits of cell e in the active dims, one byte each
+  const uint32_t *wr_dig;   // [elems] same for cell f
+};
+
+__device__ __forceinline__ uint32_t lds_pad(uint32_t e) { return e + (e >> 5); }
+
+template <typename T, bool HAS_STATUS>
+__global__ __launch_bounds__(kBlock) void reorder_brick_kernel(const T *__restrict__ in,
+                                                               const int32_t *__restrict__ st_in,
+                                                               T *__restrict__ out,
+                                                               int32_t *__restrict__ st_out, const Brick b) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  T *tile = reinterpret_cast<T *>(lds_raw);
+  const size_t tile_bytes = ((size_t)lds_pad(b.elems) * sizeof(T) + 15) & ~(size_t)15;
+  int32_t *stile = reinterpret_cast<int32_t *>(lds_raw + tile_bytes);
+
+  // brick origin: wave-uniform scalar arithmetic on blockIdx
+  uint64_t c = blockIdx.x, base_in = 0, base_out = 0;
+  // per active dim: cells of this brick inside the cube, one byte each (unused bytes: always inside)
+  uint32_t lim = b.n_act >= 4 ? 0u : (0x7F7F7F7Fu << (8 * b.n_act));
+  bool partial = false;
+#pragma unroll
+  for (int d = kMaxDims - 1; d >= 0; --d) {
+    if (d < b.nd) {
+      const uint32_t origin = (uint32_t)(c % b.nblk[d]) * b.chunk[d];
+      c /= b.nblk[d];
+      base_in += (uint64_t)origin * b.in_stride[d];
+      base_out += (uint64_t)origin * b.out_stride[d];
+      if (b.ragged) {
+        const uint32_t left = b.len[d] - origin;
+        const uint32_t l = left < b.chunk[d] ? left : b.chunk[d];
+        partial = partial || l < b.chunk[d];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (k < b.n_act && b.act_dim[k] == d) lim |= l << (8 * k);
+      }
+    }
+  }
+  // a cell is inside iff each digit byte is below its limit byte: SWAR compare of 4 bytes
+  auto inside = [&](uint32_t dig) {
+    // bytes are < 128 (chunk <= 127), so (dig | 0x80808080) - lim keeps bit 7 of a byte iff dig >= lim there
+    return (((dig | 0x80808080u) - lim) & 0x80808080u) == 0u;
+  };
+  const bool def_nan = b.def_nan != 0;
+  const T *src = in + base_in;
+  const int32_t *ssrc = HAS_STATUS ? st_in + base_in : nullptr;
+  // both phases are latency chains (table entry -> address -> data), so each lane keeps UB of them
+  // in flight
+  constexpr int UB = 8;
+  for (uint32_t e0 = threadIdx.x; e0 < b.elems; e0 += kBlock * UB) {
+    uint32_t off[UB];
+    bool ok[UB];
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+      const uint32_t e = e0 + u * kBlock;
+      ok[u] = e < b.elems;
+      if (ok[u] && partial) ok[u] = inside(b.rd_dig[e]);
+      off[u] = ok[u] ? b.rd_off[e] : 0u;
+    }
+    T x[UB];
+    int32_t sx[UB];
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+      if (ok[u]) {
+        x[u] = src[off[u]];
+        if constexpr (HAS_STATUS) sx[u] = ssrc[off[u]];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+      if (ok[u]) {
+        const uint32_t e = e0 + u * kBlock;
+        tile[lds_pad(e)] = x[u];
+        if constexpr (HAS_STATUS) stile[lds_pad(e)] = sx[u];
+      }
+    }
+  }
+  __syncthreads();
+  T *dst = out + base_out;
+  int32_t *sdst = st_out ? st_out + base_out : nullptr;
+  for (uint32_t f0 = threadIdx.x; f0 < b.elems; f0 += kBlock * UB) {
+    uint32_t off[UB], pos[UB];
+    bool ok[UB];
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+      const uint32_t f = f0 + u * kBlock;
+      ok[u] = f < b.elems;
+      if (ok[u] && partial) ok[u] = inside(b.wr_dig[f]);
+      off[u] = ok[u] ? b.wr_off[f] : 0u;
+      pos[u] = ok[u] ? b.wr_lds[f] : 0u;
+    }
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+      if (ok[u]) {
+        const T x = tile[lds_pad(pos[u])];
+        const bool set = cell_is_set<T>(x, HAS_STATUS ? stile[lds_pad(pos[u])] : OLAP_STATUS_SET, HAS_STATUS, def_nan);
+        dst[off[u]] = set ? x : Cell<T>::default_value(def_nan);
+        if (sdst) sdst[off[u]] = set ? OLAP_STATUS_SET : 0;
+      }
+    }
+  }
 }
 
 // ======================================================================= K3: drillDown
@@ -670,6 +799,28 @@ __global__ __launch_bounds__(kBlock) void fill_seeded_kernel(T *values, int32_t 
   }
 }
 
+// second half of a sharded average (in-memory.js:323-331) on reduced (sum, count) pairs
+template <typename T>
+__global__ __launch_bounds__(kBlock) void average_finish_kernel(T *values, const int32_t *counts, int32_t *status, uint64_t n,
+                                                                int def_nan_i) {
+  const bool def_nan = def_nan_i != 0;
+  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kBlock) {
+    const T v = values[i];
+    const uint32_t c16 = (uint32_t)counts[i] & 0xFFFFu;  // Uint16Array counter
+    double r = Cell<T>::to_f64(v);
+    bool has = counts[i] != 0 && !Cell<T>::is_default(v, def_nan);
+    if (c16) {
+      r = (has ? r : (def_nan ? __builtin_nan("") : 0.0)) / (double)c16;
+      has = !is_default_f64(r, def_nan);
+    }
+    T ov;
+    int32_t os;
+    emit_cell<T>(r, has, def_nan, ov, os);
+    values[i] = ov;
+    if (status) status[i] = os;
+  }
+}
+
 // float64 total + count of set cells: wave shuffle -> LDS -> one atomic pair per workgroup
 template <typename T>
 __global__ __launch_bounds__(kBlock) void total_kernel(const T *values, const int32_t *status, uint64_t n, int def_nan_i,
@@ -730,6 +881,8 @@ struct Launch {
                                     int32_t *st_out, const DrillUpGeneric &a, hipStream_t stream);
   static hipError_t gather(bool has_status, int vec, const T *in, const int32_t *st_in, T *out, int32_t *st_out,
                            const Remap &r, hipStream_t stream);
+  static hipError_t reorder_brick(bool has_status, const T *in, const int32_t *st_in, T *out, int32_t *st_out,
+                                  const Brick &b, uint64_t n_bricks, hipStream_t stream);
   static hipError_t load_scatter(bool has_status, const T *his, const int32_t *his_st, T *mine, int32_t *mine_st,
                                  const Remap &r, hipStream_t stream);
   static hipError_t drilldown(bool has_status, const T *in, const int32_t *st_in, T *out, int32_t *st_out,
@@ -743,12 +896,15 @@ struct Launch {
   static hipError_t to_f64(const T *values, double *dst, uint64_t n, hipStream_t stream);
   static hipError_t fill_seeded(T *values, int32_t *status, uint64_t n, uint64_t first, uint32_t seed, double frac,
                                 hipStream_t stream);
+  static hipError_t average_finish(T *values, const int32_t *counts, int32_t *status, uint64_t n, int def_nan,
+                                   hipStream_t stream);
   static hipError_t total(const T *values, const int32_t *status, uint64_t n, int def_nan, double *total,
                           unsigned long long *count, hipStream_t stream);
   static hipError_t set_cell(T *values, int32_t *status, uint64_t index, double value, int is_null, int def_nan,
                              hipStream_t stream);
 };
 
+inline size_t lds_pad_host(size_t e) { return e + (e >> 5); }
 inline unsigned grid_for(uint64_t threads) { return (unsigned)((threads + kBlock - 1) / kBlock); }
 inline unsigned grid_stride_for(uint64_t n) {
   const uint64_t want = (n + kBlock - 1) / kBlock;
@@ -764,7 +920,7 @@ inline unsigned grid_stride_for(uint64_t n) {
 template <typename T, int METHOD, bool HS, int VEC>
 static hipError_t drillup_axis_launch(const T *in, const int32_t *st_in, T *out, int32_t *st_out,
                                       const DrillUpAxis &a, hipStream_t stream) {
-  constexpr bool kAdditive = (METHOD == OLAP_SUM || METHOD == OLAP_AVERAGE);
+  constexpr bool kAdditive = (METHOD == OLAP_SUM || METHOD == OLAP_AVERAGE || METHOD == OLAP_PARTIAL_AVERAGE);
   const bool fast = kAdditive && !HS && !a.def_nan;
   const bool contig = a.order == nullptr;
   const uint64_t row_blocks = a.outer * a.G * a.blocks_per_row;
@@ -833,6 +989,7 @@ static hipError_t drillup_axis_method(int method, int vec, const T *in, const in
     case OLAP_LOWEST: return drillup_axis_vec<T, OLAP_LOWEST, HS>(vec, in, st_in, out, st_out, a, stream);
     case OLAP_FIRST: return drillup_axis_vec<T, OLAP_FIRST, HS>(vec, in, st_in, out, st_out, a, stream);
     case OLAP_LAST: return drillup_axis_vec<T, OLAP_LAST, HS>(vec, in, st_in, out, st_out, a, stream);
+    case OLAP_PARTIAL_AVERAGE: return drillup_axis_vec<T, OLAP_PARTIAL_AVERAGE, HS>(vec, in, st_in, out, st_out, a, stream);
     default: return drillup_axis_vec<T, OLAP_PRODUCT, HS>(vec, in, st_in, out, st_out, a, stream);
   }
 }
@@ -857,6 +1014,7 @@ static hipError_t drillup_generic_method(int method, const T *in, const int32_t 
     case OLAP_LOWEST: OLAP_GEN(OLAP_LOWEST); break;
     case OLAP_FIRST: OLAP_GEN(OLAP_FIRST); break;
     case OLAP_LAST: OLAP_GEN(OLAP_LAST); break;
+    case OLAP_PARTIAL_AVERAGE: OLAP_GEN(OLAP_PARTIAL_AVERAGE); break;
     default: OLAP_GEN(OLAP_PRODUCT); break;
   }
 #undef OLAP_GEN
@@ -883,6 +1041,17 @@ hipError_t Launch<T>::gather(bool has_status, int vec, const T *in, const int32_
     if (vec == 4) OLAP_G(false, 4); else if (vec == 2) OLAP_G(false, 2); else OLAP_G(false, 1);
   }
 #undef OLAP_G
+  return hipGetLastError();
+}
+
+template <typename T>
+hipError_t Launch<T>::reorder_brick(bool has_status, const T *in, const int32_t *st_in, T *out, int32_t *st_out,
+                                    const Brick &b, uint64_t n_bricks, hipStream_t stream) {
+  if (n_bricks == 0) return hipSuccess;
+  const size_t cells = lds_pad_host(b.elems);
+  const size_t lds = ((cells * sizeof(T) + 15) & ~(size_t)15) + (has_status ? cells * 4 : 0);
+  if (has_status) hipLaunchKernelGGL((reorder_brick_kernel<T, true>), (unsigned)n_bricks, kBlock, lds, stream, in, st_in, out, st_out, b);
+  else hipLaunchKernelGGL((reorder_brick_kernel<T, false>), (unsigned)n_bricks, kBlock, lds, stream, in, st_in, out, st_out, b);
   return hipGetLastError();
 }
 
@@ -944,6 +1113,14 @@ hipError_t Launch<T>::fill_seeded(T *values, int32_t *status, uint64_t n, uint64
                                   hipStream_t stream) {
   if (n == 0) return hipSuccess;
   hipLaunchKernelGGL((fill_seeded_kernel<T>), grid_stride_for(n), kBlock, 0, stream, values, status, n, first, seed, frac);
+  return hipGetLastError();
+}
+
+template <typename T>
+hipError_t Launch<T>::average_finish(T *values, const int32_t *counts, int32_t *status, uint64_t n, int def_nan,
+                                     hipStream_t stream) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL((average_finish_kernel<T>), grid_stride_for(n), kBlock, 0, stream, values, counts, status, n, def_nan);
   return hipGetLastError();
 }
 

@@ -8,6 +8,8 @@ map on the sharded axis) reduces each rank's own rows into a partial [G, inner0]
 same kernel and a row sub-map, then ONE collective combines the partials:
 
   sum      -> reduce-scatter (all-reduce when the output does not divide) with ncclSum over xGMI
+  average  -> the same on (float sum, int32 contribution count) pairs produced in ONE local pass
+              (OLAP_PARTIAL_AVERAGE), divided afterwards (olap_average_finish)
   other    -> all-gather of (value, status) partials, then the same drillUp kernel over the rank
               axis: highest / lowest / first / last / product are associative in rank order
 
@@ -69,6 +71,12 @@ class HipEngine:
         capi.check(capi.lib().olap_fill_seeded(values.data_ptr(), status.data_ptr(), int(n), int(first_cell),
                                                capi.DTYPES[dtype], int(seed), float(frac), self.stream()))
 
+    def average_finish(self, values, counts, status, dtype, default):
+        kind = capi.DEFAULT_NAN if default != default else capi.DEFAULT_ZERO
+        capi.check(capi.lib().olap_average_finish(values.data_ptr(), counts.data_ptr(),
+                                                  status.data_ptr() if status is not None else None, values.numel(),
+                                                  capi.DTYPES[dtype], kind, self.stream()))
+
 
 class ShardedStore:
     """One measure of a cube whose dimension 0 is split across the ranks of a process group."""
@@ -127,8 +135,6 @@ class Dim0DrillUp:
         self.dist = dist
         self.s = s = store
         self.method = method
-        if method == "average":
-            raise NotImplementedError("sharded average needs (sum, count) partials; not in this round")
         row_map = np.asarray(row_map, dtype=np.uint32)
         if row_map.size != s.lens[0]:
             raise ValueError("row_map must have one entry per row of dimension 0")
@@ -137,21 +143,25 @@ class Dim0DrillUp:
         new_len = [n_groups] + s.lens[1:]
         maps = [row_map[s.row_lo:s.row_hi]] + [np.arange(l, dtype=np.uint32) for l in s.lens[1:]]
         eng = s.engine
-        self.n_out = n_groups * s.inner0
-        self.local = eng.make_drillup(s.dtype, s.default, method, old_len, new_len, maps)
-        self.additive = method == "sum"
-        self.partial = eng.empty(self.n_out, s.dtype)
-        # sum over a zero default: the mask is a function of the value (set <=> value != 0), so the
-        # additive path neither writes nor ships it
-        self.partial_status = None if (self.additive and not (s.default != s.default)) else eng.empty(self.n_out, "int32")
         w = s.world
+        self.n_out = n_groups * s.inner0
+        self.additive = method in ("sum", "average")
+        local_method = capi.PARTIAL_AVERAGE if (method == "average" and w > 1) else method
+        self.local = eng.make_drillup(s.dtype, s.default, local_method, old_len, new_len, maps)
+        self.partial = eng.empty(self.n_out, s.dtype)
+        # `sum` over a zero default: the mask is a function of the value (set <=> value != 0), so the
+        # path neither writes nor ships it.  `average` ships contribution counts in its place.
+        zero_default = not (s.default != s.default)
+        self.partial_status = None if (method == "sum" and zero_default) else eng.empty(self.n_out, "int32")
         self.scatter = self.additive and w > 1 and self.n_out % w == 0
         self.staged = w > 1 and dist.get_backend(s.group) == "gloo" and getattr(self.partial, "is_cuda", False)
         if w == 1:
             self.result, self.result_status = self.partial, self.partial_status
         elif self.additive:
-            self.result = eng.empty(self.n_out // w if self.scatter else self.n_out, s.dtype)
-            self.result_status = None  # sum over a 0 default: set <=> value != 0
+            n_res = self.n_out // w if self.scatter else self.n_out
+            self.result = eng.empty(n_res, s.dtype)
+            self.result_status = None if self.partial_status is None else eng.empty(n_res, "int32")
+            self.result_counts = eng.empty(n_res, "int32") if method == "average" else None
         else:
             self.gathered = eng.empty(self.n_out * w, s.dtype)
             self.gathered_status = eng.empty(self.n_out * w, "int32")
@@ -168,21 +178,36 @@ class Dim0DrillUp:
             return self.s.rank * per, (self.s.rank + 1) * per
         return 0, self.n_out
 
+    def _sum_across_ranks(self, src, dst):
+        """dst <- element-wise sum of every rank's src (scattered when the output divides)."""
+        s, dist = self.s, self.dist
+        a = src.cpu() if self.staged else src
+        b = a.new_empty(dst.numel()) if self.staged else dst
+        if self.scatter and dist.get_backend(s.group) != "gloo":
+            dist.reduce_scatter_tensor(b, a, op=dist.ReduceOp.SUM, group=s.group)
+        elif self.scatter:  # gloo has no reduce_scatter: all-reduce, keep this rank's slice
+            full = a.clone()
+            dist.all_reduce(full, op=dist.ReduceOp.SUM, group=s.group)
+            lo, hi = self.result_range
+            b.copy_(full[lo:hi])
+        else:
+            b.copy_(a)
+            dist.all_reduce(b, op=dist.ReduceOp.SUM, group=s.group)
+        if self.staged:
+            dst.copy_(b)
+
     def step(self):
         s, dist = self.s, self.dist
         self.local.run(s.values, None, self.partial, self.partial_status)
         if s.world == 1:
             return self.result
         if self.additive:
-            src = self.partial.cpu() if self.staged else self.partial
-            dst = src.new_empty(self.result.numel()) if self.staged else self.result
-            if self.scatter:
-                dist.reduce_scatter_tensor(dst, src, op=dist.ReduceOp.SUM, group=s.group)
-            else:
-                dst.copy_(src)
-                dist.all_reduce(dst, op=dist.ReduceOp.SUM, group=s.group)
-            if self.staged:
-                self.result.copy_(dst)
+            self._sum_across_ranks(self.partial, self.result)
+            if self.method == "average":
+                self._sum_across_ranks(self.partial_status, self.result_counts)
+                s.engine.average_finish(self.result, self.result_counts, self.result_status, s.dtype, s.default)
+            elif self.partial_status is not None:  # sum over a NaN default: set where any rank was set
+                self._sum_across_ranks(self.partial_status, self.result_status)
             return self.result
         if self.staged:
             g = self.partial.cpu().new_empty(self.n_out * s.world)

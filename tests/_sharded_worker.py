@@ -33,6 +33,14 @@ class _OracleDrillUp:
             v = np.where(status.numpy() == 2, v, default)
         o = OracleStore(v.size, dtype, default)
         o.set_data(v)
+        if method == 7:  # OLAP_PARTIAL_AVERAGE: (sum, contribution count)
+            tv, _ = o.drill_up(old_len, new_len, maps, "sum").typed()
+            ones = OracleStore(v.size, dtype, default)
+            ones.set_data(np.where(o.dense()[1], 1.0, default))
+            cnt, _ = ones.drill_up(old_len, new_len, maps, "sum").typed()
+            out_values.copy_(torch.from_numpy(tv.astype(np.float32)))
+            out_status.copy_(torch.from_numpy(cnt.astype(np.int32)))
+            return
         tv, ts = o.drill_up(old_len, new_len, maps, method).typed()
         out_values.copy_(torch.from_numpy(tv.astype(np.float32)))
         if out_status is not None:
@@ -48,6 +56,14 @@ class OracleEngine:
 
     def make_drillup(self, *a):
         return _OracleDrillUp(*a)
+
+    def average_finish(self, values, counts, status, dtype, default):
+        c16 = counts.numpy() & 0xFFFF
+        v = values.numpy().astype(np.float64)
+        r = np.where(c16 != 0, v / np.maximum(c16, 1), v)
+        values.copy_(torch.from_numpy(r.astype(np.float32)))
+        if status is not None:
+            status.copy_(torch.from_numpy(np.where(r != 0, 2, 0).astype(np.int32)))
 
     def fill_seeded(self, values, status, n, first_cell, dtype, seed, frac):
         v, keep = config_cube(first_cell + n, seed, frac)
@@ -65,7 +81,7 @@ def main():
     row_map = np.array([0, 1, 0, 2, 1, 0, 2], np.uint32)
     for frac in (1.0, 0.4):
         s = ShardedStore(lens, "float32", 0.0, rank, world, engine).fill_seeded(77, frac)
-        for method in ("sum", "highest", "lowest", "first", "last", "product"):
+        for method in ("sum", "average", "highest", "lowest", "first", "last", "product"):
             op = s.plan_drillup_dim0(row_map, 3, method)
             res = op.step()
             lo, hi = op.result_range

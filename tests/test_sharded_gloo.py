@@ -39,13 +39,13 @@ def check(results):
         v, _ = config_cube(420, 77, frac)
         o = OracleStore(420, "float32", 0.0)
         o.set_data(v.astype(np.float64))
-        for method in ("sum", "highest", "lowest", "first", "last", "product"):
+        for method in ("sum", "average", "highest", "lowest", "first", "last", "product"):
             ev, _ = o.drill_up(lens, [3, 6, 10], maps, method).typed()
             got = np.full(180, np.nan)
             for res in results:
                 r = res["%s_%s" % (method, frac)]
                 got[r["range"][0]:r["range"][1]] = r["values"]
-            if method in ("sum", "product"):  # float32 partials combined across ranks: 1e-5 relative (north star)
+            if method in ("sum", "average", "product"):  # float32 partials combined across ranks: 1e-5 relative (north star)
                 assert np.allclose(got, ev, rtol=1e-5, atol=0), method
             else:
                 assert np.array_equal(got.astype(np.float32), ev), method
