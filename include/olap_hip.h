@@ -122,6 +122,16 @@ int olap_drilldown_plan(olap_plan **plan, int dtype, int default_kind, int metho
 int olap_dice_plan(olap_plan **plan, int dtype, int default_kind, int ndim,
                    const uint32_t *old_len, const uint32_t *new_len, const int32_t *const *sel);
 
+/* Fused dice -> drillUp (the slice / dice / drillUp chains of src/cube.js:799-857 + :995-1023):
+ * equivalent to olap_dice_plan(old_len -> mid_len, sel) followed by olap_drillup_plan(mid_len ->
+ * new_len, maps, method) with ONE rolled-up dimension, but the selection tables are folded into the
+ * reduction's address computation, so only the surviving cells are read, once, and the diced
+ * intermediate cube is never written.  More than one non-identity map: OLAP_ERR_INVALID_ARGUMENT
+ * (run the two plans instead). */
+int olap_dice_drillup_plan(olap_plan **plan, int dtype, int default_kind, int method, int ndim,
+                           const uint32_t *old_len, const uint32_t *mid_len, const uint32_t *new_len,
+                           const int32_t *const *sel, const uint32_t *const *maps);
+
 /* InMemoryStore.reorder(oldDimensions, newDimensions) — :178-211.  New axis i is old axis perm[i]. */
 int olap_reorder_plan(olap_plan **plan, int dtype, int default_kind, int ndim,
                       const uint32_t *old_len, const int32_t *perm);
@@ -219,6 +229,9 @@ int olap_store_drilldown(const olap_store *store, olap_store **out, int ndim,
                          uint64_t n_dist);
 int olap_store_dice(const olap_store *store, olap_store **out, int ndim, const uint32_t *old_len,
                     const uint32_t *new_len, const int32_t *const *sel);
+int olap_store_dice_drillup(const olap_store *store, olap_store **out, int ndim, const uint32_t *old_len,
+                            const uint32_t *mid_len, const uint32_t *new_len, const int32_t *const *sel,
+                            const uint32_t *const *maps, int method);
 int olap_store_reorder(const olap_store *store, olap_store **out, int ndim,
                        const uint32_t *old_len, const int32_t *perm);
 int olap_store_load(olap_store *store, const olap_store *other, int ndim, const uint32_t *my_len,

@@ -53,6 +53,7 @@ SIGNATURES = {
     "olap_drillup_plan": (_i32, [_pvp, _i32, _i32, _i32, _i32, _pu32, _pu32, _ppu32]),
     "olap_drilldown_plan": (_i32, [_pvp, _i32, _i32, _i32, _i32, _pu32, _pu32, _ppu32, _pdbl, _u64]),
     "olap_dice_plan": (_i32, [_pvp, _i32, _i32, _i32, _pu32, _pu32, _ppi32]),
+    "olap_dice_drillup_plan": (_i32, [_pvp, _i32, _i32, _i32, _i32, _pu32, _pu32, _pu32, _ppi32, _ppu32]),
     "olap_reorder_plan": (_i32, [_pvp, _i32, _i32, _i32, _pu32, _pi32]),
     "olap_load_plan": (_i32, [_pvp, _i32, _i32, _i32, _i32, _pu32, _pu32, _ppi32]),
     "olap_plan_in_cells": (_u64, [_vp]),
@@ -90,6 +91,7 @@ SIGNATURES = {
     "olap_store_drillup": (_i32, [_vp, _pvp, _i32, _pu32, _pu32, _ppu32, _i32]),
     "olap_store_drilldown": (_i32, [_vp, _pvp, _i32, _pu32, _pu32, _ppu32, _i32, _pdbl, _u64]),
     "olap_store_dice": (_i32, [_vp, _pvp, _i32, _pu32, _pu32, _ppi32]),
+    "olap_store_dice_drillup": (_i32, [_vp, _pvp, _i32, _pu32, _pu32, _pu32, _ppi32, _ppu32, _i32]),
     "olap_store_reorder": (_i32, [_vp, _pvp, _i32, _pu32, _pi32]),
     "olap_store_load": (_i32, [_vp, _vp, _i32, _pu32, _pu32, _ppi32]),
 }

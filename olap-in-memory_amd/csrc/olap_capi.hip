@@ -119,7 +119,7 @@ extern "C" int olap_device_synchronize(void) {
 }
 
 // ------------------------------------------------------------------ plans
-enum PlanKind { PLAN_DRILLUP_AXIS, PLAN_DRILLUP_GENERIC, PLAN_GATHER, PLAN_LOAD, PLAN_DRILLDOWN, PLAN_BRICK };
+enum PlanKind { PLAN_DRILLUP_AXIS, PLAN_DRILLUP_GENERIC, PLAN_GATHER, PLAN_LOAD, PLAN_DRILLDOWN, PLAN_BRICK, PLAN_GATHER_REDUCE };
 
 struct olap_plan {
   PlanKind kind;
@@ -133,6 +133,7 @@ struct olap_plan {
   DrillDownScale dds{};
   Brick brick{};
   uint64_t n_bricks = 0;
+  GatherReduce gr{};
   bool dd_two_pass = false;                // float cells, no distributions: scale + broadcast
   void *dev_tab2 = nullptr;                // second table set (two-pass drillDown)
   void *dev_tmp = nullptr;                 // quotients of the two-pass drillDown (old cells)
@@ -433,6 +434,154 @@ extern "C" int olap_dice_plan(olap_plan **out, int dtype, int default_kind, int 
     return rc;
   }
   p->kernel_name = "gather(dice)";
+  *out = p;
+  return OLAP_OK;
+}
+
+// ---- fused dice -> drillUp --------------------------------------------------------------------
+extern "C" int olap_dice_drillup_plan(olap_plan **out, int dtype, int default_kind, int method, int ndim,
+                                      const uint32_t *old_len, const uint32_t *mid_len, const uint32_t *new_len,
+                                      const int32_t *const *sel, const uint32_t *const *maps) {
+  if (!out) return fail(OLAP_ERR_INVALID_ARGUMENT, "plan out-pointer is NULL");
+  *out = nullptr;
+  int rc;
+  if ((rc = check_dtype(dtype)) || (rc = check_default(default_kind))) return rc;
+  if (method < OLAP_SUM || method > OLAP_PARTIAL_AVERAGE)
+    return fail(OLAP_ERR_UNSUPPORTED_METHOD, "Unsupported aggregation method: %d", method);
+  if ((rc = check_dims(ndim, old_len, mid_len)) || (rc = check_dims(ndim, mid_len, new_len))) return rc;
+  if (ndim > 0 && (!sel || !maps)) return fail(OLAP_ERR_INVALID_ARGUMENT, "sel/maps is NULL");
+  int axis = -1, n_changed = 0;
+  for (int d = 0; d < ndim; ++d) {
+    if (mid_len[d] && (!sel[d] || !maps[d])) return fail(OLAP_ERR_INVALID_ARGUMENT, "sel[%d]/maps[%d] is NULL", d, d);
+    for (uint32_t j = 0; j < mid_len[d]; ++j) {
+      if (sel[d][j] >= 0 && (uint32_t)sel[d][j] >= old_len[d])
+        return fail(OLAP_ERR_INDEX_RANGE, "dice selection of dimension %d: entry %u = %d is outside the old dimension (%u items)", d, j, sel[d][j], old_len[d]);
+      if (maps[d][j] >= new_len[d])
+        return fail(OLAP_ERR_INDEX_RANGE, "drillUp map of dimension %d: entry %u = %u is outside the new dimension (%u items)", d, j, maps[d][j], new_len[d]);
+    }
+    if (!is_identity_u32(maps[d], mid_len[d], new_len[d])) {
+      ++n_changed;
+      axis = d;
+    }
+  }
+  if (n_changed > 1)
+    return fail(OLAP_ERR_INVALID_ARGUMENT, "fused dice+drillUp takes one rolled-up dimension (%d given): run the two plans", n_changed);
+  if (n_changed == 0) {
+    if (method != OLAP_AVERAGE && method != OLAP_PARTIAL_AVERAGE)  // a plain dice (average of one cell = the cell too,
+      return olap_dice_plan(out, dtype, default_kind, ndim, old_len, mid_len, sel);  // but keep its count semantics below)
+    axis = ndim - 1;
+    if (ndim == 0) return olap_dice_plan(out, dtype, default_kind, ndim, old_len, mid_len, sel);
+  }
+  if ((rc = require_device())) return rc;
+  olap_plan *p = new (std::nothrow) olap_plan();
+  if (!p) return fail(OLAP_ERR_OUT_OF_MEMORY, "out of host memory");
+  p->kind = PLAN_GATHER_REDUCE;
+  p->dtype = dtype;
+  p->def_nan = default_kind == OLAP_DEFAULT_NAN;
+  p->method = method;
+  p->in_cells = product(old_len, ndim);
+  p->out_cells = product(new_len, ndim);
+  std::vector<uint64_t> old_stride(ndim);
+  {
+    uint64_t s = 1;
+    for (int d = ndim - 1; d >= 0; --d) {
+      old_stride[d] = s;
+      s *= old_len[d];
+    }
+  }
+  // duplicates in a selection: only the LAST new item naming an old item receives its cells (:219-224)
+  auto effective_sel = [&](int d) {
+    std::vector<int64_t> e(mid_len[d], -1);
+    std::vector<int64_t> last(old_len[d] ? old_len[d] : 1, -1);
+    for (uint32_t j = 0; j < mid_len[d]; ++j)
+      if (sel[d][j] >= 0) last[sel[d][j]] = j;
+    for (uint32_t j = 0; j < mid_len[d]; ++j)
+      if (sel[d][j] >= 0 && last[sel[d][j]] == (int64_t)j) e[j] = sel[d][j];
+    return e;
+  };
+  // output dims (collapsed): untouched neighbours merge; the rolled-up axis stays alone
+  std::vector<RemapDim> dims;
+  std::vector<int> dim_of;  // original dim of each collapsed dim's LAST member
+  int axis_c = -1;
+  for (int d = 0; d < ndim; ++d) {
+    RemapDim rd;
+    rd.len = new_len[d];
+    rd.stride = old_stride[d];
+    if (d == axis) {
+      rd.arithmetic = false;  // placeholder: handled through gstart/member_off
+      axis_c = (int)dims.size();
+      dims.push_back(rd);
+      continue;
+    }
+    const std::vector<int64_t> e = effective_sel(d);
+    bool ident = old_len[d] == mid_len[d];
+    for (uint32_t j = 0; ident && j < mid_len[d]; ++j) ident = e[j] == (int64_t)j;
+    rd.arithmetic = ident;
+    if (!ident) {
+      rd.table.resize(mid_len[d]);
+      for (uint32_t j = 0; j < mid_len[d]; ++j) rd.table[j] = e[j] < 0 ? -1 : e[j] * (int64_t)old_stride[d];
+    }
+    const bool prev_mergeable = !dims.empty() && (int)dims.size() - 1 != axis_c && dims.back().arithmetic && rd.arithmetic &&
+                                dims.back().stride == rd.stride * rd.len && (uint64_t)dims.back().len * rd.len <= 0xFFFFFFFFull;
+    if (prev_mergeable) {
+      dims.back().len *= rd.len;
+      dims.back().stride = rd.stride;
+    } else {
+      dims.push_back(rd);
+    }
+  }
+  if ((int)dims.size() > kMaxDims) {
+    olap_plan_destroy(p);
+    return fail(OLAP_ERR_INVALID_ARGUMENT, "more than %d non-mergeable dimensions", kMaxDims);
+  }
+  GatherReduce &g = p->gr;
+  Remap &r = g.r;
+  std::vector<int64_t> tab;
+  r.nd = (int)dims.size();
+  for (int d = 0; d < r.nd; ++d) {
+    r.len[d] = dims[d].len;
+    r.stride[d] = dims[d].stride;
+    if (d == axis_c || dims[d].arithmetic) {
+      r.tab_off[d] = -1;
+    } else {
+      r.tab_off[d] = (int32_t)tab.size();
+      tab.insert(tab.end(), dims[d].table.begin(), dims[d].table.end());
+    }
+  }
+  // members of each group: mid indices ascending, mapped through the selection to source offsets;
+  // rows the selection cannot find contribute nothing
+  const uint32_t G = new_len[axis], K = mid_len[axis];
+  const std::vector<int64_t> e_axis = effective_sel(axis);
+  std::vector<uint32_t> gstart((size_t)G + 1, 0);
+  for (uint32_t k = 0; k < K; ++k)
+    if (e_axis[k] >= 0) gstart[maps[axis][k] + 1]++;
+  for (uint32_t gg = 0; gg < G; ++gg) gstart[gg + 1] += gstart[gg];
+  std::vector<int64_t> member(gstart[G] ? gstart[G] : 1, 0);
+  {
+    std::vector<uint32_t> cur(gstart.begin(), gstart.end() - 1);
+    for (uint32_t k = 0; k < K; ++k)
+      if (e_axis[k] >= 0) member[cur[maps[axis][k]]++] = e_axis[k] * (int64_t)old_stride[axis];
+  }
+  const size_t member_at = tab.size();
+  tab.insert(tab.end(), member.begin(), member.end());
+  g.axis = axis_c;
+  p->vec = 1;
+  if (r.nd > 0 && axis_c != r.nd - 1 && dims.back().arithmetic && dims.back().stride == 1) p->vec = vec_for(dtype, dims.back().len);
+  r.total = p->out_cells / (uint64_t)p->vec;
+  r.def_nan = p->def_nan;
+  r.src_def_nan = p->def_nan;
+  if ((rc = upload(&p->dev_tab, tab.data(), tab.size() * sizeof(int64_t)))) {
+    olap_plan_destroy(p);
+    return rc;
+  }
+  r.tab = (const int64_t *)p->dev_tab;
+  g.member_off = r.tab + member_at;
+  if ((rc = upload(&p->dev_tab2, gstart.data(), gstart.size() * sizeof(uint32_t)))) {
+    olap_plan_destroy(p);
+    return rc;
+  }
+  g.gstart = (const uint32_t *)p->dev_tab2;
+  p->kernel_name = "gather_reduce_kernel";
   *out = p;
   return OLAP_OK;
 }
@@ -869,6 +1018,16 @@ static int run_typed(olap_plan *p, const void *in_v, const int32_t *in_s, void *
     case PLAN_BRICK:
       e = Launch<T>::reorder_brick(hs, in, in_s, out, out_s, p->brick, p->n_bricks, stream);
       break;
+    case PLAN_GATHER_REDUCE: {
+      GatherReduce g = p->gr;
+      int vec = p->vec;
+      if (vec > 1 && !(aligned16(in) && aligned16(out) && (!in_s || aligned16(in_s)) && (!out_s || aligned16(out_s)))) {
+        g.r.total *= (uint64_t)vec;
+        vec = 1;
+      }
+      e = Launch<T>::gather_reduce(p->method, hs, vec, in, in_s, out, out_s, g, stream);
+      break;
+    }
     case PLAN_DRILLDOWN: {
       if (p->dd_two_pass) {
         T *q = (T *)p->dev_tmp;
@@ -1370,6 +1529,21 @@ extern "C" int olap_store_dice(const olap_store *s, olap_store **out, int ndim, 
   *out = nullptr;
   olap_plan *plan = nullptr;
   int rc = olap_dice_plan(&plan, s->dtype, s->default_kind, ndim, old_len, new_len, sel);
+  if (rc) return rc;
+  if ((rc = check_store_cells(s, plan))) {
+    olap_plan_destroy(plan);
+    return rc;
+  }
+  return run_to_new_store(plan, s, out);
+}
+
+extern "C" int olap_store_dice_drillup(const olap_store *s, olap_store **out, int ndim, const uint32_t *old_len,
+                                       const uint32_t *mid_len, const uint32_t *new_len, const int32_t *const *sel,
+                                       const uint32_t *const *maps, int method) {
+  if (!s || !out) return fail(OLAP_ERR_INVALID_ARGUMENT, "store is NULL");
+  *out = nullptr;
+  olap_plan *plan = nullptr;
+  int rc = olap_dice_drillup_plan(&plan, s->dtype, s->default_kind, method, ndim, old_len, mid_len, new_len, sel, maps);
   if (rc) return rc;
   if ((rc = check_store_cells(s, plan))) {
     olap_plan_destroy(plan);

@@ -446,6 +446,70 @@ __global__ __launch_bounds__(kBlock) void gather_kernel(const T *__restrict__ in
   if (st_out) store_vec<int32_t, VEC>(st_out + t * VEC, os);
 }
 
+// K5: fused dice -> drillUp.  Iterates the OUTPUT cube; the source offset of an output cell is the
+// sum of per-dimension table entries (the dice selections) and the rolled-up dimension contributes
+// one offset per group member.  Only surviving cells are read, each once.
+struct GatherReduce {
+  Remap r;                   // output dims; r.tab_off[axis] is unused
+  int axis;                  // collapsed index of the rolled-up dimension
+  const uint32_t *gstart;    // [G + 1]
+  const int64_t *member_off; // source offset of each member (ascending within a group)
+};
+
+template <typename T, int METHOD, bool HAS_STATUS, int VEC, bool FAST>
+__global__ __launch_bounds__(kBlock) void gather_reduce_kernel(const T *__restrict__ in,
+                                                               const int32_t *__restrict__ st_in,
+                                                               T *__restrict__ out,
+                                                               int32_t *__restrict__ st_out,
+                                                               const GatherReduce a) {
+  const uint64_t t = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (t >= a.r.total) return;
+  const bool def_nan = a.r.def_nan != 0;
+  uint64_t c = t * VEC, base = 0;
+  uint32_t g = 0;
+  bool ok = true;
+#pragma unroll
+  for (int d = kMaxDims - 1; d >= 0; --d) {
+    if (d < a.r.nd) {
+      const uint32_t digit = (uint32_t)(c % a.r.len[d]);
+      c /= a.r.len[d];
+      if (d == a.axis) {
+        g = digit;
+      } else if (a.r.tab_off[d] < 0) {
+        base += (uint64_t)digit * a.r.stride[d];
+      } else {
+        const int64_t o = a.r.tab[a.r.tab_off[d] + digit];
+        if (o < 0) ok = false;
+        else base += (uint64_t)o;
+      }
+    }
+  }
+  Lane<T, METHOD, HAS_STATUS, VEC, FAST> lane;
+  lane.init();
+  if (ok) {
+    uint32_t j = a.gstart[g];
+    const uint32_t jend = a.gstart[g + 1];
+    constexpr int U = 4;
+    for (; j < jend; j += U) {
+      const uint32_t n = (jend - j) < (uint32_t)U ? (jend - j) : (uint32_t)U;
+      uint64_t off[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) off[u] = base + (uint64_t)a.member_off[(uint32_t)u < n ? j + u : j];
+      Vec<T, VEC> v[U];
+      Vec<int32_t, VEC> s[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        v[u] = load_vec<T, VEC>(in + off[u]);
+        if constexpr (HAS_STATUS) s[u] = load_vec<int32_t, VEC>(st_in + off[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if ((uint32_t)u < n) lane.add_row(v[u], s[u], def_nan);
+    }
+  }
+  lane.template finish_and_store<false>(def_nan, out, st_out, t * VEC);
+}
+
 // load (in-memory.js:139-176): iterate the SOURCE (the other store, dense over all its cells,
 // see the comment at :152-158), scatter into this store with setValue semantics:
 // mine.setValue(myIdx, his.getValue(hisIdx)).
@@ -881,6 +945,8 @@ struct Launch {
                                     int32_t *st_out, const DrillUpGeneric &a, hipStream_t stream);
   static hipError_t gather(bool has_status, int vec, const T *in, const int32_t *st_in, T *out, int32_t *st_out,
                            const Remap &r, hipStream_t stream);
+  static hipError_t gather_reduce(int method, bool has_status, int vec, const T *in, const int32_t *st_in, T *out,
+                                  int32_t *st_out, const GatherReduce &a, hipStream_t stream);
   static hipError_t reorder_brick(bool has_status, const T *in, const int32_t *st_in, T *out, int32_t *st_out,
                                   const Brick &b, uint64_t n_bricks, hipStream_t stream);
   static hipError_t load_scatter(bool has_status, const T *his, const int32_t *his_st, T *mine, int32_t *mine_st,
@@ -1042,6 +1108,47 @@ hipError_t Launch<T>::gather(bool has_status, int vec, const T *in, const int32_
   }
 #undef OLAP_G
   return hipGetLastError();
+}
+
+template <typename T, int METHOD, bool HS>
+static hipError_t gather_reduce_vec(int vec, const T *in, const int32_t *st_in, T *out, int32_t *st_out,
+                                    const GatherReduce &a, hipStream_t stream) {
+  constexpr bool kAdditive = (METHOD == OLAP_SUM || METHOD == OLAP_AVERAGE || METHOD == OLAP_PARTIAL_AVERAGE);
+  const bool fast = kAdditive && !HS && !a.r.def_nan;
+  const unsigned grid = grid_for(a.r.total);
+#define OLAP_GR(V, F) hipLaunchKernelGGL((gather_reduce_kernel<T, METHOD, HS, V, F>), grid, kBlock, 0, stream, in, st_in, out, st_out, a)
+  if constexpr (kAdditive && !HS) {
+    if (fast) {
+      if (vec == 4) OLAP_GR(4, true); else if (vec == 2) OLAP_GR(2, true); else OLAP_GR(1, true);
+      return hipGetLastError();
+    }
+  }
+  if (vec == 4) OLAP_GR(4, false); else if (vec == 2) OLAP_GR(2, false); else OLAP_GR(1, false);
+#undef OLAP_GR
+  return hipGetLastError();
+}
+
+template <typename T, bool HS>
+static hipError_t gather_reduce_method(int method, int vec, const T *in, const int32_t *st_in, T *out, int32_t *st_out,
+                                       const GatherReduce &a, hipStream_t stream) {
+  switch (method) {
+    case OLAP_SUM: return gather_reduce_vec<T, OLAP_SUM, HS>(vec, in, st_in, out, st_out, a, stream);
+    case OLAP_AVERAGE: return gather_reduce_vec<T, OLAP_AVERAGE, HS>(vec, in, st_in, out, st_out, a, stream);
+    case OLAP_HIGHEST: return gather_reduce_vec<T, OLAP_HIGHEST, HS>(vec, in, st_in, out, st_out, a, stream);
+    case OLAP_LOWEST: return gather_reduce_vec<T, OLAP_LOWEST, HS>(vec, in, st_in, out, st_out, a, stream);
+    case OLAP_FIRST: return gather_reduce_vec<T, OLAP_FIRST, HS>(vec, in, st_in, out, st_out, a, stream);
+    case OLAP_LAST: return gather_reduce_vec<T, OLAP_LAST, HS>(vec, in, st_in, out, st_out, a, stream);
+    case OLAP_PARTIAL_AVERAGE: return gather_reduce_vec<T, OLAP_PARTIAL_AVERAGE, HS>(vec, in, st_in, out, st_out, a, stream);
+    default: return gather_reduce_vec<T, OLAP_PRODUCT, HS>(vec, in, st_in, out, st_out, a, stream);
+  }
+}
+
+template <typename T>
+hipError_t Launch<T>::gather_reduce(int method, bool has_status, int vec, const T *in, const int32_t *st_in, T *out,
+                                    int32_t *st_out, const GatherReduce &a, hipStream_t stream) {
+  if (a.r.total == 0) return hipSuccess;
+  return has_status ? gather_reduce_method<T, true>(method, vec, in, st_in, out, st_out, a, stream)
+                    : gather_reduce_method<T, false>(method, vec, in, st_in, out, st_out, a, stream);
 }
 
 template <typename T>

@@ -103,6 +103,19 @@ class Plan:
         return cls(h)
 
     @classmethod
+    def dice_drillup(cls, dtype, default, method, old_len, mid_len, new_len, sel, maps):
+        """Fused dice -> drillUp (one rolled-up dimension)."""
+        L = capi.lib()
+        ol, ml, nl = _u32(old_len), _u32(mid_len), _u32(new_len)
+        keep_s, arr_s = _tables(sel, np.int32, C.c_int32)
+        keep_m, arr_m = _tables(maps, np.uint32, C.c_uint32)
+        h = C.c_void_p()
+        check(L.olap_dice_drillup_plan(C.byref(h), DTYPES[dtype], _default_kind(default), _method_code(method), len(ol),
+                                       ol.ctypes.data_as(capi._pu32), ml.ctypes.data_as(capi._pu32),
+                                       nl.ctypes.data_as(capi._pu32), arr_s, arr_m))
+        return cls(h)
+
+    @classmethod
     def reorder(cls, dtype, default, old_len, perm):
         L = capi.lib()
         ol, p = _u32(old_len), _i32(perm)
@@ -296,6 +309,16 @@ class HipStore:
         h = C.c_void_p()
         check(self._lib.olap_store_dice(self._h, C.byref(h), len(ol), ol.ctypes.data_as(capi._pu32),
                                         nl.ctypes.data_as(capi._pu32), arr))
+        return HipStore(0, _handle=h)
+
+    def dice_drillup(self, old_len, mid_len, new_len, sel, maps, method="sum"):
+        ol, ml, nl = _u32(old_len), _u32(mid_len), _u32(new_len)
+        keep_s, arr_s = _tables(sel, np.int32, C.c_int32)
+        keep_m, arr_m = _tables(maps, np.uint32, C.c_uint32)
+        h = C.c_void_p()
+        check(self._lib.olap_store_dice_drillup(self._h, C.byref(h), len(ol), ol.ctypes.data_as(capi._pu32),
+                                                ml.ctypes.data_as(capi._pu32), nl.ctypes.data_as(capi._pu32), arr_s, arr_m,
+                                                _method_code(method)))
         return HipStore(0, _handle=h)
 
     def reorder(self, old_len, perm):

@@ -52,7 +52,25 @@ class CellMapView {
   }
 }
 
+/**
+ * Of two new items naming the same old item only the LAST receives the cells (the reference builds
+ * `new Map(newItems.map((item, i) => [oldIdx, i]))`, in-memory.js:219-224): earlier ones become -1.
+ */
+function effectiveSelection(sel) {
+  const last = new Map();
+  sel.forEach((old, j) => {
+    if (old >= 0) last.set(old, j);
+  });
+  return Int32Array.from(sel, (old, j) => (old >= 0 && last.get(old) === j ? old : -1));
+}
+
 class HipStore {
+  /**
+   * `native` is the addon Store, or — for the result of dice() — a pending selection
+   * `{ source, oldLen, sel }` that is only materialised when cells are actually needed: a drillUp
+   * that follows (slice, removeDimension, drillUp after dice) runs fused and never writes the diced
+   * intermediate cube (K5, DESIGN.md §3).
+   */
   constructor(size, type = 'float32', defaultValue = Number.NaN, native = undefined) {
     // same checks, order and messages as in-memory.js:56-60
     if (!Number.isNaN(defaultValue) && defaultValue !== 0) throw new Error('Invalid default value, only NaN and 0 are supported');
@@ -60,8 +78,24 @@ class HipStore {
     this._size = size;
     this._type = type;
     this._defaultValue = defaultValue;
-    this._native = native || new (backend.load().Store)(size, TYPE_CODE[type], Number.isNaN(defaultValue) ? 1 : 0);
+    this._pending = null;
+    if (native && native.source) {
+      this._pending = native;
+      this._nativeStore = null;
+    } else {
+      this._nativeStore = native || new (backend.load().Store)(size, TYPE_CODE[type], Number.isNaN(defaultValue) ? 1 : 0);
+    }
     this._dataMap = new CellMapView(this);
+  }
+
+  /** The device store; a pending dice is executed on first use. */
+  get _native() {
+    if (!this._nativeStore) {
+      const p = this._pending;
+      this._nativeStore = p.source.dice(p.oldLen, p.midLen, p.sel);
+      this._pending = null;
+    }
+    return this._nativeStore;
   }
 
   _wrap(native) {
@@ -118,6 +152,13 @@ class HipStore {
   drillUp(oldDimensions, newDimensions, method = 'sum') {
     const code = backend.load().methodFromName(method); // throws 'Unsupported aggregation method: <m>'
     const maps = newDimensions.map((dim, i) => Uint32Array.from(oldDimensions[i].getGroupIndexFromRootIndexMap(dim.rootAttribute)));
+    if (this._pending) {
+      const rolled = maps.filter((map, i) => map.length !== newDimensions[i].numItems || map.some((g, k) => g !== k)).length;
+      if (rolled <= 1) {
+        const p = this._pending;
+        return this._wrap(p.source.diceDrillUp(p.oldLen, p.midLen, lengthsOf(newDimensions), p.sel, maps, code));
+      }
+    }
     return this._wrap(this._native.drillUp(lengthsOf(oldDimensions), lengthsOf(newDimensions), maps, code));
   }
 
@@ -134,7 +175,18 @@ class HipStore {
       const position = oldDimensions[i].getItemsToIdx();
       return Int32Array.from(dim.getItems(), (item) => (position[item] === undefined ? -1 : position[item]));
     });
-    return this._wrap(this._native.dice(lengthsOf(oldDimensions), lengthsOf(newDimensions), sel));
+    const midLen = lengthsOf(newDimensions);
+    let source = this._nativeStore;
+    let oldLen = lengthsOf(oldDimensions);
+    let composed = sel.map(effectiveSelection);
+    if (this._pending) {
+      // dice of a pending dice: compose the selections, still nothing is materialised
+      const p = this._pending;
+      source = p.source;
+      oldLen = p.oldLen;
+      composed = composed.map((s, d) => Int32Array.from(s, (j) => (j < 0 ? -1 : p.sel[d][j])));
+    }
+    return new HipStore(midLen.reduce((n, l) => n * l, 1), this._type, this._defaultValue, { source, oldLen, midLen, sel: composed });
   }
 
   /** in-memory.js:178-211 */

@@ -370,6 +370,25 @@ static napi_value StoreDice(napi_env env, napi_callback_info info) {
   return wrap_new_store(env, out);
 }
 
+// diceDrillUp(oldLen, midLen, newLen, sel: Int32Array[], maps: Uint32Array[], methodCode)
+static napi_value StoreDiceDrillUp(napi_env env, napi_callback_info info) {
+  STORE_METHOD_PROLOGUE(6)
+  OpArgs a;
+  std::vector<uint32_t> new_len;
+  std::vector<std::vector<uint32_t>> maps;
+  int32_t method = 0;
+  if (argc < 6 || !a.decode(env, argv[0], argv[1], argv[3]) || !get_u32_vec(env, argv[2], new_len) || !get_tables(env, argv[4], maps) ||
+      new_len.size() != a.a_len.size() || maps.size() != a.a_len.size() || napi_get_value_int32(env, argv[5], &method) != napi_ok)
+    return bad_args(env, "diceDrillUp(oldLen, midLen, newLen, sel: Int32Array[], maps: Uint32Array[], method)");
+  std::vector<const uint32_t *> map_ptrs;
+  for (auto &m : maps) map_ptrs.push_back(m.empty() ? &OpArgs::dummy : m.data());
+  olap_store *out = nullptr;
+  int rc = olap_store_dice_drillup(s, &out, (int)a.a_len.size(), a.a_len.data(), a.b_len.data(), new_len.data(),
+                                   (const int32_t *const *)a.ptrs.data(), map_ptrs.data(), method);
+  if (rc) return throw_olap(env, rc);
+  return wrap_new_store(env, out);
+}
+
 // reorder(oldLen, perm: Int32Array)
 static napi_value StoreReorder(napi_env env, napi_callback_info info) {
   STORE_METHOD_PROLOGUE(2)
@@ -454,6 +473,7 @@ static napi_value Init(napi_env env, napi_value exports) {
       {"drillUp", nullptr, StoreDrillUp, nullptr, nullptr, nullptr, napi_default, nullptr},
       {"drillDown", nullptr, StoreDrillDown, nullptr, nullptr, nullptr, napi_default, nullptr},
       {"dice", nullptr, StoreDice, nullptr, nullptr, nullptr, napi_default, nullptr},
+      {"diceDrillUp", nullptr, StoreDiceDrillUp, nullptr, nullptr, nullptr, napi_default, nullptr},
       {"reorder", nullptr, StoreReorder, nullptr, nullptr, nullptr, napi_default, nullptr},
       {"load", nullptr, StoreLoad, nullptr, nullptr, nullptr, napi_default, nullptr},
   };

@@ -172,6 +172,26 @@ describe('slice and dice', () => {
   });
 });
 
+describe('pending dice (fused dice -> drillUp)', () => {
+  it('composes selections and fuses with the following drillUp', () => {
+    const cube = testCube();
+    const diced = cube.dice('location', 'city', ['tokyo', 'paris'], true); // reordered: [[16,32],[1,2]]
+    assert.ok(diced.storedMeasures.antennas._pending, 'dice is lazy');
+    const twice = diced.dice('location', 'city', ['paris']); // [[1,2]]
+    assert.ok(twice.storedMeasures.antennas._pending, 'dice of a dice is still lazy');
+    assert.deepEqual(twice.drillUp('period', 'all').getNestedArray('antennas'), [[3]]);
+    assert.ok(twice.storedMeasures.antennas._pending, 'the fused drillUp did not materialise the dice');
+    assert.deepEqual(twice.getNestedArray('antennas'), [[1, 2]]);
+    assert.ok(!twice.storedMeasures.antennas._pending, 'reading cells materialises');
+    assert.deepEqual(diced.removeDimension('location').getNestedArray('antennas'), [17, 34]);
+    assert.deepEqual(diced.drillUp('location', 'continent').getNestedArray('antennas'), [[16, 32], [1, 2]]);
+    assert.deepEqual(diced.getNestedArray('antennas'), [[16, 32], [1, 2]]);
+    // duplicates: only the last occurrence of an item receives the cells (reference Map semantics)
+    const dup = cube.storedMeasures.antennas.dice(cube.dimensions, [new GenericDimension('location', 'city', ['paris', 'tokyo', 'paris']), cube.dimensions[1]]);
+    assert.deepEqual(dup.data, [0, 0, 16, 32, 1, 2]);
+  });
+});
+
 describe('dimensions', () => {
   it('removeDimension with every aggregator', () => {
     let cube = new Cube([new GenericDimension('location', 'city', ['paris', 'toledo', 'tokyo']), new GenericDimension('period', 'season', ['summer', 'winter'])]);

@@ -230,3 +230,96 @@ def test_full_size_properties(shape, axis):
     assert np.array_equal(got, ref.astype(np.float32).ravel())
     assert np.all(out.get_status() == 2)
     assert abs(out.total - s.total) <= 1e-6 * s.total
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_fused_dice_drillup_equals_two_steps(seed):
+    """olap_dice_drillup_plan == dice then drillUp of the oracle (selection with reordering, unknown
+    items and duplicates; one rolled-up dimension; every method, type and default)."""
+    rng = np.random.default_rng(1000 + seed)
+    shapes = [[6, 5, 8], [12], [3, 4, 5, 4], [7, 16], [5, 3, 64]]
+    old_len = shapes[seed % len(shapes)]
+    nd = len(old_len)
+    type_name = ["float32", "float64", "int32", "uint32"][seed % 4]
+    default = float("nan") if seed % 3 == 0 else 0.0
+    method = ["sum", "average", "highest", "lowest", "first", "last", "product"][seed % 7]
+    n = int(np.prod(old_len))
+    vals = rng.integers(1, 9, size=n).astype(np.float64) * (1 if type_name.endswith("int32") else 0.5)
+    unset = rng.random(n) < 0.3
+    dense = np.where(unset, default, vals)
+    sel, mid_len = [], []
+    for l in old_len:
+        if rng.random() < 0.3:
+            s = np.arange(l)
+        else:
+            s = rng.permutation(l)[: max(1, int(l * 0.7))]
+            if rng.random() < 0.5:
+                s = np.sort(s)
+            if rng.random() < 0.3:
+                s = np.insert(s, rng.integers(0, len(s) + 1), -1)
+            if rng.random() < 0.2 and len(s) > 1:
+                s = np.append(s, s[0])  # duplicate: only the last occurrence receives the cells
+        sel.append(s.astype(np.int32))
+        mid_len.append(len(s))
+    axis = int(rng.integers(0, nd))
+    groups = max(1, mid_len[axis] // 2)
+    labels = rng.integers(0, groups, size=mid_len[axis])
+    # first-appearance numbering like GenericDimension.addAttribute
+    seen, amap = {}, []
+    for x in labels:
+        seen.setdefault(int(x), len(seen))
+        amap.append(seen[int(x)])
+    maps = [np.arange(m, dtype=np.uint32) for m in mid_len]
+    maps[axis] = np.asarray(amap, dtype=np.uint32)
+    new_len = list(mid_len)
+    new_len[axis] = len(seen)
+
+    o = OracleStore(n, type_name, default)
+    o.set_data(dense)
+    diced = o.dice(old_len, mid_len, sel)
+    # A reordering dice leaves the reference's Map in SOURCE insertion order, which first/last then
+    # follow; a dense buffer has only cell order (DESIGN.md §2), so the expectation is the oracle on
+    # the diced cells re-inserted ascending (what chaining the two dense operations gives).
+    dv, dp = diced.dense()
+    redense = OracleStore(diced.size, type_name, default)
+    for i in np.nonzero(dp)[0]:
+        redense.set(int(i), float(dv[i]))
+    ev, es = expected_typed(redense.drill_up(mid_len, new_len, maps, method))
+    g = pkg.HipStore(n, type_name, default)
+    g.set_data_f64(dense)
+    out = g.dice_drillup(old_len, mid_len, new_len, sel, maps, method)
+    assert np.array_equal(out.get_status(), es)
+    assert same_typed(out.get_data(), ev)
+    two = g.dice(old_len, mid_len, sel).drill_up(mid_len, new_len, maps, method)
+    assert same_typed(two.get_data(), out.get_data()) and np.array_equal(two.get_status(), out.get_status())
+
+
+def test_config3_chain_fused_vs_unfused():
+    """BASELINE config 3: slice(dimension1,item3) -> dice(dimension4,[1,4,7]) -> drillUp(dimension0,all)
+    on the 10^8-cell cube, fused and unfused, against numpy float64 in the same order."""
+    shape = [10] * 8
+    n = 10 ** 8
+    s = pkg.HipStore(n, "float32", 0.0)
+    pkg.capi.check(pkg.lib().olap_fill_seeded(s.values_ptr, None, n, 0, 2, 20240807, 1.0, None))
+    ident = [np.arange(10, dtype=np.int32) for _ in range(8)]
+    # slice = dice to one item + drillUp of that dimension to 'all'
+    sel1 = list(ident)
+    sel1[1] = np.array([3], np.int32)
+    mid1 = [10, 1, 10, 10, 10, 10, 10, 10]
+    umap = lambda lens, axis: [np.zeros(l, np.uint32) if i == axis else np.arange(l, dtype=np.uint32) for i, l in enumerate(lens)]
+    a = s.dice_drillup(shape, mid1, mid1, sel1, umap(mid1, 1), "sum")  # [10,1,10,...]: dim1 already 'all'
+    lens2 = mid1
+    sel2 = [np.arange(l, dtype=np.int32) for l in lens2]
+    sel2[4] = np.array([1, 4, 7], np.int32)
+    mid2 = list(lens2)
+    mid2[4] = 3
+    new2 = list(mid2)
+    new2[0] = 1
+    fused = a.dice_drillup(lens2, mid2, new2, sel2, umap(mid2, 0), "sum")
+    unfused = s.dice(shape, mid1, sel1).drill_up(mid1, mid1, umap(mid1, 1), "sum").dice(lens2, mid2, sel2).drill_up(mid2, new2, umap(mid2, 0), "sum")
+    x = s.get_data().reshape(shape)[:, 3][:, :, :, [1, 4, 7]]  # dims: 0,2,3,4',5,6,7
+    ref = np.zeros(x.shape[1:], dtype=np.float64)
+    for k in range(10):
+        ref += x[k]
+    assert np.array_equal(fused.get_data(), ref.astype(np.float32).ravel())
+    assert np.array_equal(unfused.get_data(), fused.get_data())
