@@ -72,12 +72,103 @@ def read_traffic():
         return None
 
 
+def _time(torch, fn, iters=50, warm=5):
+    for _ in range(warm):
+        fn()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / iters * 1e3  # us
+
+
+def bench_config3(pkg, engine, store, torch):
+    """BASELINE configs[2]: slice(dimension1,item3) -> dice(dimension4,[1,4,7]) -> drillUp(dimension0,all)
+    on the resident 10^8-cell cube, as two fused dice->drillUp launches (K5) and as four plain ones."""
+    shape = [10] * 8
+    ident = lambda lens: [np.arange(l, dtype=np.int32) for l in lens]
+    umap = lambda lens, axis: [np.zeros(l, np.uint32) if i == axis else np.arange(l, dtype=np.uint32) for i, l in enumerate(lens)]
+    sel1 = ident(shape)
+    sel1[1] = np.array([3], np.int32)
+    mid1 = [10, 1, 10, 10, 10, 10, 10, 10]
+    sel2 = ident(mid1)
+    sel2[4] = np.array([1, 4, 7], np.int32)
+    mid2 = list(mid1)
+    mid2[4] = 3
+    new2 = [1] + mid2[1:]
+    P = pkg.Plan
+    f1 = P.dice_drillup("float32", 0.0, "sum", shape, mid1, mid1, sel1, umap(mid1, 1))
+    f2 = P.dice_drillup("float32", 0.0, "sum", mid1, mid2, new2, sel2, umap(mid2, 0))
+    u1, u2 = P.dice("float32", 0.0, shape, mid1, sel1), P.drillup("float32", 0.0, "sum", mid1, mid1, umap(mid1, 1))
+    u3, u4 = P.dice("float32", 0.0, mid1, mid2, sel2), P.drillup("float32", 0.0, "sum", mid2, new2, umap(mid2, 0))
+    t1, t2 = engine.empty(10 ** 7, "float32"), engine.empty(10 ** 7, "float32")
+    t3, t4 = engine.empty(3 * 10 ** 6, "float32"), engine.empty(3 * 10 ** 5, "float32")
+    st = engine.stream()
+    src = store.values.data_ptr()
+
+    def fused():
+        f1.run(src, None, t1.data_ptr(), None, st)
+        f2.run(t1.data_ptr(), None, t4.data_ptr(), None, st)
+
+    def unfused():
+        u1.run(src, None, t1.data_ptr(), None, st)
+        u2.run(t1.data_ptr(), None, t2.data_ptr(), None, st)
+        u3.run(t2.data_ptr(), None, t3.data_ptr(), None, st)
+        u4.run(t3.data_ptr(), None, t4.data_ptr(), None, st)
+
+    us_f, us_u = _time(torch, fused), _time(torch, unfused)
+    surviving = 3 * 10 ** 6  # cells of the cube that reach the final drillUp
+    fused_bytes = (10 ** 7 + 10 ** 7 + 3 * 10 ** 6 + 3 * 10 ** 5) * 4  # read 1e7, write 1e7, read 3e6, write 3e5
+    return {"fused_us": us_f, "unfused_us": us_u, "launches": {"fused": 2, "unfused": 4},
+            "fused_algorithmic_bytes": fused_bytes, "fused_GBps": fused_bytes / (us_f * 1e-6) / 1e9,
+            "surviving_cells": surviving, "full_cube_cells": 10 ** 8,
+            "note": "after the slice the working set (40 MB) sits in the 256 MiB Infinity Cache"}
+
+
+def bench_config5(pkg, engine, torch):
+    """BASELINE configs[4]: time(day, 2010-2019)=3652 x location(city)=100 x sku=274 (1.0006e8 cells),
+    4 measures with sum / average / first / last; drillUp(time, month) then drillUp(location, country)."""
+    import datetime
+
+    lens = [3652, 100, 274]
+    n = int(np.prod(lens))
+    d0 = datetime.date(2010, 1, 1)
+    day_to_month = np.array([(d0 + datetime.timedelta(days=i)).month - 1 + 12 * ((d0 + datetime.timedelta(days=i)).year - 2010) for i in range(3652)], np.uint32)
+    city_to_country = (np.arange(100) // 10).astype(np.uint32)
+    ident = lambda l: np.arange(l, dtype=np.uint32)
+    measures = []
+    st = engine.stream()
+    for m, method in enumerate(("sum", "average", "first", "last")):
+        v = engine.empty(n, "float32")
+        pkg.capi.check(pkg.lib().olap_fill_seeded(v.data_ptr(), None, n, 0, 2, 20240807 + m, 1.0, st))
+        p1 = pkg.Plan.drillup("float32", 0.0, method, lens, [120, 100, 274], [day_to_month, ident(100), ident(274)])
+        p2 = pkg.Plan.drillup("float32", 0.0, method, [120, 100, 274], [120, 10, 274], [ident(120), city_to_country, ident(274)])
+        measures.append((v, p1, p2, engine.empty(120 * 27400, "float32"), engine.empty(120 * 2740, "float32")))
+
+    def months():
+        for v, p1, _p2, o1, _o2 in measures:
+            p1.run(v.data_ptr(), None, o1.data_ptr(), None, st)
+
+    def countries():
+        for _v, _p1, p2, o1, o2 in measures:
+            p2.run(o1.data_ptr(), None, o2.data_ptr(), None, st)
+
+    us1, us2 = _time(torch, months, iters=20), _time(torch, countries, iters=50)
+    b1 = 4 * (n + 120 * 27400) * 4
+    return {"cells": n, "measures": 4, "drillUp_time_month_us": us1, "drillUp_time_month_GBps": b1 / (us1 * 1e-6) / 1e9,
+            "drillUp_time_month_frac": b1 / (us1 * 1e-6) / 1e9 / HBM_PEAK_GBS, "cell_measures_per_s": 4 * n / (us1 * 1e-6),
+            "drillUp_location_country_us": us2, "kernel": measures[0][1].kernel_name}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--serial-steps", action="store_true", help="N > 1: no overlap between consecutive steps")
     ap.add_argument("--rehearse", action="store_true",
                     help="developer aid: N ranks share cuda:0 and talk over gloo (exercises the N>1 code path on a 1-GPU box; numbers are meaningless)")
     args = ap.parse_args()
@@ -126,15 +217,18 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # At N > 1 the K steps are independent queries over the resident shards; they are issued as a
+    # pipeline (the reduce-scatter of step i overlaps the local reduction of step i+1, two buffer
+    # pairs).  --serial-steps times them strictly one after the other instead.
+    step = op.step if (world == 1 or args.serial_steps) else op.step_pipelined
     for _ in range(args.warmup):
-        op.step()
+        step()
+    op.flush()
     barrier()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
-    ev0.record()
     for _ in range(args.steps):
-        op.step()
-    ev1.record()
+        step()
+    op.flush()
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -203,6 +297,8 @@ def main():
             us = a.elapsed_time(b) / 200 * 1e3
             res["axis%d" % axis] = {"us_per_launch": round(us, 3), "cells_per_s": 1e6 / (us * 1e-6)}
         extra["cache_resident_1e6"] = res
+        extra["config3_chain"] = bench_config3(pkg, engine, store, torch)
+        extra["config5_time_rollup"] = bench_config5(pkg, engine, torch)
 
     if rank == 0:
         line = {
@@ -219,7 +315,8 @@ def main():
             "dtype": "f32 cells, f64 accumulate",
             "data": "synthetic (seeded mulberry32, values in [0.5,1.5), generated on device)",
             "config": {"workload": workload, "shape": lens, "cells_per_gpu": local_cells,
-                       "kernel": op.local.plan.kernel_name, "collective": ("reduce_scatter" if op.scatter else "all_reduce") if world > 1 else "none"},
+                       "kernel": op.local.plan.kernel_name, "collective": ("reduce_scatter" if op.scatter else "all_reduce") if world > 1 else "none",
+                       "steps_pipelined": bool(world > 1 and not args.serial_steps)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": read_traffic() if world == 1 else None,
                          "kernel_ms": kernel_ms, "algorithmic_bytes": alg_bytes,

@@ -196,6 +196,55 @@ class Dim0DrillUp:
         if self.staged:
             dst.copy_(b)
 
+    # ---- pipelined form for streams of independent queries (bench.py at N > 1) ----------------
+    def step_pipelined(self):
+        """Same work as step() for `sum`, but the collective is asynchronous and ping-pongs between two
+        (partial, result) buffer pairs: the reduce-scatter of query i runs on RCCL's stream while the
+        local reduction of query i+1 runs on the compute stream.  Returns the result tensor of THIS
+        query; it is complete after its work handle (or flush()) has been waited for."""
+        s, dist = self.s, self.dist
+        if s.world == 1 or self.method != "sum" or self.partial_status is not None or self.staged:
+            return self.step()
+        if not hasattr(self, "_pipe"):
+            eng = s.engine
+            self._pipe = {"i": 0, "partial": [self.partial, eng.empty(self.n_out, s.dtype)],
+                          "result": [self.result, eng.empty(self.result.numel(), s.dtype)], "work": [None, None]}
+        p = self._pipe
+        k = p["i"] & 1
+        p["i"] += 1
+        if p["work"][k] is not None:
+            p["work"][k].wait()  # the collective that last read partial[k] / wrote result[k]
+        self.local.run(s.values, None, p["partial"][k], None)
+        p["work"][k] = self._sum_across_ranks_async(p["partial"][k], p["result"][k])
+        return p["result"][k]
+
+    def _sum_across_ranks_async(self, src, dst):
+        """Asynchronous form of _sum_across_ranks; returns an object with wait()."""
+        s, dist = self.s, self.dist
+        if self.scatter and dist.get_backend(s.group) != "gloo":
+            return dist.reduce_scatter_tensor(dst, src, op=dist.ReduceOp.SUM, group=s.group, async_op=True)
+        if self.scatter:  # gloo rehearsal: all-reduce a copy, keep this rank's slice when it lands
+            full = src.clone()
+            work = dist.all_reduce(full, op=dist.ReduceOp.SUM, group=s.group, async_op=True)
+            lo, hi = self.result_range
+
+            class _Slice:
+                def wait(self_inner):
+                    work.wait()
+                    dst.copy_(full[lo:hi])
+
+            return _Slice()
+        dst.copy_(src)
+        return dist.all_reduce(dst, op=dist.ReduceOp.SUM, group=s.group, async_op=True)
+
+    def flush(self):
+        """Waits (on the current stream) for every outstanding pipelined collective."""
+        if hasattr(self, "_pipe"):
+            for k in (0, 1):
+                if self._pipe["work"][k] is not None:
+                    self._pipe["work"][k].wait()
+                    self._pipe["work"][k] = None
+
     def step(self):
         s, dist = self.s, self.dist
         self.local.run(s.values, None, self.partial, self.partial_status)

@@ -88,6 +88,12 @@ def main():
             if hasattr(res, "is_cuda") and res.is_cuda:
                 torch.cuda.synchronize()
             results["%s_%s" % (method, frac)] = {"range": [lo, hi], "values": res.cpu().numpy().astype(np.float64).tolist()}
+        # the pipelined form used by bench.py at N > 1: three queries in flight over two buffer pairs
+        op = s.plan_drillup_dim0(row_map, 3, "sum")
+        outs = [op.step_pipelined().clone() if False else op.step_pipelined() for _ in range(3)]
+        op.flush()
+        lo, hi = op.result_range
+        results["pipelined_%s" % frac] = {"range": [lo, hi], "values": outs[-1].cpu().numpy().astype(np.float64).tolist()}
         # a non-sharded axis: no communication, partition kept
         o = s.drillup_other_axis(2, np.arange(10) % 2, 2, "sum")
         if getattr(o.values, "is_cuda", False):

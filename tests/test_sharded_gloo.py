@@ -49,6 +49,12 @@ def check(results):
                 assert np.allclose(got, ev, rtol=1e-5, atol=0), method
             else:
                 assert np.array_equal(got.astype(np.float32), ev), method
+        ev, _ = o.drill_up(lens, [3, 6, 10], maps, "sum").typed()
+        got = np.full(180, np.nan)
+        for res in results:
+            r = res["pipelined_%s" % frac]
+            got[r["range"][0]:r["range"][1]] = r["values"]
+        assert np.allclose(got, ev, rtol=1e-5, atol=0), "pipelined sum"
         e2, _ = o.drill_up(lens, [7, 6, 2], [np.arange(7, dtype=np.uint32), np.arange(6, dtype=np.uint32),
                                              (np.arange(10) % 2).astype(np.uint32)], "sum").typed()
         got = np.full(84, np.nan)
