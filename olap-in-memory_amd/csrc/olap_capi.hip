@@ -134,6 +134,7 @@ struct olap_plan {
   Brick brick{};
   uint64_t n_bricks = 0;
   GatherReduce gr{};
+  DrillUpSplit split{};                    // S > 1: split regime of the one-axis drillUp
   bool dd_two_pass = false;                // float cells, no distributions: scale + broadcast
   void *dev_tab2 = nullptr;                // second table set (two-pass drillDown)
   void *dev_tmp = nullptr;                 // quotients of the two-pass drillDown (old cells)
@@ -278,7 +279,29 @@ extern "C" int olap_drillup_plan(olap_plan **out, int dtype, int default_kind, i
     }
     a.gstart = (const uint32_t *)p->dev_tab;
     a.order = contiguous ? nullptr : (const uint32_t *)p->dev_tab + order_off;
-    if (a.inner / (uint64_t)p->vec >= 128) p->kernel_name = "drillup_rows_kernel";
+    // few output cells and long groups: split every group into S segments (workspace in the plan)
+    {
+      uint32_t longest = 0;
+      for (size_t gi = 0; gi + 1 < gstart.size(); ++gi) longest = std::max(longest, gstart[gi + 1] - gstart[gi]);
+      const uint64_t cells = a.outer * a.G * a.inner;
+      if (cells > 0 && cells < 16384 && longest >= 256) {
+        const uint64_t want = (131072 + cells - 1) / cells;               // ~128 K lanes in flight
+        const uint32_t S = (uint32_t)std::min<uint64_t>(want, longest / 32);  // >= 32 members per segment
+        if (S > 1) {
+          p->split.S = S;
+          p->split.seg_len = (longest + S - 1) / S;
+          hipError_t e = hipMalloc(&p->dev_tmp, cells * S * (sizeof(double) + sizeof(uint32_t)));
+          if (e != hipSuccess) {
+            olap_plan_destroy(p);
+            return hip_fail(e, "hipMalloc(drillUp split workspace)");
+          }
+          p->split.acc = (double *)p->dev_tmp;
+          p->split.meta = (uint32_t *)((char *)p->dev_tmp + cells * S * sizeof(double));
+        }
+      }
+    }
+    if (p->split.S > 1) p->kernel_name = "drillup_split_kernel+drillup_merge_kernel";
+    else if (a.inner / (uint64_t)p->vec >= 128) p->kernel_name = "drillup_rows_kernel";
     else if (a.inner < 16 && a.K * a.inner * 4 <= (16 * 1024) / olap_dtype_size(dtype) && a.K * a.inner > 0 &&
              (a.G + 1 + a.K) * 4 <= 16 * 1024)
       p->kernel_name = "drillup_tile_kernel";
@@ -996,6 +1019,10 @@ static int run_typed(olap_plan *p, const void *in_v, const int32_t *in_s, void *
       a.n_vec = a.inner / (uint64_t)vec;
       a.total = a.outer * a.G * a.n_vec;
       a.blocks_per_row = (a.n_vec + kBlock - 1) / kBlock;
+      if (p->split.S > 1) {
+        e = Launch<T>::drillup_split(p->method, hs, in, in_s, out, out_s, a, p->split, stream);
+        break;
+      }
       e = Launch<T>::drillup_axis(p->method, hs, vec, in, in_s, out, out_s, a, stream);
       break;
     }

@@ -309,6 +309,85 @@ __global__ __launch_bounds__(kBlock) void drillup_tile_kernel(const T *__restric
   }
 }
 
+// Split regime (few output cells, long groups — e.g. [10^6, 100] -> [1, 100]): the member list of
+// every group is cut into S segments reduced by separate lanes into a float64 workspace, then a
+// second tiny launch merges the S partial states of each output cell IN SEGMENT ORDER (so
+// first/last/highest/lowest stay exact; float64 sums are re-associated across segments only).
+struct DrillUpSplit {
+  uint32_t S;        // segments per group
+  uint32_t seg_len;  // members per segment
+  double *acc;       // [outer*G*inner * S] partial value
+  uint32_t *meta;    // same shape: bit 31 = partial is set, bits 0..30 = contributions
+};
+
+template <typename T, int METHOD, bool HAS_STATUS>
+__global__ __launch_bounds__(kBlock) void drillup_split_kernel(const T *__restrict__ in,
+                                                               const int32_t *__restrict__ st_in,
+                                                               const DrillUpAxis a, const DrillUpSplit sp) {
+  const uint64_t t = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  const uint64_t cells = a.outer * a.G * a.inner;
+  if (t >= cells * sp.S) return;
+  const uint64_t i = t % a.inner;
+  const uint32_t seg = (uint32_t)((t / a.inner) % sp.S);
+  const uint64_t og = t / (a.inner * sp.S);
+  const uint64_t g = og % a.G, o = og / a.G;
+  const bool def_nan = a.def_nan != 0;
+  const T *base = in + (o * a.K) * a.inner + i;
+  const int32_t *sbase = HAS_STATUS ? st_in + (o * a.K) * a.inner + i : nullptr;
+  const uint32_t gend = a.gstart[g + 1];
+  uint64_t j64 = (uint64_t)a.gstart[g] + (uint64_t)seg * sp.seg_len;
+  uint32_t j = j64 < gend ? (uint32_t)j64 : gend;
+  const uint32_t jend = (uint64_t)j + sp.seg_len < gend ? j + sp.seg_len : gend;
+  Agg<METHOD> agg;
+  agg.init();
+  constexpr int U = 4;
+  for (; j < jend; j += U) {
+    const uint32_t n = (jend - j) < (uint32_t)U ? (jend - j) : (uint32_t)U;
+    T x[U];
+    int32_t sx[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint32_t jj = (uint32_t)u < n ? j + u : j;
+      const uint64_t k = a.order ? (uint64_t)a.order[jj] : (uint64_t)jj;
+      x[u] = base[k * a.inner];
+      sx[u] = HAS_STATUS ? sbase[k * a.inner] : OLAP_STATUS_SET;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if ((uint32_t)u < n && cell_is_set<T>(x[u], sx[u], HAS_STATUS, def_nan)) agg.add(Cell<T>::to_f64(x[u]), def_nan);
+  }
+  const uint64_t w = ((o * a.G + g) * a.inner + i) * sp.S + seg;
+  sp.acc[w] = agg.acc;
+  sp.meta[w] = (agg.has ? 0x80000000u : 0u) | (agg.count & 0x7FFFFFFFu);
+}
+
+template <typename T, int METHOD>
+__global__ __launch_bounds__(kBlock) void drillup_merge_kernel(T *__restrict__ out, int32_t *__restrict__ st_out,
+                                                               const DrillUpAxis a, const DrillUpSplit sp) {
+  const uint64_t t = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (t >= a.outer * a.G * a.inner) return;
+  const bool def_nan = a.def_nan != 0;
+  Agg<METHOD> agg;
+  agg.init();
+  for (uint32_t s = 0; s < sp.S; ++s) {
+    const uint32_t m = sp.meta[t * sp.S + s];
+    const uint32_t cnt = m & 0x7FFFFFFFu;
+    if (m & 0x80000000u) {
+      agg.add(sp.acc[t * sp.S + s], def_nan);  // counts one contribution ...
+      agg.count += cnt - 1;                    // ... the segment had `cnt`
+    } else {
+      agg.count += cnt;  // contributions that cancelled to the default inside the segment
+    }
+  }
+  agg.finish(def_nan);
+  T ov;
+  int32_t os;
+  emit_cell<T>(agg.acc, agg.has, def_nan, ov, os);
+  if constexpr (METHOD == OLAP_PARTIAL_AVERAGE) os = (int32_t)agg.count;
+  out[t] = ov;
+  if (st_out) st_out[t] = os;
+}
+
 // ======================================================================= K1g: drillUp, any maps
 // The store method accepts a map on every dimension (in-memory.js:270-274).  One lane per output
 // cell walks the cartesian product of its groups' member lists in ascending flat order.
@@ -941,6 +1020,8 @@ template <typename T>
 struct Launch {
   static hipError_t drillup_axis(int method, bool has_status, int vec, const T *in, const int32_t *st_in, T *out,
                                  int32_t *st_out, const DrillUpAxis &a, hipStream_t stream);
+  static hipError_t drillup_split(int method, bool has_status, const T *in, const int32_t *st_in, T *out, int32_t *st_out,
+                                  const DrillUpAxis &a, const DrillUpSplit &sp, hipStream_t stream);
   static hipError_t drillup_generic(int method, bool has_status, const T *in, const int32_t *st_in, T *out,
                                     int32_t *st_out, const DrillUpGeneric &a, hipStream_t stream);
   static hipError_t gather(bool has_status, int vec, const T *in, const int32_t *st_in, T *out, int32_t *st_out,
@@ -1066,6 +1147,32 @@ hipError_t Launch<T>::drillup_axis(int method, bool has_status, int vec, const T
   if (a.total == 0) return hipSuccess;
   return has_status ? drillup_axis_method<T, true>(method, vec, in, st_in, out, st_out, a, stream)
                     : drillup_axis_method<T, false>(method, vec, in, st_in, out, st_out, a, stream);
+}
+
+template <typename T, int METHOD>
+static hipError_t drillup_split_launch(bool has_status, const T *in, const int32_t *st_in, T *out, int32_t *st_out,
+                                       const DrillUpAxis &a, const DrillUpSplit &sp, hipStream_t stream) {
+  const uint64_t cells = a.outer * a.G * a.inner;
+  if (has_status) hipLaunchKernelGGL((drillup_split_kernel<T, METHOD, true>), grid_for(cells * sp.S), kBlock, 0, stream, in, st_in, a, sp);
+  else hipLaunchKernelGGL((drillup_split_kernel<T, METHOD, false>), grid_for(cells * sp.S), kBlock, 0, stream, in, st_in, a, sp);
+  hipLaunchKernelGGL((drillup_merge_kernel<T, METHOD>), grid_for(cells), kBlock, 0, stream, out, st_out, a, sp);
+  return hipGetLastError();
+}
+
+template <typename T>
+hipError_t Launch<T>::drillup_split(int method, bool has_status, const T *in, const int32_t *st_in, T *out,
+                                    int32_t *st_out, const DrillUpAxis &a, const DrillUpSplit &sp, hipStream_t stream) {
+  if (a.outer * a.G * a.inner == 0) return hipSuccess;
+  switch (method) {
+    case OLAP_SUM: return drillup_split_launch<T, OLAP_SUM>(has_status, in, st_in, out, st_out, a, sp, stream);
+    case OLAP_AVERAGE: return drillup_split_launch<T, OLAP_AVERAGE>(has_status, in, st_in, out, st_out, a, sp, stream);
+    case OLAP_HIGHEST: return drillup_split_launch<T, OLAP_HIGHEST>(has_status, in, st_in, out, st_out, a, sp, stream);
+    case OLAP_LOWEST: return drillup_split_launch<T, OLAP_LOWEST>(has_status, in, st_in, out, st_out, a, sp, stream);
+    case OLAP_FIRST: return drillup_split_launch<T, OLAP_FIRST>(has_status, in, st_in, out, st_out, a, sp, stream);
+    case OLAP_LAST: return drillup_split_launch<T, OLAP_LAST>(has_status, in, st_in, out, st_out, a, sp, stream);
+    case OLAP_PARTIAL_AVERAGE: return drillup_split_launch<T, OLAP_PARTIAL_AVERAGE>(has_status, in, st_in, out, st_out, a, sp, stream);
+    default: return drillup_split_launch<T, OLAP_PRODUCT>(has_status, in, st_in, out, st_out, a, sp, stream);
+  }
 }
 
 template <typename T, bool HS>

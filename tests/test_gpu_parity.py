@@ -323,3 +323,42 @@ def test_config3_chain_fused_vs_unfused():
         ref += x[k]
     assert np.array_equal(fused.get_data(), ref.astype(np.float32).ravel())
     assert np.array_equal(unfused.get_data(), fused.get_data())
+
+
+@pytest.mark.parametrize("method", ["sum", "average", "highest", "lowest", "first", "last", "product"])
+@pytest.mark.parametrize("type_name,default", [("float32", 0.0), ("float32", float("nan")), ("int32", 0.0), ("uint32", float("nan")), ("float64", 0.0)])
+def test_split_regime_few_outputs_long_groups(method, type_name, default):
+    """[6000, 7] -> [2, 7]: 14 output cells, groups of ~3000 rows: the split (segments + ordered merge)
+    regime.  Picks are exact; float64 sums are re-associated across segments (1e-12 relative)."""
+    rng = np.random.default_rng(5)
+    lens = [6000, 7]
+    n = 42000
+    if method == "product":
+        vals = np.where(rng.random(n) < 0.5, 1.0, -1.0) * np.where(rng.random(n) < 0.01, 2.0, 1.0)
+    else:
+        vals = rng.integers(-50, 51, size=n).astype(np.float64)
+        if type_name == "uint32":
+            vals = np.abs(vals)
+        if type_name.startswith("float"):
+            vals = vals * 0.25
+    unset = rng.random(n) < 0.3
+    dense = np.where(unset, default, vals)
+    row_map = (np.arange(6000) % 2).astype(np.uint32)  # interleaved groups -> `order` table in use
+    maps = [row_map, np.arange(7, dtype=np.uint32)]
+    plan = pkg.Plan.drillup(type_name, default, method, lens, [2, 7], maps)
+    assert "split" in plan.kernel_name
+    o = OracleStore(n, type_name, default)
+    typed = to_typed(dense, type_name).astype(np.float64)
+    if type_name in ("int32", "uint32") and default != default:
+        typed = np.where(np.isnan(dense), np.nan, typed)
+    o.set_data(typed)
+    ev, es = expected_typed(o.drill_up(lens, [2, 7], maps, method))
+    g = pkg.HipStore(n, type_name, default)
+    g.set_data_f64(dense)
+    out = g.drill_up(lens, [2, 7], maps, method)
+    assert np.array_equal(out.get_status(), es)
+    gv = out.get_data()
+    if type_name == "float64" and method in ("sum", "average", "product"):
+        assert np.allclose(gv, ev, rtol=1e-12, atol=0, equal_nan=True)
+    else:
+        assert same_typed(gv, ev)
