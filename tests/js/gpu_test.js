@@ -308,6 +308,87 @@ describe('hydrateFromCube', () => {
   });
 });
 
+describe('compose (test/cube-to-cube.js:5-401, stored-measure cases)', () => {
+  const period = () => new GenericDimension('period', 'season', ['summer', 'winter']);
+  const cities = (items) => new GenericDimension('location', 'city', items);
+  const grid = [[1, 2], [4, 8], [16, 32]];
+  function pair(dims1, data1, dims2, data2, def) {
+    const c1 = new Cube(dims1);
+    const c2 = new Cube(dims2);
+    if (def === undefined) {
+      c1.createStoredMeasure('antennas');
+      c2.createStoredMeasure('routers');
+    } else {
+      c1.createStoredMeasure('antennas', {}, 'float32', def);
+      c2.createStoredMeasure('routers', {}, 'float32', def);
+    }
+    c1.setNestedArray('antennas', data1);
+    c2.setNestedArray('routers', data2);
+    return [c1, c2];
+  }
+  for (const union of [false, true]) {
+    const tag = union ? 'union' : 'intersection';
+    // union() sorts the merged items, so the union cases start from the sorted order as the reference's do
+    const order = union ? ['paris', 'tokyo', 'toledo'] : ['paris', 'toledo', 'tokyo'];
+    it(`${tag}: same dimensions`, () => {
+      const loc = cities(order);
+      const per = period();
+      const [c1, c2] = pair([loc, per], grid, [loc, per], [[3, 2], [4, 9], [16, 32]]);
+      const c = c1.compose(c2, union);
+      assert.deepEqual(c.dimensionIds, ['location', 'period']);
+      assert.deepEqual(c.getNestedArray('routers'), [[3, 2], [4, 9], [16, 32]]);
+      assert.deepEqual(c.getNestedArray('antennas'), grid);
+    });
+    it(`${tag}: a dimension missing from one cube is summed away`, () => {
+      const loc = cities(order);
+      const [c1, c2] = pair([loc, period()], grid, [loc], [3, 4, 16]);
+      const c = c1.compose(c2, union);
+      assert.deepEqual(c.dimensionIds, ['location']);
+      assert.deepEqual(c.getNestedArray('antennas'), [3, 12, 48]);
+      assert.deepEqual(c.getNestedArray('routers'), [3, 4, 16]);
+    });
+    it(`${tag}: same time dimension`, () => {
+      const time = new TimeDimension('time', 'month', '2010-01', '2010-02');
+      const [c1, c2] = pair([time], [1, 2], [time], [3, 2]);
+      const c = c1.compose(c2, union);
+      assert.deepEqual(c.dimensionIds, ['time']);
+      assert.deepEqual(c.getNestedArray('antennas'), [1, 2]);
+      assert.deepEqual(c.getNestedArray('routers'), [3, 2]);
+    });
+  }
+  it('intersection: items missing from both cubes', () => {
+    const [c1, c2] = pair([cities(['paris', 'toledo', 'tokyo']), period()], grid, [cities(['soria', 'tokyo', 'paris']), period()], [[64, 128], [256, 512], [1024, 2048]]);
+    const c = c1.compose(c2);
+    assert.deepEqual(c.getNestedArray('antennas'), [[1, 2], [16, 32]]);
+    assert.deepEqual(c.getNestedArray('routers'), [[1024, 2048], [256, 512]]);
+  });
+  it('union: items missing from both cubes (NaN default)', () => {
+    const [c1, c2] = pair([cities(['paris', 'toledo', 'tokyo']), period()], grid, [cities(['soria', 'tokyo', 'paris']), period()], [[64, 128], [256, 512], [1024, 2048]], NaN_);
+    const c = c1.compose(c2, true);
+    assert.deepEqual(c.getDimension('location').getItems(), ['paris', 'soria', 'tokyo', 'toledo']);
+    assert.deepEqual(c.getNestedArray('antennas'), [[1, 2], [NaN_, NaN_], [16, 32], [4, 8]]);
+    assert.deepEqual(c.getNestedArray('routers'), [[1024, 2048], [64, 128], [256, 512], [NaN_, NaN_]]);
+  });
+  it('overlapping time dimensions', () => {
+    const t = (a, b, root = 'month') => new TimeDimension('time', root, a, b);
+    let [c1, c2] = pair([t('2010-01', '2010-02')], [1, 2], [t('2010-02', '2010-03')], [3, 2], NaN_);
+    assert.deepEqual(c1.compose(c2).getNestedArray('antennas'), [2]);
+    assert.deepEqual(c1.compose(c2).getNestedArray('routers'), [3]);
+    assert.deepEqual(c1.compose(c2, true).getData('antennas'), [1, 2, NaN_]);
+    assert.deepEqual(c1.compose(c2, true).getData('routers'), [NaN_, 3, 2]);
+    [c1, c2] = pair([t('2010-01', '2010-02')], [1, 2], [t('2010-03', '2010-04')], [3, 2], NaN_);
+    assert.equal(c1.compose(c2).storeSize, 0);
+    assert.deepEqual(c1.compose(c2, true).getData('antennas'), [1, 2, NaN_, NaN_]);
+    assert.deepEqual(c1.compose(c2, true).getData('routers'), [NaN_, NaN_, 3, 2]);
+    [c1, c2] = pair([t('2010-01', '2010-04')], [1, 2, 4, 8], [t('2010-Q1', '2010-Q3', 'quarter')], [16, 32, 64]);
+    assert.deepEqual(c1.compose(c2).getNestedArray('antennas'), [7, 8]);
+    assert.deepEqual(c1.compose(c2).getNestedArray('routers'), [16, 32]);
+    [c1, c2] = pair([t('2010-01', '2010-04')], [1, 2, 4, 8], [t('2010-Q1', '2010-Q3', 'quarter')], [16, 32, 64], NaN_);
+    assert.deepEqual(c1.compose(c2, true).getData('antennas'), [7, 8, NaN_]);
+    assert.deepEqual(c1.compose(c2, true).getData('routers'), [16, 32, 64]);
+  });
+});
+
 describe('BASELINE config 1 through the Cube API', () => {
   it('[10,10,10] drillUp(dimension0, all) equals the reference output', () => {
     const golden = JSON.parse(fs.readFileSync(path.join(__dirname, '..', 'golden', 'configs.json'), 'utf8')).cases.find((c) => c.name === 'config1_10x10x10_dim0');
