@@ -134,7 +134,7 @@ struct olap_plan {
   Brick brick{};
   uint64_t n_bricks = 0;
   GatherReduce gr{};
-  DrillUpSplit split{};                    // S > 1: split regime of the one-axis drillUp
+  DrillUpReduce reduce{};                  // S > 0: reduce regime of the one-axis drillUp
   bool dd_two_pass = false;                // float cells, no distributions: scale + broadcast
   void *dev_tab2 = nullptr;                // second table set (two-pass drillDown)
   void *dev_tmp = nullptr;                 // quotients of the two-pass drillDown (old cells)
@@ -279,32 +279,60 @@ extern "C" int olap_drillup_plan(olap_plan **out, int dtype, int default_kind, i
     }
     a.gstart = (const uint32_t *)p->dev_tab;
     a.order = contiguous ? nullptr : (const uint32_t *)p->dev_tab + order_off;
-    // few output cells and long groups: split every group into S segments (workspace in the plan)
+    // few output cells and long groups: cooperative reduction of S segments per group (workspace
+    // in the plan), see DrillUpReduce
     {
       uint32_t longest = 0;
       for (size_t gi = 0; gi + 1 < gstart.size(); ++gi) longest = std::max(longest, gstart[gi + 1] - gstart[gi]);
       const uint64_t cells = a.outer * a.G * a.inner;
-      if (cells > 0 && cells < 16384 && longest >= 256) {
-        const uint64_t want = (131072 + cells - 1) / cells;               // ~128 K lanes in flight
-        const uint32_t S = (uint32_t)std::min<uint64_t>(want, longest / 32);  // >= 32 members per segment
-        if (S > 1) {
-          p->split.S = S;
-          p->split.seg_len = (longest + S - 1) / S;
-          hipError_t e = hipMalloc(&p->dev_tmp, cells * S * (sizeof(double) + sizeof(uint32_t)));
-          if (e != hipSuccess) {
-            olap_plan_destroy(p);
-            return hip_fail(e, "hipMalloc(drillUp split workspace)");
+      if (cells > 0 && cells < 131072 && longest >= 256) {
+        DrillUpReduce &rd = p->reduce;
+        uint64_t S;
+        if (a.inner <= 128) {
+          const uint64_t groups = a.outer * a.G;
+          const uint64_t by_grid = (4096 + groups - 1) / groups;                              // >= ~4 K units
+          const uint64_t by_work = std::max<uint64_t>(1, (uint64_t)longest * a.inner / 8192);  // >= 8 K cells each
+          S = std::max<uint64_t>(1, std::min(by_grid, by_work));
+          // short segments: a wavefront per segment; long ones: the whole workgroup
+          const uint64_t seg_cells = ((uint64_t)longest + S - 1) / S * a.inner;
+          rd.unit = (seg_cells <= 16384 && a.inner <= 64) ? 64 : kBlock;
+          uint32_t rows = 1;
+          while (rows * 2 * a.inner <= (uint64_t)rd.unit) rows *= 2;
+          rd.rows = rows;
+          // 16 B form: one contiguous '-> all' group, whole rows and segments in multiples of 4 cells
+          uint64_t seg_len = ((uint64_t)longest + S - 1) / S;
+          seg_len = (seg_len + 3) & ~3ull;
+          uint32_t rows4 = 4;
+          while ((uint64_t)rows4 * 2 * a.inner <= (uint64_t)rd.unit * 4) rows4 *= 2;
+          if (contiguous && a.G == 1 && olap_dtype_size(dtype) == 4 && (a.K * a.inner) % 4 == 0 &&
+              (uint64_t)rows4 * a.inner <= (uint64_t)rd.unit * 4) {
+            rd.vec4 = 1;
+            rd.rows = rows4;
+            rd.seg_len = (uint32_t)seg_len;
           }
-          p->split.acc = (double *)p->dev_tmp;
-          p->split.meta = (uint32_t *)((char *)p->dev_tmp + cells * S * sizeof(double));
+        } else {
+          rd.rows = 0;
+          rd.unit = kBlock;
+          S = std::max<uint64_t>(1, std::min<uint64_t>((524288 + cells - 1) / cells, longest / 32));
         }
+        rd.S = (uint32_t)S;
+        if (!rd.vec4) rd.seg_len = (uint32_t)((longest + S - 1) / S);
+        hipError_t e = hipMalloc(&p->dev_tmp, cells * S * sizeof(Partial));
+        if (e != hipSuccess) {
+          olap_plan_destroy(p);
+          return hip_fail(e, "hipMalloc(drillUp reduce workspace)");
+        }
+        rd.part = (Partial *)p->dev_tmp;
       }
     }
-    if (p->split.S > 1) p->kernel_name = "drillup_split_kernel+drillup_merge_kernel";
+    if (p->reduce.S > 0)
+      p->kernel_name = p->reduce.vec4   ? "drillup_reduce4_kernel+drillup_merge_kernel"
+                       : p->reduce.rows ? "drillup_reduce_kernel+drillup_merge_kernel"
+                                        : "drillup_split_kernel+drillup_merge_kernel";
     else if (a.inner / (uint64_t)p->vec >= 128) p->kernel_name = "drillup_rows_kernel";
-    else if (a.inner < 16 && a.K * a.inner * 4 <= (16 * 1024) / olap_dtype_size(dtype) && a.K * a.inner > 0 &&
+    else if (a.inner < 16 && a.K * a.inner <= (16 * 1024) / olap_dtype_size(dtype) && a.K * a.inner > 0 &&
              (a.G + 1 + a.K) * 4 <= 16 * 1024)
-      p->kernel_name = "drillup_tile_kernel";
+      p->kernel_name = "drillup_tile_kernel";  // (the launcher re-checks alignment; may still pick the flat form)
     else p->kernel_name = "drillup_flat_kernel";
   } else {
     p->kind = PLAN_DRILLUP_GENERIC;
@@ -1019,8 +1047,8 @@ static int run_typed(olap_plan *p, const void *in_v, const int32_t *in_s, void *
       a.n_vec = a.inner / (uint64_t)vec;
       a.total = a.outer * a.G * a.n_vec;
       a.blocks_per_row = (a.n_vec + kBlock - 1) / kBlock;
-      if (p->split.S > 1) {
-        e = Launch<T>::drillup_split(p->method, hs, in, in_s, out, out_s, a, p->split, stream);
+      if (p->reduce.S > 0) {
+        e = Launch<T>::drillup_reduce(p->method, hs, in, in_s, out, out_s, a, p->reduce, stream);
         break;
       }
       e = Launch<T>::drillup_axis(p->method, hs, vec, in, in_s, out, out_s, a, stream);

@@ -309,38 +309,251 @@ __global__ __launch_bounds__(kBlock) void drillup_tile_kernel(const T *__restric
   }
 }
 
-// Split regime (few output cells, long groups — e.g. [10^6, 100] -> [1, 100]): the member list of
-// every group is cut into S segments reduced by separate lanes into a float64 workspace, then a
-// second tiny launch merges the S partial states of each output cell IN SEGMENT ORDER (so
-// first/last/highest/lowest stay exact; float64 sums are re-associated across segments only).
-struct DrillUpSplit {
-  uint32_t S;        // segments per group
-  uint32_t seg_len;  // members per segment
-  double *acc;       // [outer*G*inner * S] partial value
-  uint32_t *meta;    // same shape: bit 31 = partial is set, bits 0..30 = contributions
+// Reduce regime (few output cells, long groups — [10^6,100] -> [1,100], [27400,3652] -> [27400,1],
+// [10^8] -> [1]): the natural one-lane-per-output mappings above would leave the chip idle, so the
+// member list of every group is cut into S segments and reduced cooperatively; partial states are
+// merged afterwards.  Sums are float64 but RE-ASSOCIATED here (tree order instead of the
+// reference's sequential order: ~1e-16 relative before the final rounding); highest / lowest are
+// order-free; first / last carry the member position and merge by it, so they stay exact.
+struct Partial {
+  double acc;
+  uint32_t meta;  // bit 31: set, bits 0..30: contributions
+  uint32_t pos;   // member position (first / last)
 };
 
-template <typename T, int METHOD, bool HAS_STATUS>
+template <int METHOD>
+__device__ __forceinline__ Partial partial_identity() {
+  Partial p;
+  p.acc = 0.0;
+  p.meta = 0;
+  p.pos = 0;
+  return p;
+}
+
+template <int METHOD>
+__device__ __forceinline__ void partial_add(Partial &p, double v, uint32_t pos, bool def_nan) {
+  const uint32_t cnt = (p.meta & 0x7FFFFFFFu) + 1;
+  bool has = (p.meta & 0x80000000u) != 0;
+  if (!has) {
+    p.acc = v;
+    p.pos = pos;
+    has = true;
+  } else {
+    if constexpr (METHOD == OLAP_SUM || METHOD == OLAP_AVERAGE || METHOD == OLAP_PARTIAL_AVERAGE) p.acc += v;
+    else if constexpr (METHOD == OLAP_PRODUCT) p.acc *= v;
+    else if constexpr (METHOD == OLAP_HIGHEST) p.acc = js_max(p.acc, v);
+    else if constexpr (METHOD == OLAP_LOWEST) p.acc = js_min(p.acc, v);
+    else if constexpr (METHOD == OLAP_FIRST) { if (pos < p.pos) { p.acc = v; p.pos = pos; } }
+    else { if (pos >= p.pos) { p.acc = v; p.pos = pos; } }
+    if constexpr (METHOD == OLAP_SUM || METHOD == OLAP_AVERAGE || METHOD == OLAP_PARTIAL_AVERAGE || METHOD == OLAP_PRODUCT)
+      if (is_default_f64(p.acc, def_nan)) has = false;  // the key is dropped (in-memory.js:126-131)
+  }
+  p.meta = (has ? 0x80000000u : 0u) | (cnt & 0x7FFFFFFFu);
+}
+
+template <int METHOD>
+__device__ __forceinline__ void partial_merge(Partial &a, const Partial &b, bool def_nan) {
+  const uint32_t cnt = (a.meta & 0x7FFFFFFFu) + (b.meta & 0x7FFFFFFFu);
+  const bool ha = (a.meta & 0x80000000u) != 0, hb = (b.meta & 0x80000000u) != 0;
+  bool has = ha || hb;
+  if (ha && hb) {
+    if constexpr (METHOD == OLAP_SUM || METHOD == OLAP_AVERAGE || METHOD == OLAP_PARTIAL_AVERAGE) a.acc += b.acc;
+    else if constexpr (METHOD == OLAP_PRODUCT) a.acc *= b.acc;
+    else if constexpr (METHOD == OLAP_HIGHEST) a.acc = js_max(a.acc, b.acc);
+    else if constexpr (METHOD == OLAP_LOWEST) a.acc = js_min(a.acc, b.acc);
+    else if constexpr (METHOD == OLAP_FIRST) { if (b.pos < a.pos) { a.acc = b.acc; a.pos = b.pos; } }
+    else { if (b.pos >= a.pos) { a.acc = b.acc; a.pos = b.pos; } }
+    if constexpr (METHOD == OLAP_SUM || METHOD == OLAP_AVERAGE || METHOD == OLAP_PARTIAL_AVERAGE || METHOD == OLAP_PRODUCT)
+      if (is_default_f64(a.acc, def_nan)) has = false;
+  } else if (hb) {
+    a.acc = b.acc;
+    a.pos = b.pos;
+  }
+  a.meta = (has ? 0x80000000u : 0u) | (cnt & 0x7FFFFFFFu);
+}
+
+struct DrillUpReduce {
+  uint32_t S;         // segments per group
+  uint32_t seg_len;   // members per segment
+  uint32_t rows;      // member rows a unit reads per step: power of two, rows * inner <= unit
+  uint32_t unit;      // lanes cooperating on one (outer, group, segment): 64 (a wavefront) or 256
+  uint32_t vec4;      // 1: the 16 B form (drillup_reduce4_kernel) applies; `rows` is then sized for unit*4 cells
+  Partial *part;      // [outer*G*inner * S]
+};
+
+// One UNIT (a wavefront for short segments, a whole workgroup for long ones) per (outer, group,
+// segment); its lanes cover `rows` consecutive members x `inner` cells per step, i.e. consecutive
+// memory for contiguous groups: coalesced however small `inner` is.
+template <typename T, int METHOD, bool HAS_STATUS, bool FAST>
+__global__ __launch_bounds__(kBlock) void drillup_reduce_kernel(const T *__restrict__ in,
+                                                                const int32_t *__restrict__ st_in,
+                                                                const DrillUpAxis a, const DrillUpReduce rd) {
+  __shared__ Partial lds[kBlock];
+  const uint32_t inner = (uint32_t)a.inner;
+  const uint32_t units_per_block = kBlock / rd.unit;
+  const uint64_t unit_id = (uint64_t)blockIdx.x * units_per_block + threadIdx.x / rd.unit;
+  const uint64_t n_units = a.outer * a.G * rd.S;
+  const bool live = unit_id < n_units;
+  const uint32_t seg = (uint32_t)(unit_id % rd.S);
+  const uint64_t og = live ? unit_id / rd.S : 0;
+  const uint64_t g = og % a.G, o = og / a.G;
+  const uint32_t lane = threadIdx.x % rd.unit;
+  const uint32_t lds_base = threadIdx.x - lane;
+  const bool active = live && lane < rd.rows * inner;
+  const uint32_t i = lane % inner, r = lane / inner;
+  const bool def_nan = a.def_nan != 0;
+  const uint32_t gend = a.gstart[g + 1];
+  const uint64_t s0 = (uint64_t)a.gstart[g] + (uint64_t)seg * rd.seg_len;
+  const uint32_t jbeg = s0 < gend ? (uint32_t)s0 : gend;
+  const uint32_t jend = (uint64_t)jbeg + rd.seg_len < gend ? jbeg + rd.seg_len : gend;
+  const T *base = in + (o * a.K) * a.inner + i;
+  const int32_t *sbase = HAS_STATUS ? st_in + (o * a.K) * a.inner + i : nullptr;
+  Partial p = partial_identity<METHOD>();
+  if (active) {
+    constexpr int U = 8;
+    for (uint32_t j = jbeg + r; j < jend; j += rd.rows * U) {
+      T x[U];
+      int32_t sx[U];
+      uint32_t jj[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        jj[u] = j + u * rd.rows;
+        const uint32_t jc = jj[u] < jend ? jj[u] : j;
+        const uint64_t k = a.order ? (uint64_t)a.order[jc] : (uint64_t)jc;
+        x[u] = base[k * a.inner];
+        sx[u] = HAS_STATUS ? sbase[k * a.inner] : OLAP_STATUS_SET;
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if constexpr (FAST) {
+          // additive method, zero default, no mask: unset cells hold 0 (see Lane::add_row)
+          const double v = jj[u] < jend ? Cell<T>::to_f64(x[u]) : 0.0;
+          p.acc += v;
+          p.meta += (v != 0.0) ? 1u : 0u;
+        } else {
+          if (jj[u] < jend && cell_is_set<T>(x[u], sx[u], HAS_STATUS, def_nan)) partial_add<METHOD>(p, Cell<T>::to_f64(x[u]), jj[u], def_nan);
+        }
+      }
+    }
+  }
+  if constexpr (FAST) p.meta = (p.meta & 0x7FFFFFFFu) | ((p.meta != 0 && p.acc != 0.0) ? 0x80000000u : 0u);
+  lds[lds_base + lane] = p;
+  __syncthreads();
+  for (uint32_t s = rd.rows >> 1; s > 0; s >>= 1) {
+    if (active && r < s) {
+      Partial q = lds[lds_base + lane + s * inner];
+      partial_merge<METHOD>(p, q, def_nan);
+      lds[lds_base + lane] = p;
+    }
+    __syncthreads();
+  }
+  if (active && r == 0) rd.part[((o * a.G + g) * a.inner + i) * rd.S + seg] = p;
+}
+
+// 16 B form of the cooperative reduction for '-> all' roll-ups of contiguous rows (G == 1, no member
+// table, K*inner and the segment length multiples of 4 cells): the unit streams `rows*inner`
+// consecutive cells per step as one float4 per lane; lane element e always lands on output cell
+// (lane*4 + e) % inner because the step is a whole number of rows.
+template <typename T, int METHOD, bool HAS_STATUS, bool FAST>
+__global__ __launch_bounds__(kBlock) void drillup_reduce4_kernel(const T *__restrict__ in,
+                                                                 const int32_t *__restrict__ st_in,
+                                                                 const DrillUpAxis a, const DrillUpReduce rd) {
+  __shared__ Partial lds[kBlock * 4];
+  const uint32_t inner = (uint32_t)a.inner;
+  const uint32_t units_per_block = kBlock / rd.unit;
+  const uint64_t unit_id = (uint64_t)blockIdx.x * units_per_block + threadIdx.x / rd.unit;
+  const uint64_t n_units = a.outer * rd.S;  // G == 1
+  const bool live = unit_id < n_units;
+  const uint32_t seg = (uint32_t)(unit_id % rd.S);
+  const uint64_t o = live ? unit_id / rd.S : 0;
+  const uint32_t lane = threadIdx.x % rd.unit;
+  const uint32_t lds_base = (threadIdx.x - lane) * 4;
+  const uint32_t step_cells = rd.rows * inner;          // multiple of 4, <= unit * 4
+  const bool active = live && lane * 4 < step_cells;
+  const bool def_nan = a.def_nan != 0;
+  const uint64_t jbeg = (uint64_t)seg * rd.seg_len < a.K ? (uint64_t)seg * rd.seg_len : a.K;
+  const uint64_t jend = jbeg + rd.seg_len < a.K ? jbeg + rd.seg_len : a.K;
+  const uint64_t cell_beg = jbeg * inner, cell_end = jend * inner;  // within the row `o`
+  const T *row = in + o * a.K * a.inner;
+  const int32_t *srow = HAS_STATUS ? st_in + o * a.K * a.inner : nullptr;
+  Partial p[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) p[e] = partial_identity<METHOD>();
+  if (active) {
+    constexpr int U = 4;
+    constexpr int V = 4;
+    for (uint64_t c = cell_beg + lane * 4; c < cell_end; c += (uint64_t)step_cells * U) {
+      Vec<T, V> x[U];
+      Vec<int32_t, V> sx[U];
+      uint64_t cc[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        cc[u] = c + (uint64_t)u * step_cells;
+        const uint64_t at = cc[u] < cell_end ? cc[u] : c;  // cell_end - cell_beg is a multiple of 4
+        x[u] = load_stream<T, V>(row + at);
+        if constexpr (HAS_STATUS) sx[u] = load_stream<int32_t, V>(srow + at);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const bool in_range = cc[u] < cell_end;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if constexpr (FAST) {
+            const double v = in_range ? Cell<T>::to_f64(x[u].v[e]) : 0.0;
+            p[e].acc += v;
+            p[e].meta += (v != 0.0) ? 1u : 0u;
+          } else {
+            const int32_t st = HAS_STATUS ? sx[u].v[e] : OLAP_STATUS_SET;
+            if (in_range && cell_is_set<T>(x[u].v[e], st, HAS_STATUS, def_nan))
+              partial_add<METHOD>(p[e], Cell<T>::to_f64(x[u].v[e]), (uint32_t)((cc[u] + e) / inner), def_nan);
+          }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    if constexpr (FAST) p[e].meta = (p[e].meta & 0x7FFFFFFFu) | ((p[e].meta != 0 && p[e].acc != 0.0) ? 0x80000000u : 0u);
+    lds[lds_base + lane * 4 + e] = p[e];
+  }
+  __syncthreads();
+  // tree over the rows of a step: flat slot f = r*inner + i
+  for (uint32_t s = rd.rows >> 1; s > 0; s >>= 1) {
+    if (live) {
+      for (uint32_t f = lane; f < s * inner; f += rd.unit) {
+        Partial x = lds[lds_base + f];
+        const Partial y = lds[lds_base + f + s * inner];
+        partial_merge<METHOD>(x, y, def_nan);
+        lds[lds_base + f] = x;
+      }
+    }
+    __syncthreads();
+  }
+  if (live)
+    for (uint32_t i = lane; i < inner; i += rd.unit) rd.part[(o * a.inner + i) * rd.S + seg] = lds[lds_base + i];
+}
+
+// Lane-per-(cell, segment) form for wide `inner` (> 128): lanes along `inner` are already coalesced.
+template <typename T, int METHOD, bool HAS_STATUS, bool FAST>
 __global__ __launch_bounds__(kBlock) void drillup_split_kernel(const T *__restrict__ in,
                                                                const int32_t *__restrict__ st_in,
-                                                               const DrillUpAxis a, const DrillUpSplit sp) {
+                                                               const DrillUpAxis a, const DrillUpReduce rd) {
   const uint64_t t = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
   const uint64_t cells = a.outer * a.G * a.inner;
-  if (t >= cells * sp.S) return;
+  if (t >= cells * rd.S) return;
   const uint64_t i = t % a.inner;
-  const uint32_t seg = (uint32_t)((t / a.inner) % sp.S);
-  const uint64_t og = t / (a.inner * sp.S);
+  const uint32_t seg = (uint32_t)((t / a.inner) % rd.S);
+  const uint64_t og = t / (a.inner * rd.S);
   const uint64_t g = og % a.G, o = og / a.G;
   const bool def_nan = a.def_nan != 0;
   const T *base = in + (o * a.K) * a.inner + i;
   const int32_t *sbase = HAS_STATUS ? st_in + (o * a.K) * a.inner + i : nullptr;
   const uint32_t gend = a.gstart[g + 1];
-  uint64_t j64 = (uint64_t)a.gstart[g] + (uint64_t)seg * sp.seg_len;
-  uint32_t j = j64 < gend ? (uint32_t)j64 : gend;
-  const uint32_t jend = (uint64_t)j + sp.seg_len < gend ? j + sp.seg_len : gend;
-  Agg<METHOD> agg;
-  agg.init();
-  constexpr int U = 4;
+  const uint64_t s0 = (uint64_t)a.gstart[g] + (uint64_t)seg * rd.seg_len;
+  uint32_t j = s0 < gend ? (uint32_t)s0 : gend;
+  const uint32_t jend = (uint64_t)j + rd.seg_len < gend ? j + rd.seg_len : gend;
+  Partial p = partial_identity<METHOD>();
+  constexpr int U = 8;
   for (; j < jend; j += U) {
     const uint32_t n = (jend - j) < (uint32_t)U ? (jend - j) : (uint32_t)U;
     T x[U];
@@ -353,39 +566,54 @@ __global__ __launch_bounds__(kBlock) void drillup_split_kernel(const T *__restri
       sx[u] = HAS_STATUS ? sbase[k * a.inner] : OLAP_STATUS_SET;
     }
 #pragma unroll
-    for (int u = 0; u < U; ++u)
-      if ((uint32_t)u < n && cell_is_set<T>(x[u], sx[u], HAS_STATUS, def_nan)) agg.add(Cell<T>::to_f64(x[u]), def_nan);
-  }
-  const uint64_t w = ((o * a.G + g) * a.inner + i) * sp.S + seg;
-  sp.acc[w] = agg.acc;
-  sp.meta[w] = (agg.has ? 0x80000000u : 0u) | (agg.count & 0x7FFFFFFFu);
-}
-
-template <typename T, int METHOD>
-__global__ __launch_bounds__(kBlock) void drillup_merge_kernel(T *__restrict__ out, int32_t *__restrict__ st_out,
-                                                               const DrillUpAxis a, const DrillUpSplit sp) {
-  const uint64_t t = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (t >= a.outer * a.G * a.inner) return;
-  const bool def_nan = a.def_nan != 0;
-  Agg<METHOD> agg;
-  agg.init();
-  for (uint32_t s = 0; s < sp.S; ++s) {
-    const uint32_t m = sp.meta[t * sp.S + s];
-    const uint32_t cnt = m & 0x7FFFFFFFu;
-    if (m & 0x80000000u) {
-      agg.add(sp.acc[t * sp.S + s], def_nan);  // counts one contribution ...
-      agg.count += cnt - 1;                    // ... the segment had `cnt`
-    } else {
-      agg.count += cnt;  // contributions that cancelled to the default inside the segment
+    for (int u = 0; u < U; ++u) {
+      if constexpr (FAST) {
+        const double v = (uint32_t)u < n ? Cell<T>::to_f64(x[u]) : 0.0;
+        p.acc += v;
+        p.meta += (v != 0.0) ? 1u : 0u;
+      } else {
+        if ((uint32_t)u < n && cell_is_set<T>(x[u], sx[u], HAS_STATUS, def_nan)) partial_add<METHOD>(p, Cell<T>::to_f64(x[u]), j + u, def_nan);
+      }
     }
   }
-  agg.finish(def_nan);
-  T ov;
-  int32_t os;
-  emit_cell<T>(agg.acc, agg.has, def_nan, ov, os);
-  if constexpr (METHOD == OLAP_PARTIAL_AVERAGE) os = (int32_t)agg.count;
-  out[t] = ov;
-  if (st_out) st_out[t] = os;
+  if constexpr (FAST) p.meta = (p.meta & 0x7FFFFFFFu) | ((p.meta != 0 && p.acc != 0.0) ? 0x80000000u : 0u);
+  rd.part[((o * a.G + g) * a.inner + i) * rd.S + seg] = p;
+}
+
+// One wavefront per output cell merges its S partial states (segments are ascending member ranges).
+template <typename T, int METHOD>
+__global__ __launch_bounds__(kBlock) void drillup_merge_kernel(T *__restrict__ out, int32_t *__restrict__ st_out,
+                                                               const DrillUpAxis a, const DrillUpReduce rd) {
+  const uint64_t cell = ((uint64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
+  const uint32_t lane = threadIdx.x & 63;
+  if (cell >= a.outer * a.G * a.inner) return;  // whole waves leave together
+  const bool def_nan = a.def_nan != 0;
+  Partial p = partial_identity<METHOD>();
+  for (uint32_t s = lane; s < rd.S; s += 64) {
+    const Partial q = rd.part[cell * rd.S + s];
+    partial_merge<METHOD>(p, q, def_nan);
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    Partial q;
+    q.acc = __shfl_down(p.acc, off, 64);
+    q.meta = __shfl_down(p.meta, off, 64);
+    q.pos = __shfl_down(p.pos, off, 64);
+    partial_merge<METHOD>(p, q, def_nan);
+  }
+  if (lane == 0) {
+    Agg<METHOD> agg;
+    agg.acc = p.acc;
+    agg.has = (p.meta & 0x80000000u) != 0;
+    agg.count = p.meta & 0x7FFFFFFFu;
+    agg.finish(def_nan);
+    T ov;
+    int32_t os;
+    emit_cell<T>(agg.acc, agg.has, def_nan, ov, os);
+    if constexpr (METHOD == OLAP_PARTIAL_AVERAGE) os = (int32_t)agg.count;
+    out[cell] = ov;
+    if (st_out) st_out[cell] = os;
+  }
 }
 
 // ======================================================================= K1g: drillUp, any maps
@@ -1020,8 +1248,8 @@ template <typename T>
 struct Launch {
   static hipError_t drillup_axis(int method, bool has_status, int vec, const T *in, const int32_t *st_in, T *out,
                                  int32_t *st_out, const DrillUpAxis &a, hipStream_t stream);
-  static hipError_t drillup_split(int method, bool has_status, const T *in, const int32_t *st_in, T *out, int32_t *st_out,
-                                  const DrillUpAxis &a, const DrillUpSplit &sp, hipStream_t stream);
+  static hipError_t drillup_reduce(int method, bool has_status, const T *in, const int32_t *st_in, T *out, int32_t *st_out,
+                                   const DrillUpAxis &a, const DrillUpReduce &rd, hipStream_t stream);
   static hipError_t drillup_generic(int method, bool has_status, const T *in, const int32_t *st_in, T *out,
                                     int32_t *st_out, const DrillUpGeneric &a, hipStream_t stream);
   static hipError_t gather(bool has_status, int vec, const T *in, const int32_t *st_in, T *out, int32_t *st_out,
@@ -1079,10 +1307,14 @@ static hipError_t drillup_axis_launch(const T *in, const int32_t *st_in, T *out,
     const uint64_t row_elems = a.K * a.inner;
     const uint64_t budget = kTileBytes / sizeof(T);
     const uint64_t csr_bytes = (a.G + 1 + a.K) * 4;
-    if (a.aligned16 && a.inner < 16 && row_elems > 0 && row_elems * 4 <= budget && csr_bytes <= 16 * 1024 &&
-        a.G * a.inner <= 0xFFFFFFFFull) {
+    // rows per tile: as many as fit; every tile must start 16 B aligned, i.e. R*row_elems % V == 0
+    uint64_t R = row_elems ? budget / row_elems : 0;
+    constexpr uint64_t V = 16 / sizeof(T);
+    if (R >= 4) R &= ~3ull;
+    while (R > 0 && (R * row_elems) % V != 0) --R;
+    if (a.aligned16 && a.inner < 16 && R > 0 && csr_bytes <= 16 * 1024 && a.G * a.inner <= 0xFFFFFFFFull) {
       DrillUpTile tl;
-      tl.rows_per_tile = (uint32_t)((budget / row_elems) & ~3ull);
+      tl.rows_per_tile = (uint32_t)R;
       tl.row_elems = (uint32_t)row_elems;
       tl.out_row = (uint32_t)(a.G * a.inner);
       tl.inner = (uint32_t)a.inner;
@@ -1150,28 +1382,52 @@ hipError_t Launch<T>::drillup_axis(int method, bool has_status, int vec, const T
 }
 
 template <typename T, int METHOD>
-static hipError_t drillup_split_launch(bool has_status, const T *in, const int32_t *st_in, T *out, int32_t *st_out,
-                                       const DrillUpAxis &a, const DrillUpSplit &sp, hipStream_t stream) {
+static hipError_t drillup_reduce_launch(bool has_status, const T *in, const int32_t *st_in, T *out, int32_t *st_out,
+                                        const DrillUpAxis &a, const DrillUpReduce &rd, hipStream_t stream) {
   const uint64_t cells = a.outer * a.G * a.inner;
-  if (has_status) hipLaunchKernelGGL((drillup_split_kernel<T, METHOD, true>), grid_for(cells * sp.S), kBlock, 0, stream, in, st_in, a, sp);
-  else hipLaunchKernelGGL((drillup_split_kernel<T, METHOD, false>), grid_for(cells * sp.S), kBlock, 0, stream, in, st_in, a, sp);
-  hipLaunchKernelGGL((drillup_merge_kernel<T, METHOD>), grid_for(cells), kBlock, 0, stream, out, st_out, a, sp);
+  constexpr bool kAdditive = (METHOD == OLAP_SUM || METHOD == OLAP_AVERAGE || METHOD == OLAP_PARTIAL_AVERAGE);
+  const bool fast = kAdditive && !has_status && !a.def_nan;
+  if (rd.rows > 0) {  // cooperative form (inner <= 128)
+    const uint64_t upb = kBlock / rd.unit;
+    const unsigned grid = (unsigned)((a.outer * a.G * rd.S + upb - 1) / upb);
+    if (rd.vec4 && a.aligned16 && sizeof(T) == 4) {
+      if (has_status) hipLaunchKernelGGL((drillup_reduce4_kernel<T, METHOD, true, false>), grid, kBlock, 0, stream, in, st_in, a, rd);
+      else if (kAdditive && fast) hipLaunchKernelGGL((drillup_reduce4_kernel<T, METHOD, false, kAdditive>), grid, kBlock, 0, stream, in, st_in, a, rd);
+      else hipLaunchKernelGGL((drillup_reduce4_kernel<T, METHOD, false, false>), grid, kBlock, 0, stream, in, st_in, a, rd);
+    } else {
+      DrillUpReduce r1 = rd;
+      if (rd.vec4) {  // plan sized `rows` for 16 B lanes; the scalar form covers unit cells per step
+        uint32_t rows = 1;
+        while ((uint64_t)rows * 2 * a.inner <= rd.unit) rows *= 2;
+        r1.rows = rows;
+      }
+      if (has_status) hipLaunchKernelGGL((drillup_reduce_kernel<T, METHOD, true, false>), grid, kBlock, 0, stream, in, st_in, a, r1);
+      else if (kAdditive && fast) hipLaunchKernelGGL((drillup_reduce_kernel<T, METHOD, false, kAdditive>), grid, kBlock, 0, stream, in, st_in, a, r1);
+      else hipLaunchKernelGGL((drillup_reduce_kernel<T, METHOD, false, false>), grid, kBlock, 0, stream, in, st_in, a, r1);
+    }
+  } else {
+    const unsigned grid = grid_for(cells * rd.S);
+    if (has_status) hipLaunchKernelGGL((drillup_split_kernel<T, METHOD, true, false>), grid, kBlock, 0, stream, in, st_in, a, rd);
+    else if (kAdditive && fast) hipLaunchKernelGGL((drillup_split_kernel<T, METHOD, false, kAdditive>), grid, kBlock, 0, stream, in, st_in, a, rd);
+    else hipLaunchKernelGGL((drillup_split_kernel<T, METHOD, false, false>), grid, kBlock, 0, stream, in, st_in, a, rd);
+  }
+  hipLaunchKernelGGL((drillup_merge_kernel<T, METHOD>), grid_for(cells * 64), kBlock, 0, stream, out, st_out, a, rd);
   return hipGetLastError();
 }
 
 template <typename T>
-hipError_t Launch<T>::drillup_split(int method, bool has_status, const T *in, const int32_t *st_in, T *out,
-                                    int32_t *st_out, const DrillUpAxis &a, const DrillUpSplit &sp, hipStream_t stream) {
+hipError_t Launch<T>::drillup_reduce(int method, bool has_status, const T *in, const int32_t *st_in, T *out,
+                                     int32_t *st_out, const DrillUpAxis &a, const DrillUpReduce &rd, hipStream_t stream) {
   if (a.outer * a.G * a.inner == 0) return hipSuccess;
   switch (method) {
-    case OLAP_SUM: return drillup_split_launch<T, OLAP_SUM>(has_status, in, st_in, out, st_out, a, sp, stream);
-    case OLAP_AVERAGE: return drillup_split_launch<T, OLAP_AVERAGE>(has_status, in, st_in, out, st_out, a, sp, stream);
-    case OLAP_HIGHEST: return drillup_split_launch<T, OLAP_HIGHEST>(has_status, in, st_in, out, st_out, a, sp, stream);
-    case OLAP_LOWEST: return drillup_split_launch<T, OLAP_LOWEST>(has_status, in, st_in, out, st_out, a, sp, stream);
-    case OLAP_FIRST: return drillup_split_launch<T, OLAP_FIRST>(has_status, in, st_in, out, st_out, a, sp, stream);
-    case OLAP_LAST: return drillup_split_launch<T, OLAP_LAST>(has_status, in, st_in, out, st_out, a, sp, stream);
-    case OLAP_PARTIAL_AVERAGE: return drillup_split_launch<T, OLAP_PARTIAL_AVERAGE>(has_status, in, st_in, out, st_out, a, sp, stream);
-    default: return drillup_split_launch<T, OLAP_PRODUCT>(has_status, in, st_in, out, st_out, a, sp, stream);
+    case OLAP_SUM: return drillup_reduce_launch<T, OLAP_SUM>(has_status, in, st_in, out, st_out, a, rd, stream);
+    case OLAP_AVERAGE: return drillup_reduce_launch<T, OLAP_AVERAGE>(has_status, in, st_in, out, st_out, a, rd, stream);
+    case OLAP_HIGHEST: return drillup_reduce_launch<T, OLAP_HIGHEST>(has_status, in, st_in, out, st_out, a, rd, stream);
+    case OLAP_LOWEST: return drillup_reduce_launch<T, OLAP_LOWEST>(has_status, in, st_in, out, st_out, a, rd, stream);
+    case OLAP_FIRST: return drillup_reduce_launch<T, OLAP_FIRST>(has_status, in, st_in, out, st_out, a, rd, stream);
+    case OLAP_LAST: return drillup_reduce_launch<T, OLAP_LAST>(has_status, in, st_in, out, st_out, a, rd, stream);
+    case OLAP_PARTIAL_AVERAGE: return drillup_reduce_launch<T, OLAP_PARTIAL_AVERAGE>(has_status, in, st_in, out, st_out, a, rd, stream);
+    default: return drillup_reduce_launch<T, OLAP_PRODUCT>(has_status, in, st_in, out, st_out, a, rd, stream);
   }
 }
 

@@ -328,8 +328,9 @@ def test_config3_chain_fused_vs_unfused():
 @pytest.mark.parametrize("method", ["sum", "average", "highest", "lowest", "first", "last", "product"])
 @pytest.mark.parametrize("type_name,default", [("float32", 0.0), ("float32", float("nan")), ("int32", 0.0), ("uint32", float("nan")), ("float64", 0.0)])
 def test_split_regime_few_outputs_long_groups(method, type_name, default):
-    """[6000, 7] -> [2, 7]: 14 output cells, groups of ~3000 rows: the split (segments + ordered merge)
-    regime.  Picks are exact; float64 sums are re-associated across segments (1e-12 relative)."""
+    """[6000, 7] -> [2, 7]: 14 output cells, groups of ~3000 rows: the reduce regime (cooperative
+    segments + merge).  Picks are exact; float64 sums are re-associated (1e-12 relative; the inputs
+    here are quarter-integers, so float32/int results are still exact)."""
     rng = np.random.default_rng(5)
     lens = [6000, 7]
     n = 42000
@@ -346,7 +347,7 @@ def test_split_regime_few_outputs_long_groups(method, type_name, default):
     row_map = (np.arange(6000) % 2).astype(np.uint32)  # interleaved groups -> `order` table in use
     maps = [row_map, np.arange(7, dtype=np.uint32)]
     plan = pkg.Plan.drillup(type_name, default, method, lens, [2, 7], maps)
-    assert "split" in plan.kernel_name
+    assert "reduce" in plan.kernel_name or "split" in plan.kernel_name
     o = OracleStore(n, type_name, default)
     typed = to_typed(dense, type_name).astype(np.float64)
     if type_name in ("int32", "uint32") and default != default:
@@ -362,3 +363,32 @@ def test_split_regime_few_outputs_long_groups(method, type_name, default):
         assert np.allclose(gv, ev, rtol=1e-12, atol=0, equal_nan=True)
     else:
         assert same_typed(gv, ev)
+
+
+@pytest.mark.parametrize("lens,axis", [([300, 4000], 1), ([5, 70000], 1), ([40000, 200], 0), ([1, 100000], 1), ([100000], 0)])
+@pytest.mark.parametrize("method", ["sum", "average", "first", "last", "highest", "product"])
+def test_reduce_regime_shapes(lens, axis, method):
+    """Long groups with few output cells in every geometry of the reduce regime (cooperative
+    workgroups for inner <= 128, lane-split for wider rows, one- and multi-segment)."""
+    rng = np.random.default_rng(11)
+    n = int(np.prod(lens))
+    if method == "product":
+        vals = np.where(rng.random(n) < 0.5, 1.0, -1.0)
+    else:
+        vals = rng.integers(-8, 9, size=n).astype(np.float64) * 0.5
+    dense = np.where(rng.random(n) < 0.4, 0.0, vals)
+    K = lens[axis]
+    amap = (np.arange(K) * 3 // K).astype(np.uint32) if K >= 3 else np.zeros(K, np.uint32)  # 3 contiguous groups
+    new = list(lens)
+    new[axis] = int(amap.max()) + 1
+    maps = [amap if i == axis else np.arange(l, dtype=np.uint32) for i, l in enumerate(lens)]
+    plan = pkg.Plan.drillup("float32", 0.0, method, lens, new, maps)
+    assert "reduce" in plan.kernel_name or "split" in plan.kernel_name, plan.kernel_name
+    o = OracleStore(n, "float32", 0.0)
+    o.set_data(dense)
+    ev, es = expected_typed(o.drill_up(lens, new, maps, method))
+    g = pkg.HipStore(n, "float32", 0.0)
+    g.set_data_f64(dense)
+    out = g.drill_up(lens, new, maps, method)
+    assert np.array_equal(out.get_status(), es)
+    assert same_typed(out.get_data(), ev)
