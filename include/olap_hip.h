@@ -220,6 +220,17 @@ int olap_store_set_value(olap_store *store, uint64_t index, double value, int is
 int olap_store_fill(olap_store *store, double value);                                         /* :135-137 */
 int olap_store_total(const olap_store *store, double *total);                                 /* :22-28 */
 
+/* The sparse form the reference serialises (in-memory.js:94-100: `indexes` = Map keys as Uint32,
+ * `dataBuffer` = the values as the store's TypedArray): device-side stream compaction of the set
+ * cells in ascending index order, and its inverse.  olap_store_sparse_count() sizes the host
+ * arrays; indices are 32-bit like the reference's (stores above 2^32 cells are refused). */
+int olap_store_to_sparse(const olap_store *store, uint32_t *host_indexes, void *host_values,
+                         uint64_t cap, uint64_t *n_set);
+/* new store with the given cells set (deserialize, in-memory.js:103-116).  Values are stored as
+ * given (TypedArray of the store's dtype); setValue semantics apply (a default value unsets). */
+int olap_store_from_sparse(olap_store **store, uint64_t size, int dtype, int default_kind,
+                           const uint32_t *host_indexes, const void *host_values, uint64_t n);
+
 /* The five bulk operations; each returns a NEW store (load mutates `store`). */
 int olap_store_drillup(const olap_store *store, olap_store **out, int ndim, const uint32_t *old_len,
                        const uint32_t *new_len, const uint32_t *const *maps, int method);

@@ -1521,6 +1521,96 @@ extern "C" int olap_store_total(const olap_store *s, double *total) {
   return olap_total(s->values, s->status, s->size, s->dtype, s->default_kind, total, nullptr, nullptr);
 }
 
+// ---- sparse form (the reference's serialised layout, in-memory.js:75-116) ------------------------
+extern "C" int olap_store_to_sparse(const olap_store *s, uint32_t *host_indexes, void *host_values, uint64_t cap,
+                                    uint64_t *n_set) {
+  if (!s || !n_set) return fail(OLAP_ERR_INVALID_ARGUMENT, "store is NULL");
+  if (s->size > 0xFFFFFFFFull) return fail(OLAP_ERR_INVALID_ARGUMENT, "sparse form uses 32-bit indexes: store too large");
+  *n_set = 0;
+  if (s->size == 0) return OLAP_OK;
+  const unsigned n_chunks = (unsigned)std::min<uint64_t>(2048, (s->size + kBlock - 1) / kBlock);
+  const uint64_t chunk = (s->size + n_chunks - 1) / n_chunks;
+  const int32_t *mask = mask_is_primary(s) ? s->status : nullptr;
+  unsigned long long *dev_counts = nullptr;
+  HIP_TRY(hipMalloc((void **)&dev_counts, n_chunks * sizeof(unsigned long long)));
+  std::vector<unsigned long long> counts(n_chunks), offsets(n_chunks);
+  hipError_t e = hipSuccess;
+  DISPATCH_DTYPE(s->dtype, e = Launch<T>::compact_count((const T *)s->values, mask, s->size, chunk, n_chunks, s->default_kind == OLAP_DEFAULT_NAN, dev_counts, nullptr));
+  if (e == hipSuccess) e = hipMemcpy(counts.data(), dev_counts, n_chunks * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+  unsigned long long total = 0;
+  for (unsigned b = 0; b < n_chunks; ++b) {
+    offsets[b] = total;
+    total += counts[b];
+  }
+  *n_set = total;
+  if (e == hipSuccess && host_indexes && host_values && total > 0) {
+    if (cap < total) {
+      (void)hipFree(dev_counts);
+      return fail(OLAP_ERR_LENGTH_MISMATCH, "sparse form needs room for %llu cells, %llu given", total, (unsigned long long)cap);
+    }
+    uint32_t *dev_idx = nullptr;
+    void *dev_val = nullptr;
+    const size_t es = olap_dtype_size(s->dtype);
+    e = hipMalloc((void **)&dev_idx, total * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc(&dev_val, total * es);
+    if (e == hipSuccess) e = hipMemcpy(dev_counts, offsets.data(), n_chunks * sizeof(unsigned long long), hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+      DISPATCH_DTYPE(s->dtype, e = Launch<T>::compact_write((const T *)s->values, mask, s->size, chunk, n_chunks, s->default_kind == OLAP_DEFAULT_NAN, dev_counts, dev_idx, (T *)dev_val, nullptr));
+    }
+    if (e == hipSuccess) e = hipMemcpy(host_indexes, dev_idx, total * sizeof(uint32_t), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(host_values, dev_val, total * es, hipMemcpyDeviceToHost);
+    if (dev_idx) (void)hipFree(dev_idx);
+    if (dev_val) (void)hipFree(dev_val);
+  }
+  (void)hipFree(dev_counts);
+  if (e != hipSuccess) return hip_fail(e, "to_sparse");
+  return OLAP_OK;
+}
+
+extern "C" int olap_store_from_sparse(olap_store **store, uint64_t size, int dtype, int default_kind,
+                                      const uint32_t *host_indexes, const void *host_values, uint64_t n) {
+  if (!store) return fail(OLAP_ERR_INVALID_ARGUMENT, "store out-pointer is NULL");
+  *store = nullptr;
+  if (n && (!host_indexes || !host_values)) return fail(OLAP_ERR_INVALID_ARGUMENT, "indexes/values is NULL");
+  for (uint64_t i = 0; i < n; ++i)
+    if (host_indexes[i] >= size) return fail(OLAP_ERR_INDEX_RANGE, "cell index %u out of bounds [0, %llu[", host_indexes[i], (unsigned long long)size);
+  olap_store *s = nullptr;
+  int rc = olap_store_create(&s, size, dtype, default_kind);
+  if (rc) return rc;
+  if (n) {
+    uint32_t *dev_idx = nullptr;
+    void *dev_val = nullptr;
+    const size_t es = olap_dtype_size(dtype);
+    hipError_t e = hipMalloc((void **)&dev_idx, n * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc(&dev_val, n * es);
+    if (e == hipSuccess) e = hipMemcpy(dev_idx, host_indexes, n * sizeof(uint32_t), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(dev_val, host_values, n * es, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+      DISPATCH_DTYPE(dtype, e = Launch<T>::scatter_sparse((T *)s->values, dev_idx, (const T *)dev_val, n, size, nullptr));
+    }
+    if (e == hipSuccess && s->status) {
+      // integer cells under a NaN default: the listed cells are exactly the set ones
+      std::vector<int32_t> two(n, OLAP_STATUS_SET);
+      int32_t *dev_two = nullptr;
+      e = hipMalloc((void **)&dev_two, n * sizeof(int32_t));
+      if (e == hipSuccess) e = hipMemcpy(dev_two, two.data(), n * sizeof(int32_t), hipMemcpyHostToDevice);
+      if (e == hipSuccess) e = Launch<int32_t>::scatter_sparse(s->status, dev_idx, dev_two, n, size, nullptr);
+      if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
+      if (dev_two) (void)hipFree(dev_two);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
+    if (dev_idx) (void)hipFree(dev_idx);
+    if (dev_val) (void)hipFree(dev_val);
+    if (e != hipSuccess) {
+      olap_store_destroy(s);
+      return hip_fail(e, "from_sparse");
+    }
+    // setValue semantics: a listed default value leaves the cell unset (float cells: implied by the value)
+  }
+  *store = s;
+  return OLAP_OK;
+}
+
 // Integer cells under a NaN default are the one case where the mask carries information the
 // values cannot; everywhere else the kernels derive "set" from the value and skip the mask read.
 static const int32_t *mask_needed(const olap_store *s) { return mask_is_primary(s) ? s->status : nullptr; }

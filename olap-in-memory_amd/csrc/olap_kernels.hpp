@@ -1243,6 +1243,69 @@ __global__ void set_cell_kernel(T *values, int32_t *status, uint64_t index, doub
   if (status) status[index] = os;
 }
 
+// ======================================================================= sparse <-> dense
+// Stream compaction of the set cells (ascending), for the reference's wire format: each workgroup
+// owns a contiguous chunk; pass 1 counts, the host prefix-sums the (few thousand) chunk counts,
+// pass 2 writes.  Inside a chunk the order comes from 64-bit wave ballots + popcounts.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void compact_count_kernel(const T *values, const int32_t *status, uint64_t n,
+                                                               uint64_t chunk, int def_nan_i, unsigned long long *counts) {
+  const bool def_nan = def_nan_i != 0;
+  const uint64_t lo = (uint64_t)blockIdx.x * chunk, hi = lo + chunk < n ? lo + chunk : n;
+  unsigned long long c = 0;
+  for (uint64_t i = lo + threadIdx.x; i < hi; i += kBlock)
+    c += cell_is_set<T>(values[i], status ? status[i] : OLAP_STATUS_SET, status != nullptr, def_nan) ? 1 : 0;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
+  __shared__ unsigned long long s[kBlock / 64];
+  if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) counts[blockIdx.x] = s[0] + s[1] + s[2] + s[3];
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void compact_write_kernel(const T *values, const int32_t *status, uint64_t n,
+                                                               uint64_t chunk, int def_nan_i,
+                                                               const unsigned long long *offsets, uint32_t *idx_out,
+                                                               T *val_out) {
+  const bool def_nan = def_nan_i != 0;
+  const uint64_t lo = (uint64_t)blockIdx.x * chunk, hi = lo + chunk < n ? lo + chunk : n;
+  __shared__ unsigned long long s_wave[kBlock / 64];
+  __shared__ unsigned long long s_base;
+  if (threadIdx.x == 0) s_base = offsets[blockIdx.x];
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (uint64_t base = lo; base < hi; base += kBlock) {  // uniform trip count for the whole workgroup
+    const uint64_t i = base + threadIdx.x;
+    T v = T(0);
+    bool set = false;
+    if (i < hi) {
+      v = values[i];
+      set = cell_is_set<T>(v, status ? status[i] : OLAP_STATUS_SET, status != nullptr, def_nan);
+    }
+    const unsigned long long ballot = __ballot(set);
+    if (lane == 0) s_wave[wave] = __popcll(ballot);
+    __syncthreads();
+    unsigned long long before = s_base;
+    for (int w = 0; w < wave; ++w) before += s_wave[w];
+    if (set) {
+      const unsigned long long at = before + __popcll(ballot & ((1ull << lane) - 1ull));
+      idx_out[at] = (uint32_t)i;
+      val_out[at] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) s_base += s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+    __syncthreads();
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void scatter_sparse_kernel(T *values, const uint32_t *idx, const T *vals, uint64_t n_set,
+                                                                uint64_t size) {
+  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n_set; i += (uint64_t)gridDim.x * kBlock)
+    if (idx[i] < size) values[idx[i]] = vals[i];
+}
+
 // ======================================================================= launchers
 template <typename T>
 struct Launch {
@@ -1275,6 +1338,13 @@ struct Launch {
                                    hipStream_t stream);
   static hipError_t total(const T *values, const int32_t *status, uint64_t n, int def_nan, double *total,
                           unsigned long long *count, hipStream_t stream);
+  static hipError_t compact_count(const T *values, const int32_t *status, uint64_t n, uint64_t chunk, unsigned n_chunks,
+                                  int def_nan, unsigned long long *counts, hipStream_t stream);
+  static hipError_t compact_write(const T *values, const int32_t *status, uint64_t n, uint64_t chunk, unsigned n_chunks,
+                                  int def_nan, const unsigned long long *offsets, uint32_t *idx_out, T *val_out,
+                                  hipStream_t stream);
+  static hipError_t scatter_sparse(T *values, const uint32_t *idx, const T *vals, uint64_t n_set, uint64_t size,
+                                   hipStream_t stream);
   static hipError_t set_cell(T *values, int32_t *status, uint64_t index, double value, int is_null, int def_nan,
                              hipStream_t stream);
 };
@@ -1599,6 +1669,31 @@ hipError_t Launch<T>::total(const T *values, const int32_t *status, uint64_t n, 
                             unsigned long long *count, hipStream_t stream) {
   if (n == 0) return hipSuccess;
   hipLaunchKernelGGL((total_kernel<T>), grid_stride_for(n), kBlock, 0, stream, values, status, n, def_nan, total, count);
+  return hipGetLastError();
+}
+
+template <typename T>
+hipError_t Launch<T>::compact_count(const T *values, const int32_t *status, uint64_t n, uint64_t chunk, unsigned n_chunks,
+                                    int def_nan, unsigned long long *counts, hipStream_t stream) {
+  if (n_chunks == 0) return hipSuccess;
+  hipLaunchKernelGGL((compact_count_kernel<T>), n_chunks, kBlock, 0, stream, values, status, n, chunk, def_nan, counts);
+  return hipGetLastError();
+}
+
+template <typename T>
+hipError_t Launch<T>::compact_write(const T *values, const int32_t *status, uint64_t n, uint64_t chunk, unsigned n_chunks,
+                                    int def_nan, const unsigned long long *offsets, uint32_t *idx_out, T *val_out,
+                                    hipStream_t stream) {
+  if (n_chunks == 0) return hipSuccess;
+  hipLaunchKernelGGL((compact_write_kernel<T>), n_chunks, kBlock, 0, stream, values, status, n, chunk, def_nan, offsets, idx_out, val_out);
+  return hipGetLastError();
+}
+
+template <typename T>
+hipError_t Launch<T>::scatter_sparse(T *values, const uint32_t *idx, const T *vals, uint64_t n_set, uint64_t size,
+                                     hipStream_t stream) {
+  if (n_set == 0) return hipSuccess;
+  hipLaunchKernelGGL((scatter_sparse_kernel<T>), grid_stride_for(n_set), kBlock, 0, stream, values, idx, vals, n_set, size);
   return hipGetLastError();
 }
 

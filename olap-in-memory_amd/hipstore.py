@@ -258,6 +258,26 @@ class HipStore:
         check(self._lib.olap_store_get_keys(self._h, out.ctypes.data_as(capi._pu64), n.value, C.byref(n)))
         return out[: n.value]
 
+    def to_sparse(self):
+        """(indexes uint32[n], values typed[n]) of the set cells, ascending: the reference's serialised form."""
+        n = C.c_uint64()
+        check(self._lib.olap_store_to_sparse(self._h, None, None, 0, C.byref(n)))
+        idx = np.zeros(max(n.value, 1), dtype=np.uint32)
+        vals = np.zeros(max(n.value, 1), dtype=NP_DTYPES[self.type])
+        check(self._lib.olap_store_to_sparse(self._h, idx.ctypes.data_as(capi._pu32), vals.ctypes.data_as(C.c_void_p),
+                                             n.value, C.byref(n)))
+        return idx[: n.value], vals[: n.value]
+
+    @classmethod
+    def from_sparse(cls, size, type, default, indexes, values):
+        L = capi.lib()
+        idx = np.ascontiguousarray(np.asarray(indexes, dtype=np.uint32))
+        vals = np.ascontiguousarray(np.asarray(values, dtype=NP_DTYPES[type]))
+        h = C.c_void_p()
+        check(L.olap_store_from_sparse(C.byref(h), int(size), DTYPES[type], _default_kind(default),
+                                       idx.ctypes.data_as(capi._pu32), vals.ctypes.data_as(C.c_void_p), idx.size))
+        return cls(0, _handle=h)
+
     def get_value(self, index):
         v, s = C.c_double(), C.c_int()
         check(self._lib.olap_store_get_value(self._h, int(index), C.byref(v), C.byref(s)))

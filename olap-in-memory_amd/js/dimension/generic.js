@@ -7,6 +7,7 @@
  * intersect :320-337); the implementation is independent.
  */
 const AbstractDimension = require('./abstract');
+const { toBuffer, fromBuffer } = require('../wire');
 
 const resolve = (source, key) => {
   if (!source) return key;
@@ -187,8 +188,38 @@ class GenericDimension extends AbstractDimension {
     return this.drillUp(attribute).dice(attribute, common);
   }
 
+  /** Same record as the reference (generic.js:62-72). */
   serialize() {
-    throw new Error('Serialisation is outside the accelerated path (see DESIGN.md §7)');
+    const items = {};
+    const labels = {};
+    const maps = {};
+    for (const attr of this.attributes) {
+      items[attr] = this._attr[attr].items;
+      labels[attr] = this._attr[attr].labels;
+      maps[attr] = this._attr[attr].map;
+    }
+    return toBuffer({
+      id: this.id,
+      label: this.label,
+      rootAttribute: this._rootAttribute,
+      rootItems: items[this._rootAttribute],
+      attributeItems: items,
+      attributeLabels: labels,
+      attributeMappings: maps,
+    });
+  }
+
+  static deserialize(buffer) {
+    const data = fromBuffer(buffer);
+    const dimension = new GenericDimension(data.id, data.rootAttribute, data.attributeItems[data.rootAttribute], data.label);
+    for (const attr of Object.keys(data.attributeItems)) {
+      dimension._attr[attr] = {
+        items: data.attributeItems[attr],
+        map: Uint32Array.from(data.attributeMappings[attr]),
+        labels: (data.attributeLabels && data.attributeLabels[attr]) || {},
+      };
+    }
+    return dimension;
   }
 }
 

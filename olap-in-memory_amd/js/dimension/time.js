@@ -8,6 +8,7 @@
  */
 const AbstractDimension = require('./abstract');
 const TimeSlot = require('../calendar');
+const { toBuffer, fromBuffer } = require('../wire');
 
 const dayOf = (value, edge) => TimeSlot.fromDate(TimeSlot.fromValue(value)[edge], 'day');
 
@@ -121,8 +122,14 @@ class TimeDimension extends AbstractDimension {
     throw new Error('The dimensions are not compatible');
   }
 
+  /** Same record as the reference (time.js:39-47). */
   serialize() {
-    throw new Error('Serialisation is outside the accelerated path (see DESIGN.md §7)');
+    return toBuffer({ id: this.id, label: this.label, rootAttribute: this.rootAttribute, start: this._start.value, end: this._end.value });
+  }
+
+  static deserialize(buffer) {
+    const data = fromBuffer(buffer);
+    return new TimeDimension(data.id, data.rootAttribute, data.start, data.end, data.label);
   }
 }
 

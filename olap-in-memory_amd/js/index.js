@@ -9,9 +9,10 @@ const GenericDimension = require('./dimension/generic');
 const TimeDimension = require('./dimension/time');
 const HipStore = require('./store/hip');
 const TimeSlot = require('./calendar');
+const wire = require('./wire');
 
 function getParser() {
   throw new Error('getParser (expr-eval computed measures) is outside the accelerated aggregation path of olap-in-memory_amd');
 }
 
-module.exports = { Cube, GenericDimension, TimeDimension, getParser, HipStore, TimeSlot };
+module.exports = { Cube, GenericDimension, TimeDimension, getParser, HipStore, TimeSlot, wire };

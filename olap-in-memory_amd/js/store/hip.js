@@ -9,6 +9,7 @@
  * (include/olap_hip.h) and forwards; all cell work happens in the HIP kernels.
  */
 const backend = require('../backend');
+const { toBuffer, fromBuffer } = require('../wire');
 
 const TYPE_CODE = { int32: 0, uint32: 1, float32: 2, float64: 3 };
 const BYTES = { int32: 4, uint32: 4, float32: 4, float64: 8 };
@@ -210,8 +211,25 @@ class HipStore {
     this._native.load(otherStore._native, lengthsOf(myDimensions), lengthsOf(hisDimensions), hisToMine);
   }
 
+  /**
+   * Same blob as the reference (in-memory.js:75-101): the set cells in sparse form.  The compaction
+   * (set cells -> ascending index / value lists) runs on the device.
+   */
   serialize() {
-    throw new Error('Serialisation is outside the accelerated path (see DESIGN.md §7)');
+    const sparse = this._native.toSparse();
+    return toBuffer({ size: this._size, type: this._type, defaultValue: this._defaultValue, indexes: sparse.indexes, dataBuffer: sparse.values });
+  }
+
+  /** in-memory.js:103-116; accepts blobs written by the reference. */
+  static deserialize(buffer) {
+    const data = fromBuffer(buffer);
+    const type = data.type;
+    if (!Object.prototype.hasOwnProperty.call(TYPE_CODE, type)) throw new Error('Invalid type');
+    const defaultValue = Number.isNaN(data.defaultValue) ? Number.NaN : 0;
+    const TA = { int32: Int32Array, uint32: Uint32Array, float32: Float32Array, float64: Float64Array }[type];
+    const values = data.dataBuffer instanceof TA ? data.dataBuffer : TA.from(data.dataBuffer);
+    const native = backend.load().storeFromSparse(data.size, TYPE_CODE[type], Number.isNaN(defaultValue) ? 1 : 0, Uint32Array.from(data.indexes), values);
+    return new HipStore(data.size, type, defaultValue, native);
   }
 }
 

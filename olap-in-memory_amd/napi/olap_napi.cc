@@ -272,6 +272,55 @@ static napi_value StoreClone(napi_env env, napi_callback_info info) {
   return wrap_new_store(env, c);
 }
 
+// toSparse() -> { indexes: Uint32Array, values: TypedArray } of the set cells (ascending)
+static napi_value StoreToSparse(napi_env env, napi_callback_info info) {
+  STORE_METHOD_PROLOGUE(0)
+  uint64_t n = 0;
+  int rc = olap_store_to_sparse(s, nullptr, nullptr, 0, &n);
+  if (rc) return throw_olap(env, rc);
+  void *idx, *vals;
+  const int dt = olap_store_dtype(s);
+  napi_value ta_idx = make_ta(env, napi_uint32_array, 4, n, &idx);
+  napi_value ta_val = make_ta(env, ta_of(dt), olap_dtype_size(dt), n, &vals);
+  if (!ta_idx || !ta_val) return nullptr;
+  if (n) {
+    rc = olap_store_to_sparse(s, (uint32_t *)idx, vals, n, &n);
+    if (rc) return throw_olap(env, rc);
+  }
+  napi_value out;
+  NAPI_OK(napi_create_object(env, &out));
+  NAPI_OK(napi_set_named_property(env, out, "indexes", ta_idx));
+  NAPI_OK(napi_set_named_property(env, out, "values", ta_val));
+  return out;
+}
+
+// Store.fromSparse(size, dtypeCode, defaultKind, indexes: Uint32Array, values: TypedArray)
+static napi_value StoreFromSparse(napi_env env, napi_callback_info info) {
+  size_t argc = 5;
+  napi_value argv[5];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+  if (argc < 5) return nullptr;
+  double size = 0;
+  int32_t dtype = 0, def = 0;
+  NAPI_OK(napi_get_value_double(env, argv[0], &size));
+  NAPI_OK(napi_get_value_int32(env, argv[1], &dtype));
+  NAPI_OK(napi_get_value_int32(env, argv[2], &def));
+  napi_typedarray_type t_idx, t_val;
+  size_t n_idx = 0, n_val = 0;
+  void *idx = nullptr, *vals = nullptr;
+  if (napi_get_typedarray_info(env, argv[3], &t_idx, &n_idx, &idx, nullptr, nullptr) != napi_ok || t_idx != napi_uint32_array ||
+      napi_get_typedarray_info(env, argv[4], &t_val, &n_val, &vals, nullptr, nullptr) != napi_ok || n_idx != n_val ||
+      t_val != ta_of(dtype)) {
+    napi_throw_type_error(env, nullptr, "fromSparse(size, dtype, default, indexes: Uint32Array, values: TypedArray of the store type)");
+    return nullptr;
+  }
+  olap_store *s = nullptr;
+  static const uint32_t none = 0;
+  int rc = olap_store_from_sparse(&s, (uint64_t)size, dtype, def, idx ? (const uint32_t *)idx : &none, vals ? vals : (const void *)&none, n_idx);
+  if (rc) return throw_olap(env, rc);
+  return wrap_new_store(env, s);
+}
+
 // ---- argument decoding for the bulk operations -----------------------------------------------
 static bool get_u32_vec(napi_env env, napi_value v, std::vector<uint32_t> &out) {
   bool is_ta = false;
@@ -469,6 +518,7 @@ static napi_value Init(napi_env env, napi_value exports) {
       {"setValue", nullptr, StoreSetValue, nullptr, nullptr, nullptr, napi_default, nullptr},
       {"fill", nullptr, StoreFill, nullptr, nullptr, nullptr, napi_default, nullptr},
       {"total", nullptr, StoreTotal, nullptr, nullptr, nullptr, napi_default, nullptr},
+      {"toSparse", nullptr, StoreToSparse, nullptr, nullptr, nullptr, napi_default, nullptr},
       {"clone", nullptr, StoreClone, nullptr, nullptr, nullptr, napi_default, nullptr},
       {"drillUp", nullptr, StoreDrillUp, nullptr, nullptr, nullptr, napi_default, nullptr},
       {"drillDown", nullptr, StoreDrillDown, nullptr, nullptr, nullptr, napi_default, nullptr},
@@ -482,6 +532,7 @@ static napi_value Init(napi_env env, napi_value exports) {
   napi_create_reference(env, ctor, 1, &g_store_ctor);
   napi_set_named_property(env, exports, "Store", ctor);
   napi_property_descriptor fns[] = {
+      {"storeFromSparse", nullptr, StoreFromSparse, nullptr, nullptr, nullptr, napi_default, nullptr},
       {"methodFromName", nullptr, MethodFromName, nullptr, nullptr, nullptr, napi_default, nullptr},
       {"deviceCount", nullptr, DeviceCount, nullptr, nullptr, nullptr, napi_default, nullptr},
       {"abiVersion", nullptr, AbiVersion, nullptr, nullptr, nullptr, napi_default, nullptr},

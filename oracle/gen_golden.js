@@ -531,6 +531,28 @@ function buildConfigs() {
   return meta;
 }
 
+/* ====================== 4. wire format (src/serialization.js) ====================== */
+function buildWire() {
+  const { toBuffer } = require(REF + 'serialization.js');
+  const b64 = (ab) => Buffer.from(ab).toString('base64');
+  const primitives = [Number.NaN, 32, new Int32Array([255]), 'totot', new Float32Array([666]), { toto: { tata: new Float32Array([666]) } }, null, true, [1.5, 'é']];
+  const location = new GenericDimension('location', 'city', ['paris', 'toledo', 'tokyo'], 'Location', { paris: 'Paris', toledo: 'Toledo', tokyo: 'Tokyo' });
+  location.addAttribute('city', 'continent', { paris: 'europe', toledo: 'europe', tokyo: 'asia' });
+  const store = makeStore(12, 'float32', 0, [[1, 1.5], [4, -2], [7, 1e10], [11, 0.25]]);
+  const storeNan = makeStore(5, 'uint32', Number.NaN, [[0, 0], [3, 4000000000]]);
+  return {
+    primitives: b64(toBuffer(primitives)),
+    genericDimension: {
+      blob: b64(location.serialize()),
+      id: 'location', rootAttribute: 'city', label: 'Location', attributes: location.attributes,
+      items: { all: location.getItems('all'), city: location.getItems('city'), continent: location.getItems('continent') },
+      continentMap: Array.from(location.getGroupIndexFromRootIndexMap('continent')),
+    },
+    store: { blob: b64(store.serialize()), dump: dumpStore(store), type: 'float32', default: 0 },
+    storeNanDefault: { blob: b64(storeNan.serialize()), dump: dumpStore(storeNan), type: 'uint32', default: 'NaN' },
+  };
+}
+
 function writeJson(file, obj) {
   fs.writeFileSync(path.join(OUT, file), JSON.stringify(obj));
   console.log(`${file}: ${Array.isArray(obj.cases) ? obj.cases.length : ''} cases`);
@@ -544,3 +566,4 @@ const header = {
 writeJson('store_kat.json', Object.assign({ cases: buildKats() }, header));
 writeJson('store_random.json', Object.assign({ cases: buildRandom() }, header));
 writeJson('configs.json', Object.assign({ cases: buildConfigs() }, header));
+writeJson('wire.json', Object.assign({ cases: buildWire() }, header));

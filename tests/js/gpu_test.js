@@ -389,6 +389,39 @@ describe('compose (test/cube-to-cube.js:5-401, stored-measure cases)', () => {
   });
 });
 
+describe('serialisation (test/cube-serialize.js + blobs written by the reference)', () => {
+  const { HipStore, wire } = require('../../olap-in-memory_amd/js');
+  const golden = JSON.parse(fs.readFileSync(path.join(__dirname, '..', 'golden', 'wire.json'), 'utf8')).cases;
+  const bytes = (b64) => wire.toArrayBuffer(Buffer.from(b64, 'base64'));
+  it('reads store blobs written by the reference and writes the same bytes back', () => {
+    for (const key of ['store', 'storeNanDefault']) {
+      const g = golden[key];
+      const store = HipStore.deserialize(bytes(g.blob));
+      assert.equal(store.size, g.dump.size);
+      assert.equal(store._type, g.type);
+      assert.deepEqual(Array.from(store._dataMap.keys()), g.dump.keys);
+      assert.deepEqual(Array.from(store._dataMap.values()), g.dump.values.map((v) => (g.type === 'float32' ? Math.fround(Number(v)) : Number(v))));
+      const mine = store.serialize();
+      assert.deepEqual(wire.fromBuffer(mine), wire.fromBuffer(bytes(g.blob)));
+      // byte-identical too, except that a NaN default's payload bits are whatever V8 held (not observable in JS)
+      if (key === 'store') assert.equal(Buffer.from(mine).toString('base64'), g.blob, `${key}: byte-identical blob`);
+      else assert.equal(mine.byteLength, bytes(g.blob).byteLength);
+    }
+  });
+  it('cube round trip, 50 x 50 x 13 cells', () => {
+    const items = [];
+    for (let i = 0; i < 50; ++i) items.push(i.toString());
+    const cube = new Cube([new GenericDimension('dim1', 'root', items), new GenericDimension('dim2', 'root', items), new TimeDimension('time', 'month', '2010-01', '2011-01')]);
+    cube.createStoredMeasure('main', { time: 'average' }, 'float32', 0);
+    cube.setData('main', Array.from({ length: 50 * 50 * 13 }).map((_v, i) => (i % 7 === 0 ? 0 : 30 + (i % 5))));
+    const copy = Cube.deserialize(cube.serialize());
+    assert.deepEqual(copy.getNestedObject('main'), cube.getNestedObject('main'));
+    assert.deepEqual(copy.storedMeasuresRules, cube.storedMeasuresRules);
+    assert.deepEqual(Cube.deserializeFromBase64String(cube.serializeToBase64String()).getData('main'), cube.getData('main'));
+    assert.deepEqual(copy.drillUp('time', 'year').getData('main'), cube.drillUp('time', 'year').getData('main'));
+  });
+});
+
 describe('BASELINE config 1 through the Cube API', () => {
   it('[10,10,10] drillUp(dimension0, all) equals the reference output', () => {
     const golden = JSON.parse(fs.readFileSync(path.join(__dirname, '..', 'golden', 'configs.json'), 'utf8')).cases.find((c) => c.name === 'config1_10x10x10_dim0');

@@ -167,6 +167,44 @@ describe('formatters', () => {
   });
 });
 
+describe('wire format (interoperability with blobs written by the reference)', () => {
+  const fs = require('fs');
+  const path = require('path');
+  const { wire } = require('../../olap-in-memory_amd/js');
+  const golden = JSON.parse(fs.readFileSync(path.join(__dirname, '..', 'golden', 'wire.json'), 'utf8')).cases;
+  const bytes = (b64) => wire.toArrayBuffer(Buffer.from(b64, 'base64'));
+  const same = (ab, b64) => Buffer.from(ab).toString('base64') === b64;
+
+  it('decodes and re-encodes the reference bytes of a mixed value', () => {
+    const value = wire.fromBuffer(bytes(golden.primitives));
+    assert.deepEqual(value, [Number.NaN, 32, new Int32Array([255]), 'totot', new Float32Array([666]), { toto: { tata: new Float32Array([666]) } }, null, true, [1.5, 'é']]);
+    assert.ok(same(wire.toBuffer(value), golden.primitives), 'encoder output is byte-identical to the reference');
+  });
+
+  it('reads a GenericDimension written by the reference and writes the same bytes back', () => {
+    const g = golden.genericDimension;
+    const dim = GenericDimension.deserialize(bytes(g.blob));
+    assert.equal(dim.id, g.id);
+    assert.equal(dim.rootAttribute, g.rootAttribute);
+    assert.equal(dim.label, g.label);
+    assert.deepEqual(dim.attributes, g.attributes);
+    for (const attr of Object.keys(g.items)) assert.deepEqual(dim.getItems(attr), g.items[attr]);
+    assert.deepEqual(Array.from(dim.getGroupIndexFromRootIndexMap('continent')), g.continentMap);
+    assert.deepEqual(dim.getEntries(), [['paris', 'Paris'], ['toledo', 'Toledo'], ['tokyo', 'Tokyo']]);
+    assert.ok(same(dim.serialize(), g.blob), 'GenericDimension.serialize() is byte-identical to the reference');
+    const own = new GenericDimension('location', 'city', ['paris', 'toledo', 'tokyo'], 'Location', { paris: 'Paris', toledo: 'Toledo', tokyo: 'Tokyo' });
+    own.addAttribute('city', 'continent', { paris: 'europe', toledo: 'europe', tokyo: 'asia' });
+    assert.ok(same(own.serialize(), g.blob));
+  });
+
+  it('TimeDimension round trip', () => {
+    const t = new TimeDimension('time', 'month', '2009-12', '2010-02');
+    const back = TimeDimension.deserialize(t.serialize());
+    assert.deepEqual(back.getItems(), t.getItems());
+    assert.deepEqual(back.getItems('quarter'), t.getItems('quarter'));
+  });
+});
+
 describe('errors raised before any device work', () => {
   it('store constructor', () => {
     assert.throws(() => new HipStore(4, 'float32', 1), /Invalid default value, only NaN and 0 are supported/);

@@ -392,3 +392,21 @@ def test_reduce_regime_shapes(lens, axis, method):
     out = g.drill_up(lens, new, maps, method)
     assert np.array_equal(out.get_status(), es)
     assert same_typed(out.get_data(), ev)
+
+
+@pytest.mark.parametrize("type_name,default", [("float32", 0.0), ("float32", float("nan")), ("uint32", float("nan")), ("float64", 0.0), ("int32", 0.0)])
+def test_sparse_form_round_trip(type_name, default):
+    """Device-side stream compaction (the reference's serialised layout, in-memory.js:94-100) and back."""
+    rng = np.random.default_rng(3)
+    for n in (0, 1, 63, 64, 65, 1000, 300_001):
+        vals = rng.integers(1, 100, size=n).astype(np.float64)
+        unset = rng.random(n) < 0.6
+        dense = np.where(unset, default, vals)
+        s = pkg.HipStore(n, type_name, default)
+        s.set_data_f64(dense)
+        idx, v = s.to_sparse()
+        keep = np.nonzero(~unset)[0]
+        assert np.array_equal(idx, keep.astype(np.uint32))
+        assert np.array_equal(v.astype(np.float64), vals[keep])
+        back = pkg.HipStore.from_sparse(n, type_name, default, idx, v)
+        assert same_typed(back.get_data(), s.get_data()) and np.array_equal(back.get_status(), s.get_status())
