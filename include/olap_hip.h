@@ -180,6 +180,20 @@ int olap_fill_seeded(void *values, int32_t *status, uint64_t n, uint64_t first_c
  * values[i] / (counts[i] mod 65536) : values[i]; out_status (optional) gets the mask. */
 int olap_average_finish(void *values, const int32_t *counts, int32_t *out_status, uint64_t n,
                         int dtype, int default_kind, void *stream);
+/* Computed measures (src/cube.js:326-363: one formula evaluated per cell over the stored measures'
+ * getValue(i)), as an element-wise interpreter on the device.  `code` is a postfix program
+ * (opcodes: olap-in-memory_amd/js/formula.js OP / csrc FormulaOp; CONST k, INPUT i and SCALAR j
+ * carry one operand word), at most OLAP_FORMULA_MAX_CODE words, OLAP_FORMULA_MAX_CONSTS constants,
+ * OLAP_FORMULA_MAX_INPUTS input measures (device buffers of n cells each; status may be NULL per
+ * input) and as many scalars (`<measure>__total` parameters).  out_f64: n float64 results. */
+#define OLAP_FORMULA_MAX_CODE 96
+#define OLAP_FORMULA_MAX_CONSTS 24
+#define OLAP_FORMULA_MAX_INPUTS 8
+#define OLAP_FORMULA_MAX_STACK 16
+int olap_eval_formula(const int32_t *code, int n_code, const double *consts, int n_consts, int n_inputs,
+                      const void *const *in_values, const int32_t *const *in_status, const int *in_dtypes,
+                      const int *in_defaults, const double *scalars, int n_scalars, double *out_f64,
+                      uint64_t n, void *stream);
 /* `total` getter (in-memory.js:22-28): float64 sum of the set cells, and their count.
  * Synchronises `stream`. */
 int olap_total(const void *values, const int32_t *status, uint64_t n, int dtype, int default_kind,
@@ -230,6 +244,11 @@ int olap_store_to_sparse(const olap_store *store, uint32_t *host_indexes, void *
  * given (TypedArray of the store's dtype); setValue semantics apply (a default value unsets). */
 int olap_store_from_sparse(olap_store **store, uint64_t size, int dtype, int default_kind,
                            const uint32_t *host_indexes, const void *host_values, uint64_t n);
+
+/* olap_eval_formula over stores (all of the same size) into a host float64 array */
+int olap_store_eval_formula(const int32_t *code, int n_code, const double *consts, int n_consts, int n_inputs,
+                            const olap_store *const *inputs, const double *scalars, int n_scalars,
+                            double *host_out);
 
 /* The five bulk operations; each returns a NEW store (load mutates `store`). */
 int olap_store_drillup(const olap_store *store, olap_store **out, int ndim, const uint32_t *old_len,

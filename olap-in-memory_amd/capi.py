@@ -67,6 +67,8 @@ SIGNATURES = {
     "olap_convert_to_f64": (_i32, [_vp, _vp, _u64, _i32, _vp]),
     "olap_fill_seeded": (_i32, [_vp, _vp, _u64, _u64, _i32, C.c_uint32, _dbl, _vp]),
     "olap_average_finish": (_i32, [_vp, _vp, _vp, _u64, _i32, _i32, _vp]),
+    "olap_eval_formula": (_i32, [_pi32, _i32, _pdbl, _i32, _i32, _pvp, _pvp, C.POINTER(C.c_int), C.POINTER(C.c_int), _pdbl, _i32, _vp, _u64, _vp]),
+    "olap_store_eval_formula": (_i32, [_pi32, _i32, _pdbl, _i32, _i32, _pvp, _pdbl, _i32, _pdbl]),
     "olap_total": (_i32, [_vp, _vp, _u64, _i32, _i32, _pdbl, _pu64, _vp]),
     "olap_store_create": (_i32, [_pvp, _u64, _i32, _i32]),
     "olap_store_destroy": (None, [_vp]),

@@ -138,6 +138,7 @@ struct olap_plan {
   bool dd_two_pass = false;                // float cells, no distributions: scale + broadcast
   void *dev_tab2 = nullptr;                // second table set (two-pass drillDown)
   void *dev_tmp = nullptr;                 // quotients of the two-pass drillDown (old cells)
+  std::vector<void *> owned;               // further device allocations freed with the plan
   void *dev_tab = nullptr;                 // index tables
   double *dev_dist = nullptr;              // drillDown distributions
   unsigned long long *dev_err = nullptr;   // drillDown deferred error word
@@ -182,6 +183,7 @@ static int vec_for(int dtype, uint64_t contiguous) {
 
 extern "C" void olap_plan_destroy(olap_plan *p) {
   if (!p) return;
+  for (void *q : p->owned) (void)hipFree(q);
   if (p->dev_tab) (void)hipFree(p->dev_tab);
   if (p->dev_tab2) (void)hipFree(p->dev_tab2);
   if (p->dev_tmp) (void)hipFree(p->dev_tmp);
@@ -987,7 +989,7 @@ extern "C" int olap_drilldown_plan(olap_plan **out, int dtype, int default_kind,
       olap_plan_destroy(p);
       return hip_fail(e, "hipMalloc(drillDown quotients)");
     }
-    p->dev_dist = (double *)cnt;  // owned: freed with the plan (distributions are absent on this path)
+    p->owned.push_back(cnt);
   }
   a.total = p->out_cells;
   a.def_nan = p->def_nan;
@@ -1202,6 +1204,72 @@ extern "C" int olap_average_finish(void *values, const int32_t *counts, int32_t 
   hipError_t e = hipSuccess;
   DISPATCH_DTYPE(dtype, e = Launch<T>::average_finish((T *)values, counts, out_status, n, default_kind == OLAP_DEFAULT_NAN, (hipStream_t)stream));
   if (e != hipSuccess) return hip_fail(e, "average_finish");
+  return OLAP_OK;
+}
+
+// ---- computed measures --------------------------------------------------------------------------
+// the kernel is not templated: it lives in this translation unit
+static int check_formula(const int32_t *code, int n_code, int n_consts, int n_inputs, int n_scalars) {
+  if (!code || n_code <= 0 || n_code > OLAP_FORMULA_MAX_CODE) return fail(OLAP_ERR_INVALID_ARGUMENT, "formula program has %d words (1..%d allowed)", n_code, OLAP_FORMULA_MAX_CODE);
+  if (n_consts < 0 || n_consts > OLAP_FORMULA_MAX_CONSTS || n_inputs < 0 || n_inputs > OLAP_FORMULA_MAX_INPUTS || n_scalars < 0 ||
+      n_scalars > OLAP_FORMULA_MAX_INPUTS)
+    return fail(OLAP_ERR_INVALID_ARGUMENT, "formula uses too many constants / measures / totals");
+  int depth = 0;
+  for (int pc = 0; pc < n_code; ++pc) {
+    const int op = code[pc];
+    if (op == F_CONST || op == F_INPUT || op == F_SCALAR) {
+      if (pc + 1 >= n_code) return fail(OLAP_ERR_INVALID_ARGUMENT, "formula program truncated");
+      const int k = code[++pc];
+      const int lim = op == F_CONST ? n_consts : (op == F_INPUT ? n_inputs : n_scalars);
+      if (k < 0 || k >= lim) return fail(OLAP_ERR_INDEX_RANGE, "formula operand %d out of range", k);
+      ++depth;
+    } else if (op == F_SELECT) {
+      if (depth < 3) return fail(OLAP_ERR_INVALID_ARGUMENT, "formula program underflows its stack");
+      depth -= 2;
+    } else if (op == F_NEG || op == F_ISNAN || (op >= F_ABS && op <= F_NOT)) {
+      if (depth < 1) return fail(OLAP_ERR_INVALID_ARGUMENT, "formula program underflows its stack");
+    } else if (op >= F_ADD && op <= F_ROUNDTO) {
+      if (depth < 2) return fail(OLAP_ERR_INVALID_ARGUMENT, "formula program underflows its stack");
+      --depth;
+    } else {
+      return fail(OLAP_ERR_INVALID_ARGUMENT, "unknown formula opcode %d", op);
+    }
+    if (depth > OLAP_FORMULA_MAX_STACK) return fail(OLAP_ERR_INVALID_ARGUMENT, "formula needs a stack deeper than %d", OLAP_FORMULA_MAX_STACK);
+  }
+  if (depth != 1) return fail(OLAP_ERR_INVALID_ARGUMENT, "formula program leaves %d values on its stack", depth);
+  return OLAP_OK;
+}
+
+extern "C" int olap_eval_formula(const int32_t *code, int n_code, const double *consts, int n_consts, int n_inputs,
+                                 const void *const *in_values, const int32_t *const *in_status, const int *in_dtypes,
+                                 const int *in_defaults, const double *scalars, int n_scalars, double *out_f64,
+                                 uint64_t n, void *stream) {
+  int rc = check_formula(code, n_code, n_consts, n_inputs, n_scalars);
+  if (rc) return rc;
+  if ((n_consts && !consts) || (n_scalars && !scalars) || (n_inputs && (!in_values || !in_dtypes || !in_defaults)))
+    return fail(OLAP_ERR_INVALID_ARGUMENT, "formula argument arrays must not be NULL");
+  for (int k = 0; k < n_inputs; ++k) {
+    if ((rc = check_dtype(in_dtypes[k])) || (rc = check_default(in_defaults[k]))) return rc;
+    if (n && !in_values[k]) return fail(OLAP_ERR_INVALID_ARGUMENT, "formula input %d is NULL", k);
+  }
+  if (n && !out_f64) return fail(OLAP_ERR_INVALID_ARGUMENT, "out is NULL");
+  if ((rc = require_device())) return rc;
+  if (n == 0) return OLAP_OK;
+  FormulaProgram p{};
+  p.n_code = n_code;
+  memcpy(p.code, code, n_code * sizeof(int32_t));
+  if (n_consts) memcpy(p.consts, consts, n_consts * sizeof(double));
+  p.n_inputs = n_inputs;
+  for (int k = 0; k < n_inputs; ++k) {
+    p.in_values[k] = in_values[k];
+    p.in_status[k] = in_status ? in_status[k] : nullptr;
+    p.in_dtype[k] = in_dtypes[k];
+    p.in_def_nan[k] = in_defaults[k] == OLAP_DEFAULT_NAN;
+  }
+  for (int k = 0; k < n_scalars; ++k) p.scalars[k] = scalars[k];
+  hipLaunchKernelGGL(eval_formula_kernel<OLAP_FORMULA_MAX_STACK>, grid_stride_for(n), kBlock, 0, (hipStream_t)stream, p, out_f64, n);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return hip_fail(e, "eval_formula");
   return OLAP_OK;
 }
 
@@ -1519,6 +1587,37 @@ extern "C" int olap_store_fill(olap_store *s, double value) {
 extern "C" int olap_store_total(const olap_store *s, double *total) {
   if (!s || !total) return fail(OLAP_ERR_INVALID_ARGUMENT, "store is NULL");
   return olap_total(s->values, s->status, s->size, s->dtype, s->default_kind, total, nullptr, nullptr);
+}
+
+extern "C" int olap_store_eval_formula(const int32_t *code, int n_code, const double *consts, int n_consts, int n_inputs,
+                                       const olap_store *const *inputs, const double *scalars, int n_scalars,
+                                       double *host_out) {
+  int rc = check_formula(code, n_code, n_consts, n_inputs, n_scalars);
+  if (rc) return rc;
+  if (n_inputs <= 0 || !inputs) return fail(OLAP_ERR_INVALID_ARGUMENT, "a formula needs at least one stored measure to size its result");
+  const void *vals[OLAP_FORMULA_MAX_INPUTS];
+  const int32_t *stat[OLAP_FORMULA_MAX_INPUTS];
+  int dtypes[OLAP_FORMULA_MAX_INPUTS], defs[OLAP_FORMULA_MAX_INPUTS];
+  const uint64_t n = inputs[0] ? inputs[0]->size : 0;
+  for (int k = 0; k < n_inputs; ++k) {
+    if (!inputs[k]) return fail(OLAP_ERR_INVALID_ARGUMENT, "formula input %d is NULL", k);
+    if (inputs[k]->size != n) return fail(OLAP_ERR_LENGTH_MISMATCH, "formula inputs have different sizes");
+    vals[k] = inputs[k]->values;
+    stat[k] = mask_is_primary(inputs[k]) ? inputs[k]->status : nullptr;
+    dtypes[k] = inputs[k]->dtype;
+    defs[k] = inputs[k]->default_kind;
+  }
+  if (n && !host_out) return fail(OLAP_ERR_INVALID_ARGUMENT, "out is NULL");
+  if (n == 0) return OLAP_OK;
+  double *dev = nullptr;
+  HIP_TRY(hipMalloc((void **)&dev, n * sizeof(double)));
+  rc = olap_eval_formula(code, n_code, consts, n_consts, n_inputs, vals, stat, dtypes, defs, scalars, n_scalars, dev, n, nullptr);
+  hipError_t e = hipSuccess;
+  if (!rc) e = hipMemcpy(host_out, dev, n * sizeof(double), hipMemcpyDeviceToHost);
+  (void)hipFree(dev);
+  if (rc) return rc;
+  if (e != hipSuccess) return hip_fail(e, "store_eval_formula");
+  return OLAP_OK;
 }
 
 // ---- sparse form (the reference's serialised layout, in-memory.js:75-116) ------------------------

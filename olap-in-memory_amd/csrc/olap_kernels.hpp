@@ -1243,6 +1243,112 @@ __global__ void set_cell_kernel(T *values, int32_t *status, uint64_t index, doub
   if (status) status[index] = os;
 }
 
+// ======================================================================= computed measures
+// Element-wise postfix interpreter ("next" row f4).  Opcodes mirror olap-in-memory_amd/js/formula.js.
+enum FormulaOp {
+  F_CONST = 0, F_INPUT = 1, F_SCALAR = 2, F_ADD = 3, F_SUB = 4, F_MUL = 5, F_DIV = 6, F_MOD = 7, F_POW = 8, F_NEG = 9,
+  F_NANADD = 10, F_SELECT = 11, F_MIN = 12, F_MAX = 13, F_ATAN2 = 14, F_HYPOT = 15, F_ROUNDTO = 16, F_ISNAN = 17,
+  F_ABS = 20, F_CEIL = 21, F_FLOOR = 22, F_ROUND = 23, F_TRUNC = 24, F_SQRT = 25, F_CBRT = 26, F_EXP = 27, F_LN = 28,
+  F_LOG10 = 29, F_LOG2 = 30, F_SIGN = 31, F_SIN = 32, F_COS = 33, F_TAN = 34, F_ASIN = 35, F_ACOS = 36, F_ATAN = 37, F_NOT = 38
+};
+
+struct FormulaProgram {
+  int n_code;
+  int32_t code[OLAP_FORMULA_MAX_CODE];
+  double consts[OLAP_FORMULA_MAX_CONSTS];
+  int n_inputs;
+  const void *in_values[OLAP_FORMULA_MAX_INPUTS];
+  const int32_t *in_status[OLAP_FORMULA_MAX_INPUTS];
+  int in_dtype[OLAP_FORMULA_MAX_INPUTS];
+  int in_def_nan[OLAP_FORMULA_MAX_INPUTS];
+  double scalars[OLAP_FORMULA_MAX_INPUTS];
+};
+
+__device__ __forceinline__ bool js_truthy(double v) { return v == v && v != 0.0; }
+__device__ __forceinline__ double js_round(double v) { return floor(v + 0.5); }  // Math.round: halves go up
+
+template <int STACK>  // a template only so that the header may be included by several translation units
+__global__ __launch_bounds__(kBlock) void eval_formula_kernel(const FormulaProgram p, double *__restrict__ out, uint64_t n) {
+  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kBlock) {
+    double st[STACK];
+    int sp = 0;
+    for (int pc = 0; pc < p.n_code; ++pc) {
+      const int op = p.code[pc];
+      if (op == F_CONST) {
+        st[sp++] = p.consts[p.code[++pc]];
+      } else if (op == F_INPUT) {
+        const int k = p.code[++pc];
+        double v;
+        switch (p.in_dtype[k]) {  // getValue(i): the stored value, or the default where unset
+          case OLAP_INT32: v = (double)((const int32_t *)p.in_values[k])[i]; break;
+          case OLAP_UINT32: v = (double)((const uint32_t *)p.in_values[k])[i]; break;
+          case OLAP_FLOAT32: v = (double)((const float *)p.in_values[k])[i]; break;
+          default: v = ((const double *)p.in_values[k])[i]; break;
+        }
+        if (p.in_status[k] && !(p.in_status[k][i] & OLAP_STATUS_SET)) v = p.in_def_nan[k] ? __builtin_nan("") : 0.0;
+        st[sp++] = v;
+      } else if (op == F_SCALAR) {
+        st[sp++] = p.scalars[p.code[++pc]];
+      } else if (op == F_SELECT) {
+        const double c = st[sp - 3], a = st[sp - 2], b = st[sp - 1];
+        sp -= 2;
+        st[sp - 1] = js_truthy(c) ? a : b;
+      } else if (op == F_NEG || op == F_ISNAN || op >= F_ABS) {
+        const double a = st[sp - 1];
+        double r;
+        switch (op) {
+          case F_NEG: r = -a; break;
+          case F_ISNAN: r = (a != a) ? 1.0 : 0.0; break;
+          case F_ABS: r = fabs(a); break;
+          case F_CEIL: r = ceil(a); break;
+          case F_FLOOR: r = floor(a); break;
+          case F_ROUND: r = js_round(a); break;
+          case F_TRUNC: r = trunc(a); break;
+          case F_SQRT: r = sqrt(a); break;
+          case F_CBRT: r = cbrt(a); break;
+          case F_EXP: r = exp(a); break;
+          case F_LN: r = log(a); break;
+          case F_LOG10: r = log10(a); break;
+          case F_LOG2: r = log2(a); break;
+          case F_SIGN: r = (a != a) ? a : (a > 0.0 ? 1.0 : (a < 0.0 ? -1.0 : a)); break;
+          case F_SIN: r = sin(a); break;
+          case F_COS: r = cos(a); break;
+          case F_TAN: r = tan(a); break;
+          case F_ASIN: r = asin(a); break;
+          case F_ACOS: r = acos(a); break;
+          case F_ATAN: r = atan(a); break;
+          default: r = js_truthy(a) ? 0.0 : 1.0; break;  // F_NOT
+        }
+        st[sp - 1] = r;
+      } else {
+        const double a = st[sp - 2], b = st[sp - 1];
+        --sp;
+        double r;
+        switch (op) {
+          case F_ADD: r = a + b; break;
+          case F_SUB: r = a - b; break;
+          case F_MUL: r = a * b; break;
+          case F_DIV: r = a / b; break;
+          case F_MOD: r = fmod(a, b); break;
+          case F_POW: r = pow(a, b); break;
+          case F_NANADD: r = (a != a && b == b) ? b : ((a == a && b != b) ? a : a + b); break;  // src/parser.js:18-23
+          case F_MIN: r = js_min(a, b); break;
+          case F_MAX: r = js_max(a, b); break;
+          case F_ATAN2: r = atan2(a, b); break;
+          case F_HYPOT: r = hypot(a, b); break;
+          default: {  // F_ROUNDTO
+            const double f = pow(10.0, trunc(b));
+            r = js_round(a * f) / f;
+            break;
+          }
+        }
+        st[sp - 1] = r;
+      }
+    }
+    out[i] = sp > 0 ? st[sp - 1] : __builtin_nan("");
+  }
+}
+
 // ======================================================================= sparse <-> dense
 // Stream compaction of the set cells (ascending), for the reference's wire format: each workgroup
 // owns a contiguous chunk; pass 1 counts, the host prefix-sums the (few thousand) chunk counts,

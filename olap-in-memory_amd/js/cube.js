@@ -12,14 +12,17 @@
  *     addDimension / removeDimension which deep-copy the rules (:931, :957);
  *   - removeDimension = drillUp(id, 'all') with the dimension dropped from the list (:950-964);
  *   - slice = dice + removeDimension (:799-807); collapse = slice every dimension to 'all' (:320-324).
- * Outside the accelerated path and therefore not provided: computed measures (expr-eval
- * formulas); they throw a descriptive Error.  (De)serialisation uses the reference's container.
+ * Computed measures use ./formula.js (own parser for the arithmetic subset of expr-eval the
+ * reference enables) and are evaluated by one element-wise device launch; (de)serialisation uses
+ * the reference's container (./wire.js).
  */
 const HipStore = require('./store/hip');
 const CatchAllDimension = require('./dimension/catch-all');
 const TimeSlot = require('./calendar');
 const { toNestedArray, fromNestedArray, toNestedObject, fromNestedObject } = require('./formatter');
 const { toBuffer, fromBuffer, toArrayBuffer } = require('./wire');
+const { getParser } = require('./formula');
+const backend = require('./backend');
 
 const MEASURE_ID = /^[a-z][_a-z0-9]+$|^[_a-z0-9]+__total$/i;
 const OUT_OF_SCOPE = (what) => new Error(`${what} is outside the accelerated aggregation path of olap-in-memory_amd (DESIGN.md §7)`);
@@ -93,8 +96,72 @@ class Cube {
     this.storedMeasuresRules[measureId] = rules;
   }
 
-  createComputedMeasure() {
-    throw OUT_OF_SCOPE('createComputedMeasure (expr-eval formulas)');
+  /**
+   * A measure defined by a formula over stored measures (and `<measure>__total`), evaluated per
+   * cell on demand (src/cube.js:97-140).  Formulas naming other computed measures are inlined.
+   */
+  createComputedMeasure(measureId, formula) {
+    if (!MEASURE_ID.test(measureId)) throw new Error(`Invalid measureId: ${measureId}`);
+    if (this.storedMeasures[measureId] !== undefined || this.computedMeasures[measureId] !== undefined) throw new Error(`This measure already exists ${measureId}`);
+    let text = formula;
+    for (const id of this.computedMeasureIds) {
+      const whole = new RegExp(`\\b${id}\\b`, 'g');
+      if (text.match(whole)) text = text.replace(whole, `(${this.computedMeasures[id].toString()})`);
+    }
+    const expression = getParser().parse(text);
+    const known = this.storedMeasureIds.concat(this.storedMeasureIds.map((m) => `${m}__total`));
+    const variables = expression.variables({ withMembers: true });
+    if (!variables.every((v) => known.includes(v))) throw new Error(`Unknown measure(s): ${variables.filter((v) => !this.storedMeasureIds.includes(v))}`);
+    this.computedMeasures[measureId] = expression;
+  }
+
+  copyToStoredMeasure(computedMeasureId, storedMeasureId, rules = {}, type = 'float32', defaultValue = 0) {
+    const data = this.getData(computedMeasureId);
+    this.createStoredMeasure(storedMeasureId, rules, type, defaultValue);
+    this.setData(storedMeasureId, data);
+  }
+
+  convertToStoredMeasure(measureId, rules = {}, type = 'float32', defaultValue = 0) {
+    if (!this.computedMeasures[measureId]) throw new Error(`convertToStoredMeasure: no such computed measure: ${measureId}`);
+    const data = this.getData(measureId);
+    this.dropMeasure(measureId);
+    this.createStoredMeasure(measureId, rules, type, defaultValue);
+    this.setData(measureId, data);
+  }
+
+  replaceStoredMeasure(toKeep, toDrop) {
+    for (const id of [toKeep, toDrop]) if (this.storedMeasures[id] === undefined) throw new Error(`replaceStoredMeasure: no such measure ${id}`);
+    for (const id of this.computedMeasureIds) {
+      const expression = this.computedMeasures[id];
+      if (expression.variables().includes(toDrop)) this.computedMeasures[id] = expression.substitute(toDrop, toKeep);
+    }
+    this.dropMeasure(toDrop);
+  }
+
+  /** One device launch evaluates the formula for every cell (olap_eval_formula). */
+  _evaluateComputed(measureId) {
+    const expression = this.computedMeasures[measureId];
+    const inputs = {};
+    const scalars = {};
+    const stores = [];
+    const totals = [];
+    for (const name of expression.variables({ withMembers: true })) {
+      if (name.includes('__total')) {
+        scalars[name] = totals.push(this.storedMeasures[name.replace('__total', '')].total) - 1;
+      } else {
+        inputs[name] = stores.push(this.storedMeasures[name]._native) - 1;
+      }
+    }
+    if (stores.length === 0) {
+      // a formula of constants / totals only: nothing to stream, evaluate once on the host
+      const params = {};
+      Object.keys(scalars).forEach((name) => {
+        params[name] = totals[scalars[name]];
+      });
+      return new Array(this.storeSize).fill(expression.evaluate(params));
+    }
+    const program = expression.compile(inputs, scalars);
+    return Array.from(backend.load().evalFormula(program.code, program.consts, stores, Float64Array.from(totals)));
   }
 
   copyStoredMeasure(measureId, copyMeasureId) {
@@ -116,17 +183,31 @@ class Cube {
   renameMeasure(oldMeasureId, newMeasureId) {
     // eslint-disable-next-line eqeqeq
     if (oldMeasureId == newMeasureId) return;
+    if (this.computedMeasures[oldMeasureId]) {
+      this.computedMeasures[newMeasureId] = this.computedMeasures[oldMeasureId];
+      delete this.computedMeasures[oldMeasureId];
+      return;
+    }
     if (!this.storedMeasures[oldMeasureId]) throw new Error(`renameMeasure: no such measure ${oldMeasureId} -> ${newMeasureId}`);
     this.storedMeasures[newMeasureId] = this.storedMeasures[oldMeasureId];
     this.storedMeasuresRules[newMeasureId] = this.storedMeasuresRules[oldMeasureId];
     delete this.storedMeasures[oldMeasureId];
     delete this.storedMeasuresRules[oldMeasureId];
+    for (const id of this.computedMeasureIds) {
+      const expression = this.computedMeasures[id];
+      if (expression.variables().includes(oldMeasureId)) this.computedMeasures[id] = expression.substitute(oldMeasureId, newMeasureId);
+    }
   }
 
   dropMeasure(measureId) {
+    if (this.computedMeasures[measureId] !== undefined) {
+      delete this.computedMeasures[measureId];
+      return;
+    }
     if (this.storedMeasures[measureId] === undefined) throw new Error(`dropMeasure: no such measure: ${measureId}`);
     delete this.storedMeasures[measureId];
     delete this.storedMeasuresRules[measureId];
+    for (const id of this.computedMeasureIds) if (this.computedMeasures[id].variables().includes(measureId)) delete this.computedMeasures[id];
   }
 
   dropMeasures(measureIds) {
@@ -138,7 +219,9 @@ class Cube {
   }
 
   keepMeasures(measureIds) {
-    this.storedMeasureIds.filter((id) => !measureIds.includes(id)).forEach((id) => this.dropMeasure(id));
+    this.computedMeasureIds.concat(this.storedMeasureIds).filter((id) => !measureIds.includes(id)).forEach((id) => {
+      if (this.computedMeasures[id] !== undefined || this.storedMeasures[id] !== undefined) this.dropMeasure(id);
+    });
   }
 
   updateStoredMeasureRules(measureId, cb) {
@@ -149,6 +232,7 @@ class Cube {
     // dimension objects are immutable for every query, so the copy may share them
     const copy = new Cube(this.dimensions.slice());
     const wanted = (id) => measures.length === 0 || measures.includes(id);
+    for (const id of this.computedMeasureIds.filter(wanted)) copy.computedMeasures[id] = this.computedMeasures[id];
     for (const id of this.storedMeasureIds.filter(wanted)) {
       copy.storedMeasures[id] = this.storedMeasures[id].clone();
       copy.storedMeasuresRules[id] = deepCopy(this.storedMeasuresRules[id]);
@@ -164,11 +248,18 @@ class Cube {
   }
 
   getData(measureId) {
+    if (this.computedMeasures[measureId] !== undefined && this.storedMeasures[measureId] === undefined) return this._evaluateComputed(measureId);
     return this._store(measureId, 'getData').data;
   }
 
   getStatusMap(measureId) {
-    return this._store(measureId, 'getStatusMap')._dataMap;
+    if (this.storedMeasures[measureId] !== undefined) return this.storedMeasures[measureId]._dataMap;
+    if (this.computedMeasures[measureId] === undefined) throw new Error(`getStatusMap: no such measure ${measureId}`);
+    // src/cube.js:373-386: the union of every stored measure's keys, values OR-ed together
+    const result = new Map();
+    for (const store of Object.values(this.storedMeasures))
+      for (const [key, value] of store._dataMap.entries()) result.set(key, result.get(key) ? result.get(key) | value : value);
+    return result;
   }
 
   getTotal(measureId) {
@@ -264,7 +355,12 @@ class Cube {
   getSingleData(measureId, coords) {
     this._checkCoords('getSingleData', coords);
     const position = this.getPosition(coords);
-    return this._store(measureId, 'getSingleData').getValue(position);
+    if (this.storedMeasures[measureId] !== undefined) return this.storedMeasures[measureId].getValue(position);
+    if (this.computedMeasures[measureId] === undefined) throw new Error(`getSingleData: no such measure ${measureId}`);
+    const expression = this.computedMeasures[measureId];
+    const params = {};
+    for (const name of expression.variables({ withMembers: true })) params[name] = this.storedMeasures[name].getValue(position);
+    return expression.evaluate(params);
   }
 
   _combinations(dimensionsFilter) {
@@ -513,7 +609,10 @@ class Cube {
       storedMeasuresKeys: this.storedMeasureIds,
       storedMeasures: Object.values(this.storedMeasures).map((store) => store.serialize()),
       storedMeasuresRules: this.storedMeasuresRules,
-      computedMeasures: {},
+      computedMeasures: this.computedMeasureIds.reduce((out, id) => {
+        out[id] = this.computedMeasures[id].toString();
+        return out;
+      }, {}),
     });
   }
 
@@ -525,14 +624,13 @@ class Cube {
     const GenericDimension = require('./dimension/generic');
     const TimeDimension = require('./dimension/time');
     const data = fromBuffer(buffer);
-    if (data.computedMeasures && Object.keys(data.computedMeasures).length)
-      throw OUT_OF_SCOPE('deserialising computed measures (expr-eval formulas)');
     // a time dimension's record carries `start` (src/dimension/factory.js:6-12)
     const cube = new Cube(data.dimensions.map((blob) => (fromBuffer(blob).start ? TimeDimension.deserialize(blob) : GenericDimension.deserialize(blob))));
     cube.storedMeasuresRules = data.storedMeasuresRules || {};
     data.storedMeasuresKeys.forEach((id, i) => {
       cube.storedMeasures[id] = HipStore.deserialize(data.storedMeasures[i]);
     });
+    for (const id of Object.keys(data.computedMeasures || {})) cube.computedMeasures[id] = getParser().parse(data.computedMeasures[id]);
     return cube;
   }
 

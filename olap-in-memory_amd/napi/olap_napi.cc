@@ -466,6 +466,42 @@ static napi_value StoreLoad(napi_env env, napi_callback_info info) {
   return nullptr;
 }
 
+// evalFormula(code: Int32Array, consts: Float64Array, stores: Store[], scalars: Float64Array) -> Float64Array
+static napi_value EvalFormula(napi_env env, napi_callback_info info) {
+  size_t argc = 4;
+  napi_value argv[4];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+  if (argc < 4) return bad_args(env, "evalFormula(code, consts, stores, scalars)");
+  napi_typedarray_type t;
+  size_t n_code = 0, n_consts = 0, n_scalars = 0;
+  void *code = nullptr, *consts = nullptr, *scalars = nullptr;
+  if (napi_get_typedarray_info(env, argv[0], &t, &n_code, &code, nullptr, nullptr) != napi_ok || t != napi_int32_array ||
+      napi_get_typedarray_info(env, argv[1], &t, &n_consts, &consts, nullptr, nullptr) != napi_ok || t != napi_float64_array ||
+      napi_get_typedarray_info(env, argv[3], &t, &n_scalars, &scalars, nullptr, nullptr) != napi_ok || t != napi_float64_array)
+    return bad_args(env, "evalFormula(code: Int32Array, consts: Float64Array, stores: Store[], scalars: Float64Array)");
+  bool is_arr = false;
+  napi_is_array(env, argv[2], &is_arr);
+  if (!is_arr) return bad_args(env, "evalFormula: stores must be an array of Store");
+  uint32_t n_inputs = 0;
+  napi_get_array_length(env, argv[2], &n_inputs);
+  std::vector<const olap_store *> stores(n_inputs);
+  for (uint32_t i = 0; i < n_inputs; ++i) {
+    napi_value e;
+    NAPI_OK(napi_get_element(env, argv[2], i, &e));
+    stores[i] = unwrap(env, e);
+    if (!stores[i]) return nullptr;
+  }
+  const uint64_t n = n_inputs ? olap_store_size(stores[0]) : 0;
+  void *out;
+  napi_value ta = make_ta(env, napi_float64_array, 8, n, &out);
+  if (!ta) return nullptr;
+  static const double zero = 0;
+  int rc = olap_store_eval_formula((const int32_t *)code, (int)n_code, consts ? (const double *)consts : &zero, (int)n_consts, (int)n_inputs,
+                                   stores.data(), scalars ? (const double *)scalars : &zero, (int)n_scalars, (double *)out);
+  if (rc) return throw_olap(env, rc);
+  return ta;
+}
+
 // ---- module functions -------------------------------------------------------------------------
 static napi_value MethodFromName(napi_env env, napi_callback_info info) {
   size_t argc = 1;
@@ -532,6 +568,7 @@ static napi_value Init(napi_env env, napi_value exports) {
   napi_create_reference(env, ctor, 1, &g_store_ctor);
   napi_set_named_property(env, exports, "Store", ctor);
   napi_property_descriptor fns[] = {
+      {"evalFormula", nullptr, EvalFormula, nullptr, nullptr, nullptr, napi_default, nullptr},
       {"storeFromSparse", nullptr, StoreFromSparse, nullptr, nullptr, nullptr, napi_default, nullptr},
       {"methodFromName", nullptr, MethodFromName, nullptr, nullptr, nullptr, napi_default, nullptr},
       {"deviceCount", nullptr, DeviceCount, nullptr, nullptr, nullptr, napi_default, nullptr},

@@ -389,6 +389,97 @@ describe('compose (test/cube-to-cube.js:5-401, stored-measure cases)', () => {
   });
 });
 
+describe('computed measures (formula.js + the device interpreter)', () => {
+  const withComputed = () => {
+    const cube = testCube();
+    cube.createComputedMeasure('router_by_antennas', 'routers / antennas');
+    return cube;
+  };
+  it('evaluates the reference fixture formula per cell', () => {
+    const cube = withComputed();
+    assert.deepEqual(cube.getData('router_by_antennas'), [3 / 1, 2 / 2, 4 / 4, 9 / 8, 16 / 16, 32 / 32]);
+    assert.equal(cube.getSingleData('router_by_antennas', { location: 'toledo', period: 'winter' }), 9 / 8);
+    assert.deepEqual(cube.computedMeasureIds, ['router_by_antennas']);
+    // derived cubes carry the formula and evaluate it on their own (aggregated) cells
+    assert.deepEqual(cube.drillUp('location', 'continent').getNestedArray('router_by_antennas'), [[7 / 5, 11 / 10], [1, 1]]);
+    assert.deepEqual(cube.slice('period', 'season', 'winter').getData('router_by_antennas'), [1, 9 / 8, 1]);
+  });
+  it('totals, inlining of other computed measures, unknown measures', () => {
+    const cube = withComputed();
+    cube.createComputedMeasure('share', 'antennas / antennas__total');
+    assert.deepEqual(cube.getData('share'), [1, 2, 4, 8, 16, 32].map((v) => v / 63));
+    cube.createComputedMeasure('twice', 'router_by_antennas * 2');
+    assert.deepEqual(cube.getData('twice'), [6, 2, 2, 9 / 4, 2, 2]);
+    assert.throws(() => cube.createComputedMeasure('bad', 'antennas + nothing'), /Unknown measure\(s\): nothing/);
+    assert.throws(() => cube.createComputedMeasure('antennas', 'routers'), /This measure already exists antennas/);
+  });
+  it('NaN-coalescing || (test/cube-to-cube.js:355-382)', () => {
+    const t = (a, b) => new TimeDimension('time', 'month', a, b);
+    const c1 = new Cube([t('2010-01', '2010-02')]);
+    c1.createStoredMeasure('antennas', {}, 'float32', NaN_);
+    c1.setNestedArray('antennas', [1, 2]);
+    const c2 = new Cube([t('2010-03', '2010-04')]);
+    c2.createStoredMeasure('routers', {}, 'float32', NaN_);
+    c2.setNestedArray('routers', [3, 2]);
+    const c = c1.compose(c2, true);
+    c.createComputedMeasure('safe_sum', 'antennas + routers');
+    c.createComputedMeasure('unsafe_sum', 'antennas || routers');
+    assert.deepEqual(c.getData('safe_sum'), [NaN_, NaN_, NaN_, NaN_]);
+    assert.deepEqual(c.getData('unsafe_sum'), [1, 2, 3, 2]);
+  });
+  it('rename / drop keep formulas consistent (test/cube-rename.js)', () => {
+    const cube = withComputed();
+    assert.throws(() => cube.renameMeasure('missing', 'missing2'));
+    const a = cube.clone();
+    a.renameMeasure('router_by_antennas', 'router_by_receivers');
+    assert.doesNotThrow(() => a.getData('router_by_receivers'));
+    assert.throws(() => a.getData('router_by_antennas'));
+    const b = cube.clone();
+    b.renameMeasure('antennas', 'receivers');
+    assert.deepEqual(b.getData('router_by_antennas'), cube.getData('router_by_antennas'));
+    assert.throws(() => b.getData('antennas'));
+    b.dropMeasure('receivers');
+    assert.deepEqual(b.computedMeasureIds, []);
+    const c = cube.clone();
+    c.convertToStoredMeasure('router_by_antennas', {}, 'float32', 0);
+    assert.deepEqual(c.storedMeasureIds, ['antennas', 'routers', 'router_by_antennas']);
+    assert.deepEqual(c.getData('router_by_antennas'), [3, 1, 1, 1.125, 1, 1]);
+  });
+  it('device interpreter agrees with the host evaluator on every operator and function', () => {
+    const n = 4096;
+    const cube = new Cube([new GenericDimension('d', 'root', Array.from({ length: n }, (_x, i) => `i${i}`))]);
+    cube.createStoredMeasure('aa', {}, 'float64', NaN_);
+    cube.createStoredMeasure('bb', {}, 'float32', 0);
+    cube.createStoredMeasure('cc', {}, 'int32', NaN_);
+    let seed = 12345;
+    const rnd = () => ((seed = (Math.imul(seed, 1664525) + 1013904223) | 0) >>> 0) / 4294967296;
+    cube.setData('aa', Array.from({ length: n }, () => (rnd() < 0.2 ? NaN_ : (rnd() - 0.5) * 20)));
+    cube.setData('bb', Array.from({ length: n }, () => (rnd() < 0.3 ? 0 : Math.fround(rnd() * 8))));
+    cube.setData('cc', Array.from({ length: n }, () => (rnd() < 0.3 ? NaN_ : Math.floor(rnd() * 21) - 10)));
+    const formulas = ['aa + bb * cc - 2', 'aa / bb', 'cc % 3 + 2 ^ bb', '-aa || bb', 'abs aa + sqrt(bb) + floor(aa / 3) + ceil aa + round(aa) + trunc aa',
+      'min(aa, bb, cc) + max(aa, 1) * hypot(bb, cc)', 'bb ? aa : cc', 'if(isNaN(aa), bb, aa) + not bb', 'exp(bb / 4) + ln(bb + 1) + log10(bb + 1) + log2(bb + 2) + cbrt aa',
+      'sin aa + cos(aa) * tan(bb / 10) + atan2(aa, bb) + asin(bb / 8) + acos(bb / 8) + atan cc', 'sign(aa) * roundTo(aa, 2) + PI * E', 'aa__total + bb__total / cc__total', '(aa + 1) * (bb - 2) / (cc + 0.5) ^ 2'];
+    formulas.forEach((formula, k) => {
+      cube.createComputedMeasure(`f_${k}x`, formula);
+      const device = cube.getData(`f_${k}x`);
+      const expression = cube.computedMeasures[`f_${k}x`];
+      const [A, B, C] = ['aa', 'bb', 'cc'].map((m) => cube.getData(m));
+      const totals = { aa__total: cube.getTotal('aa'), bb__total: cube.getTotal('bb'), cc__total: cube.getTotal('cc') };
+      for (let i = 0; i < n; ++i) {
+        const host = expression.evaluate(Object.assign({ aa: A[i], bb: B[i], cc: C[i] }, totals));
+        const ok = (Number.isNaN(host) && Number.isNaN(device[i])) || host === device[i] || Math.abs(host - device[i]) <= 1e-12 * Math.max(1, Math.abs(host));
+        assert.ok(ok, `${formula} @${i}: host ${host} device ${device[i]} (aa=${A[i]} bb=${B[i]} cc=${C[i]})`);
+      }
+    });
+  });
+  it('formulas survive serialisation', () => {
+    const cube = withComputed();
+    const copy = Cube.deserialize(cube.serialize());
+    assert.deepEqual(copy.computedMeasureIds, ['router_by_antennas']);
+    assert.deepEqual(copy.getData('router_by_antennas'), cube.getData('router_by_antennas'));
+  });
+});
+
 describe('serialisation (test/cube-serialize.js + blobs written by the reference)', () => {
   const { HipStore, wire } = require('../../olap-in-memory_amd/js');
   const golden = JSON.parse(fs.readFileSync(path.join(__dirname, '..', 'golden', 'wire.json'), 'utf8')).cases;

@@ -205,6 +205,40 @@ describe('wire format (interoperability with blobs written by the reference)', (
   });
 });
 
+describe('formula parser (no device)', () => {
+  const { getParser } = require('../../olap-in-memory_amd/js');
+  const parse = (t) => getParser().parse(t);
+  it('precedence, associativity, printing', () => {
+    assert.equal(parse('routers / antennas').toString(), '(routers / antennas)');
+    assert.equal(parse('a + b * 2 ^ 3 ^ 2 - -c').toString(), '((a + (b * (2 ^ (3 ^ 2)))) - (-c))');
+    assert.equal(parse('a || b + c').toString(), '((a || b) + c)'); // || sits on the additive level, as in expr-eval
+    assert.equal(parse('-x ^ 2').evaluate({ x: 3 }), -9);
+    assert.equal(parse('2 ^ -1').evaluate({}), 0.5);
+    assert.equal(parse('sqrt 16 + abs(-2)').evaluate({}), 6);
+    assert.equal(parse('a ? b : c ? 1 : 2').evaluate({ a: 0, b: 5, c: 0 }), 2);
+    assert.deepEqual(parse('max(a__total, b.c) + PI').variables(), ['a__total', 'b.c']);
+    assert.equal(parse(parse('min(a, 2) % 3 + if(a, 1, 0)').toString()).evaluate({ a: 7 }), 3);
+  });
+  it('the reference configuration: || is a NaN-coalescing sum, comparisons and logic are off', () => {
+    const or = parse('a || b');
+    assert.equal(or.evaluate({ a: Number.NaN, b: 3 }), 3);
+    assert.equal(or.evaluate({ a: 2, b: Number.NaN }), 2);
+    assert.equal(or.evaluate({ a: 2, b: 3 }), 5);
+    assert.ok(Number.isNaN(or.evaluate({ a: Number.NaN, b: Number.NaN })));
+    assert.throws(() => parse('a > 1'));
+    assert.throws(() => parse('a and b'));
+    assert.throws(() => parse('a = 1'));
+    assert.throws(() => parse('(a + 1'));
+    assert.throws(() => parse('nosuch(a)'));
+  });
+  it('substitute renames or inlines', () => {
+    const e = parse('a / (a + b)');
+    assert.equal(e.substitute('a', 'x').toString(), '(x / (x + b))');
+    assert.equal(e.substitute('b', parse('c * 2')).toString(), '(a / (a + (c * 2)))');
+    assert.equal(e.toString(), '(a / (a + b))');
+  });
+});
+
 describe('errors raised before any device work', () => {
   it('store constructor', () => {
     assert.throws(() => new HipStore(4, 'float32', 1), /Invalid default value, only NaN and 0 are supported/);
