@@ -410,3 +410,64 @@ def test_sparse_form_round_trip(type_name, default):
         assert np.array_equal(v.astype(np.float64), vals[keep])
         back = pkg.HipStore.from_sparse(n, type_name, default, idx, v)
         assert same_typed(back.get_data(), s.get_data()) and np.array_equal(back.get_status(), s.get_status())
+
+
+def _mulberry_cell_values(cells, seed=20240807):
+    """fround(0.5 + u(2*cell + 1)) for arbitrary (64-bit) cell indices — the device generator in closed form."""
+    cells = np.asarray(cells, dtype=np.uint64)
+    a = ((np.uint64(seed) + (np.uint64(2) * cells + np.uint64(1)) * np.uint64(0x6D2B79F5)) & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+    with np.errstate(over="ignore"):
+        t = (a ^ (a >> np.uint32(15))) * (np.uint32(1) | a)
+        t = (t + ((t ^ (t >> np.uint32(7))) * (np.uint32(61) | t))) ^ t
+        r = t ^ (t >> np.uint32(14))
+    return (0.5 + r.astype(np.float64) / 4294967296.0).astype(np.float32)
+
+
+@pytest.mark.parametrize("axis", [0, 1, 2])
+def test_five_billion_cells_64bit_indexing(axis):
+    """A 5x10^9-cell measure (20 GB, flat indices beyond 2^32): drillUp of each axis, spot-checked
+    against the closed form of the on-device generator (no 20 GB download)."""
+    shape = [5000, 1000, 1000]
+    n = int(np.prod(shape))
+    L = pkg.lib()
+    s = pkg.HipStore(n, "float32", 0.0)
+    pkg.capi.check(L.olap_fill_seeded(s.values_ptr, None, n, 0, 2, 20240807, 1.0, None))
+    new_len = list(shape)
+    new_len[axis] = 1
+    maps = [np.zeros(l, np.uint32) if i == axis else np.arange(l, dtype=np.uint32) for i, l in enumerate(shape)]
+    out = s.drill_up(shape, new_len, maps, "sum")
+    got = out.get_data()
+    assert got.size == n // shape[axis]
+    rng = np.random.default_rng(axis)
+    strides = [shape[1] * shape[2], shape[2], 1]
+    out_shape = list(new_len)
+    for flat in list(rng.integers(0, got.size, size=24)) + [0, got.size - 1]:
+        idx = list(np.unravel_index(int(flat), out_shape))
+        base = sum(int(idx[d]) * strides[d] for d in range(3) if d != axis)
+        cells = np.uint64(base) + np.arange(shape[axis], dtype=np.uint64) * np.uint64(strides[axis])
+        expect = np.float32(np.sum(_mulberry_cell_values(cells).astype(np.float64)))  # ascending k, float64
+        ref = 0.0
+        for v in _mulberry_cell_values(cells).astype(np.float64):
+            ref += v
+        assert got[int(flat)] == np.float32(ref), (axis, flat, got[int(flat)], ref, expect)
+    del s, out
+
+
+def test_empty_and_degenerate_shapes():
+    """Zero-length dimensions, zero-dimensional cubes and empty selections (test/cube-filtering.js:98-100)."""
+    s = pkg.HipStore(6, "float32", 0.0)
+    s.set_data(np.array([1, 2, 4, 8, 16, 32], np.float32))
+    empty = s.dice([3, 2], [0, 2], [np.zeros(0, np.int32), np.arange(2, dtype=np.int32)])
+    assert empty.size == 0 and empty.get_data().size == 0 and empty.count_set() == 0 and empty.total == 0
+    # rolling up an empty dimension gives its one 'all' item, unset
+    up = empty.drill_up([0, 2], [1, 2], [np.zeros(0, np.uint32), np.arange(2, dtype=np.uint32)], "sum")
+    assert up.size == 2 and np.array_equal(up.get_data(), [0, 0]) and up.count_set() == 0
+    scalar = pkg.HipStore(1, "float32", 0.0)
+    scalar.set_data(np.array([32], np.float32))
+    same = scalar.drill_up([], [], [], "average")
+    assert np.array_equal(same.get_data(), [32])
+    assert np.array_equal(scalar.reorder([], []).get_data(), [32])
+    zero = pkg.HipStore(0, "int32", float("nan"))
+    assert zero.get_data().size == 0 and zero.keys().size == 0
+    idx, vals = zero.to_sparse()
+    assert idx.size == 0 and vals.size == 0
