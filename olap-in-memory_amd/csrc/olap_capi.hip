@@ -45,6 +45,101 @@ static int hip_fail(hipError_t e, const char *what) {
     if (e__ != hipSuccess) return hip_fail(e__, #expr); \
   } while (0)
 
+// ------------------------------------------------------------------ device memory pool
+// hipMalloc / hipFree cost milliseconds for buffers of tens of MB (and hipFree synchronises the
+// device), which would dwarf a 70 us kernel: every query allocates its result store.  Freed blocks
+// are therefore kept in per-size free lists and handed out again; sizes are rounded up to 1/8-octave
+// steps (<= 12.5 % slack).  OLAP_POOL_BYTES caps what may sit idle in the lists (default 16 GiB);
+// beyond it blocks go back to the driver.
+#include <map>
+#include <mutex>
+#include <unordered_map>
+
+namespace {
+struct DevicePool {
+  std::mutex mu;
+  std::multimap<std::pair<int, size_t>, void *> idle;          // (device, rounded bytes) -> block
+  std::unordered_map<void *, std::pair<int, size_t>> live;     // block -> (device, rounded bytes)
+  size_t idle_bytes = 0;
+  size_t cap = 16ull << 30;
+  DevicePool() {
+    if (const char *e = getenv("OLAP_POOL_BYTES")) cap = (size_t)strtoull(e, nullptr, 10);
+  }
+  static size_t round_up(size_t bytes) {
+    if (bytes < 256) return 256;
+    size_t step = 256;
+    while ((step << 4) <= bytes) step <<= 1;  // step = 1/8 .. 1/16 of the size's octave
+    return (bytes + step - 1) / step * step;
+  }
+  hipError_t alloc(void **out, size_t bytes) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const size_t r = round_up(bytes);
+    {
+      std::lock_guard<std::mutex> lock(mu);
+      auto it = idle.find({dev, r});
+      if (it != idle.end()) {
+        *out = it->second;
+        idle.erase(it);
+        idle_bytes -= r;
+        live[*out] = {dev, r};
+        return hipSuccess;
+      }
+    }
+    hipError_t e = hipMalloc(out, r);
+    if (e != hipSuccess) {  // give the driver back what we hoard, then retry once
+      (void)hipGetLastError();
+      trim(0);
+      e = hipMalloc(out, r);
+    }
+    if (e == hipSuccess) {
+      std::lock_guard<std::mutex> lock(mu);
+      live[*out] = {dev, r};
+    }
+    return e;
+  }
+  void release(void *p) {
+    if (!p) return;
+    std::pair<int, size_t> key;
+    {
+      std::lock_guard<std::mutex> lock(mu);
+      auto it = live.find(p);
+      if (it == live.end()) {  // not ours
+        (void)hipFree(p);
+        return;
+      }
+      key = it->second;
+      live.erase(it);
+      if (idle_bytes + key.second <= cap) {
+        idle.insert({key, p});
+        idle_bytes += key.second;
+        return;
+      }
+    }
+    (void)hipFree(p);
+  }
+  void trim(size_t keep) {
+    std::vector<void *> drop;
+    {
+      std::lock_guard<std::mutex> lock(mu);
+      for (auto it = idle.begin(); it != idle.end() && idle_bytes > keep;) {
+        drop.push_back(it->second);
+        idle_bytes -= it->first.second;
+        it = idle.erase(it);
+      }
+    }
+    for (void *q : drop) (void)hipFree(q);
+  }
+};
+DevicePool &pool() {
+  static DevicePool *p = new DevicePool();  // leaked on purpose: outlives every handle finalizer
+  return *p;
+}
+}  // namespace
+
+static hipError_t dev_alloc(void **out, size_t bytes) { return pool().alloc(out, bytes); }
+static void dev_free(void *p) { pool().release(p); }
+
 extern "C" const char *olap_last_error(void) { return g_last_error.c_str(); }
 extern "C" int olap_abi_version(void) { return OLAP_ABI_VERSION; }
 
@@ -169,7 +264,7 @@ static int check_dims(int ndim, const uint32_t *a, const uint32_t *b) {
 static int upload(void **dev, const void *host, size_t bytes) {
   *dev = nullptr;
   if (bytes == 0) bytes = 16;
-  HIP_TRY(hipMalloc(dev, bytes));
+  HIP_TRY(dev_alloc(dev, bytes));
   if (host) HIP_TRY(hipMemcpy(*dev, host, bytes, hipMemcpyHostToDevice));
   return OLAP_OK;
 }
@@ -183,12 +278,15 @@ static int vec_for(int dtype, uint64_t contiguous) {
 
 extern "C" void olap_plan_destroy(olap_plan *p) {
   if (!p) return;
-  for (void *q : p->owned) (void)hipFree(q);
-  if (p->dev_tab) (void)hipFree(p->dev_tab);
-  if (p->dev_tab2) (void)hipFree(p->dev_tab2);
-  if (p->dev_tmp) (void)hipFree(p->dev_tmp);
-  if (p->dev_dist) (void)hipFree(p->dev_dist);
-  if (p->dev_err) (void)hipFree(p->dev_err);
+  // the tables go back to the pool and may be handed out again at once: wait for the launches
+  // that still read them (hipFree used to imply this)
+  if (p->ran) (void)hipStreamSynchronize(p->last_stream);
+  for (void *q : p->owned) dev_free(q);
+  if (p->dev_tab) dev_free(p->dev_tab);
+  if (p->dev_tab2) dev_free(p->dev_tab2);
+  if (p->dev_tmp) dev_free(p->dev_tmp);
+  if (p->dev_dist) dev_free(p->dev_dist);
+  if (p->dev_err) dev_free(p->dev_err);
   delete p;
 }
 
@@ -319,7 +417,7 @@ extern "C" int olap_drillup_plan(olap_plan **out, int dtype, int default_kind, i
         }
         rd.S = (uint32_t)S;
         if (!rd.vec4) rd.seg_len = (uint32_t)((longest + S - 1) / S);
-        hipError_t e = hipMalloc(&p->dev_tmp, cells * S * sizeof(Partial));
+        hipError_t e = dev_alloc(&p->dev_tmp, cells * S * sizeof(Partial));
         if (e != hipSuccess) {
           olap_plan_destroy(p);
           return hip_fail(e, "hipMalloc(drillUp reduce workspace)");
@@ -983,9 +1081,9 @@ extern "C" int olap_drilldown_plan(olap_plan **out, int dtype, int default_kind,
     }
     sc.tab = (const uint32_t *)cnt;
     p->dev_tmp = nullptr;
-    hipError_t e = hipMalloc(&p->dev_tmp, (p->in_cells ? p->in_cells : 1) * olap_dtype_size(dtype) + (size_t)16);
+    hipError_t e = dev_alloc(&p->dev_tmp, (p->in_cells ? p->in_cells : 1) * olap_dtype_size(dtype) + (size_t)16);
     if (e != hipSuccess) {
-      (void)hipFree(cnt);
+      dev_free(cnt);
       olap_plan_destroy(p);
       return hip_fail(e, "hipMalloc(drillDown quotients)");
     }
@@ -1284,14 +1382,14 @@ extern "C" int olap_total(const void *values, const int32_t *status, uint64_t n,
     unsigned long long count;
   } host = {0.0, 0};
   Acc *dev = nullptr;
-  HIP_TRY(hipMalloc((void **)&dev, sizeof(Acc)));
+  HIP_TRY(dev_alloc((void **)&dev, sizeof(Acc)));
   hipError_t e = hipMemcpyAsync(dev, &host, sizeof(host), hipMemcpyHostToDevice, (hipStream_t)stream);
   if (e == hipSuccess) {
     DISPATCH_DTYPE(dtype, e = Launch<T>::total((const T *)values, status, n, default_kind == OLAP_DEFAULT_NAN, &dev->total, &dev->count, (hipStream_t)stream));
   }
   if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
   if (e == hipSuccess) e = hipMemcpy(&host, dev, sizeof(host), hipMemcpyDeviceToHost);
-  (void)hipFree(dev);
+  dev_free(dev);
   if (e != hipSuccess) return hip_fail(e, "total");
   if (total) *total = host.total;
   if (n_set) *n_set = host.count;
@@ -1325,10 +1423,10 @@ static int store_alloc(olap_store **out, uint64_t size, int dtype, int default_k
   s->values = nullptr;
   s->status = nullptr;
   const size_t vb = (size ? size : 1) * olap_dtype_size(dtype), sb = (size ? size : 1) * sizeof(int32_t);
-  hipError_t e = hipMalloc(&s->values, vb);
-  if (e == hipSuccess && mask_is_primary(s)) e = hipMalloc((void **)&s->status, sb);
+  hipError_t e = dev_alloc(&s->values, vb);
+  if (e == hipSuccess && mask_is_primary(s)) e = dev_alloc((void **)&s->status, sb);
   if (e != hipSuccess) {
-    if (s->values) (void)hipFree(s->values);
+    if (s->values) dev_free(s->values);
     delete s;
     return hip_fail(e, "hipMalloc(store)");
   }
@@ -1340,7 +1438,7 @@ static int store_alloc(olap_store **out, uint64_t size, int dtype, int default_k
 static int ensure_status(const olap_store *s) {
   if (s->status) return OLAP_OK;
   int32_t *st = nullptr;
-  HIP_TRY(hipMalloc((void **)&st, (s->size ? s->size : 1) * sizeof(int32_t)));
+  HIP_TRY(dev_alloc((void **)&st, (s->size ? s->size : 1) * sizeof(int32_t)));
   s->status = st;
   int rc = olap_canonicalize(s->values, s->status, s->size, s->dtype, s->default_kind, 0, nullptr);
   if (rc) return rc;
@@ -1383,8 +1481,8 @@ extern "C" int olap_store_create(olap_store **store, uint64_t size, int dtype, i
 
 extern "C" void olap_store_destroy(olap_store *s) {
   if (!s) return;
-  if (s->values) (void)hipFree(s->values);
-  if (s->status) (void)hipFree(s->status);
+  if (s->values) dev_free(s->values);
+  if (s->status) dev_free(s->status);
   delete s;
 }
 
@@ -1424,7 +1522,7 @@ static int check_length(const olap_store *s, uint64_t n) {
 // a bulk write replaces every cell: a lazily built mask is dropped, a primary one is rewritten
 static void drop_lazy_status(olap_store *s) {
   if (s->status && !mask_is_primary(s)) {
-    (void)hipFree(s->status);
+    dev_free(s->status);
     s->status = nullptr;
   }
 }
@@ -1448,13 +1546,13 @@ extern "C" int olap_store_set_data_f64(olap_store *s, const double *host_values,
   if (n == 0) return OLAP_OK;
   drop_lazy_status(s);
   double *tmp = nullptr;
-  HIP_TRY(hipMalloc((void **)&tmp, n * sizeof(double)));
+  HIP_TRY(dev_alloc((void **)&tmp, n * sizeof(double)));
   hipError_t e = hipMemcpy(tmp, host_values, n * sizeof(double), hipMemcpyHostToDevice);
   if (e == hipSuccess) {
     rc = olap_convert_from_f64(tmp, s->values, s->status, n, s->dtype, s->default_kind, nullptr);
     if (!rc) e = hipStreamSynchronize(nullptr);
   }
-  (void)hipFree(tmp);
+  dev_free(tmp);
   if (rc) return rc;
   if (e != hipSuccess) return hip_fail(e, "set_data_f64");
   return OLAP_OK;
@@ -1471,11 +1569,11 @@ extern "C" int olap_store_get_data_f64(const olap_store *s, double *host_values)
   if (!s->size) return OLAP_OK;
   if (s->dtype == OLAP_FLOAT64) return olap_store_get_data(s, host_values);
   double *tmp = nullptr;
-  HIP_TRY(hipMalloc((void **)&tmp, s->size * sizeof(double)));
+  HIP_TRY(dev_alloc((void **)&tmp, s->size * sizeof(double)));
   int rc = olap_convert_to_f64(s->values, tmp, s->size, s->dtype, nullptr);
   hipError_t e = hipSuccess;
   if (!rc) e = hipMemcpy(host_values, tmp, s->size * sizeof(double), hipMemcpyDeviceToHost);
-  (void)hipFree(tmp);
+  dev_free(tmp);
   if (rc) return rc;
   if (e != hipSuccess) return hip_fail(e, "get_data_f64");
   // integer cells under a NaN default read back as NaN where unset, like getValue (:118-120)
@@ -1563,12 +1661,12 @@ extern "C" int olap_store_fill(olap_store *s, double value) {
   drop_lazy_status(s);
   std::vector<double> one(1, value);
   double *tmp = nullptr;
-  HIP_TRY(hipMalloc((void **)&tmp, sizeof(double)));
+  HIP_TRY(dev_alloc((void **)&tmp, sizeof(double)));
   hipError_t e = hipMemcpy(tmp, one.data(), sizeof(double), hipMemcpyHostToDevice);
   int rc = OLAP_OK;
   if (e == hipSuccess) rc = olap_convert_from_f64(tmp, s->values, s->status, 1, s->dtype, s->default_kind, nullptr);
   if (e == hipSuccess && !rc) e = hipStreamSynchronize(nullptr);
-  (void)hipFree(tmp);
+  dev_free(tmp);
   if (rc) return rc;
   if (e != hipSuccess) return hip_fail(e, "fill");
   // replicate cell 0 (value + status) by doubling copies
@@ -1610,11 +1708,11 @@ extern "C" int olap_store_eval_formula(const int32_t *code, int n_code, const do
   if (n && !host_out) return fail(OLAP_ERR_INVALID_ARGUMENT, "out is NULL");
   if (n == 0) return OLAP_OK;
   double *dev = nullptr;
-  HIP_TRY(hipMalloc((void **)&dev, n * sizeof(double)));
+  HIP_TRY(dev_alloc((void **)&dev, n * sizeof(double)));
   rc = olap_eval_formula(code, n_code, consts, n_consts, n_inputs, vals, stat, dtypes, defs, scalars, n_scalars, dev, n, nullptr);
   hipError_t e = hipSuccess;
   if (!rc) e = hipMemcpy(host_out, dev, n * sizeof(double), hipMemcpyDeviceToHost);
-  (void)hipFree(dev);
+  dev_free(dev);
   if (rc) return rc;
   if (e != hipSuccess) return hip_fail(e, "store_eval_formula");
   return OLAP_OK;
@@ -1631,7 +1729,7 @@ extern "C" int olap_store_to_sparse(const olap_store *s, uint32_t *host_indexes,
   const uint64_t chunk = (s->size + n_chunks - 1) / n_chunks;
   const int32_t *mask = mask_is_primary(s) ? s->status : nullptr;
   unsigned long long *dev_counts = nullptr;
-  HIP_TRY(hipMalloc((void **)&dev_counts, n_chunks * sizeof(unsigned long long)));
+  HIP_TRY(dev_alloc((void **)&dev_counts, n_chunks * sizeof(unsigned long long)));
   std::vector<unsigned long long> counts(n_chunks), offsets(n_chunks);
   hipError_t e = hipSuccess;
   DISPATCH_DTYPE(s->dtype, e = Launch<T>::compact_count((const T *)s->values, mask, s->size, chunk, n_chunks, s->default_kind == OLAP_DEFAULT_NAN, dev_counts, nullptr));
@@ -1644,24 +1742,24 @@ extern "C" int olap_store_to_sparse(const olap_store *s, uint32_t *host_indexes,
   *n_set = total;
   if (e == hipSuccess && host_indexes && host_values && total > 0) {
     if (cap < total) {
-      (void)hipFree(dev_counts);
+      dev_free(dev_counts);
       return fail(OLAP_ERR_LENGTH_MISMATCH, "sparse form needs room for %llu cells, %llu given", total, (unsigned long long)cap);
     }
     uint32_t *dev_idx = nullptr;
     void *dev_val = nullptr;
     const size_t es = olap_dtype_size(s->dtype);
-    e = hipMalloc((void **)&dev_idx, total * sizeof(uint32_t));
-    if (e == hipSuccess) e = hipMalloc(&dev_val, total * es);
+    e = dev_alloc((void **)&dev_idx, total * sizeof(uint32_t));
+    if (e == hipSuccess) e = dev_alloc(&dev_val, total * es);
     if (e == hipSuccess) e = hipMemcpy(dev_counts, offsets.data(), n_chunks * sizeof(unsigned long long), hipMemcpyHostToDevice);
     if (e == hipSuccess) {
       DISPATCH_DTYPE(s->dtype, e = Launch<T>::compact_write((const T *)s->values, mask, s->size, chunk, n_chunks, s->default_kind == OLAP_DEFAULT_NAN, dev_counts, dev_idx, (T *)dev_val, nullptr));
     }
     if (e == hipSuccess) e = hipMemcpy(host_indexes, dev_idx, total * sizeof(uint32_t), hipMemcpyDeviceToHost);
     if (e == hipSuccess) e = hipMemcpy(host_values, dev_val, total * es, hipMemcpyDeviceToHost);
-    if (dev_idx) (void)hipFree(dev_idx);
-    if (dev_val) (void)hipFree(dev_val);
+    if (dev_idx) dev_free(dev_idx);
+    if (dev_val) dev_free(dev_val);
   }
-  (void)hipFree(dev_counts);
+  dev_free(dev_counts);
   if (e != hipSuccess) return hip_fail(e, "to_sparse");
   return OLAP_OK;
 }
@@ -1680,8 +1778,8 @@ extern "C" int olap_store_from_sparse(olap_store **store, uint64_t size, int dty
     uint32_t *dev_idx = nullptr;
     void *dev_val = nullptr;
     const size_t es = olap_dtype_size(dtype);
-    hipError_t e = hipMalloc((void **)&dev_idx, n * sizeof(uint32_t));
-    if (e == hipSuccess) e = hipMalloc(&dev_val, n * es);
+    hipError_t e = dev_alloc((void **)&dev_idx, n * sizeof(uint32_t));
+    if (e == hipSuccess) e = dev_alloc(&dev_val, n * es);
     if (e == hipSuccess) e = hipMemcpy(dev_idx, host_indexes, n * sizeof(uint32_t), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(dev_val, host_values, n * es, hipMemcpyHostToDevice);
     if (e == hipSuccess) {
@@ -1691,15 +1789,15 @@ extern "C" int olap_store_from_sparse(olap_store **store, uint64_t size, int dty
       // integer cells under a NaN default: the listed cells are exactly the set ones
       std::vector<int32_t> two(n, OLAP_STATUS_SET);
       int32_t *dev_two = nullptr;
-      e = hipMalloc((void **)&dev_two, n * sizeof(int32_t));
+      e = dev_alloc((void **)&dev_two, n * sizeof(int32_t));
       if (e == hipSuccess) e = hipMemcpy(dev_two, two.data(), n * sizeof(int32_t), hipMemcpyHostToDevice);
       if (e == hipSuccess) e = Launch<int32_t>::scatter_sparse(s->status, dev_idx, dev_two, n, size, nullptr);
       if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
-      if (dev_two) (void)hipFree(dev_two);
+      if (dev_two) dev_free(dev_two);
     }
     if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
-    if (dev_idx) (void)hipFree(dev_idx);
-    if (dev_val) (void)hipFree(dev_val);
+    if (dev_idx) dev_free(dev_idx);
+    if (dev_val) dev_free(dev_val);
     if (e != hipSuccess) {
       olap_store_destroy(s);
       return hip_fail(e, "from_sparse");

@@ -9,6 +9,7 @@
 
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -32,15 +33,83 @@ static napi_value throw_olap(napi_env env, int code) {
   return nullptr;
 }
 
-static void finalize_store(napi_env, void *data, void *) { olap_store_destroy((olap_store *)data); }
+// Device memory and the JS garbage collector.  Telling V8 about every result store
+// (napi_adjust_external_memory) makes it start an incremental mark-sweep for each 40 MB result: a
+// drillUp then costs ~9 ms of GC around a 70 us kernel.  Telling it nothing would let dead stores
+// pile up until the JS heap itself needs collecting.  So only what is held BEYOND a budget is
+// reported (OLAP_NAPI_GC_BYTES, default 64 GiB of the 288 GB): below it V8 is left alone, above it
+// every new store adds pressure until finalizers have brought the total back under the budget.
+static int64_t g_held = 0, g_reported = 0;
+static int64_t gc_budget() {
+  static int64_t b = -1;
+  if (b < 0) {
+    const char *e = getenv("OLAP_NAPI_GC_BYTES");
+    b = e ? (int64_t)strtoll(e, nullptr, 10) : ((int64_t)64 << 30);
+  }
+  return b;
+}
+static void account(napi_env env, int64_t delta) {
+  g_held += delta;
+  const int64_t target = g_held > gc_budget() ? g_held - gc_budget() : 0;
+  if (target != g_reported) {
+    int64_t total;
+    napi_adjust_external_memory(env, target - g_reported, &total);
+    g_reported = target;
+  }
+}
+
+// Node runs N-API finalizers on a later event-loop turn, never inside a synchronous loop (even an
+// explicit gc() does not run them), so a loop of 3 000 queries would hold 3 000 result stores.  Each
+// wrapper therefore keeps its store in a small box next to a weak reference: once the budget is
+// exceeded, creating a store first sweeps the boxes and frees the device memory of every wrapper the
+// collector has already found dead (the weak reference is cleared during the GC itself); the late
+// finalizer then finds an empty box.
+struct StoreBox {
+  olap_store *store;
+  napi_ref ref;
+  bool finalized;
+};
+static std::vector<StoreBox *> g_boxes;
+
+static void release_box(napi_env env, StoreBox *box) {
+  if (!box->store) return;
+  account(env, -(int64_t)olap_store_byte_length(box->store));
+  olap_store_destroy(box->store);
+  box->store = nullptr;
+}
+
+static void finalize_store(napi_env env, void *data, void *) {
+  StoreBox *box = (StoreBox *)data;
+  release_box(env, box);
+  if (box->ref) napi_delete_reference(env, box->ref);
+  box->ref = nullptr;
+  box->finalized = true;  // the box itself is deleted by the next sweep
+}
+
+static void sweep_boxes(napi_env env) {
+  size_t keep = 0;
+  for (size_t i = 0; i < g_boxes.size(); ++i) {
+    StoreBox *box = g_boxes[i];
+    if (box->finalized) {
+      delete box;
+      continue;
+    }
+    if (box->store && box->ref) {
+      napi_value alive = nullptr;
+      if (napi_get_reference_value(env, box->ref, &alive) == napi_ok && alive == nullptr) release_box(env, box);
+    }
+    g_boxes[keep++] = box;
+  }
+  g_boxes.resize(keep);
+}
 
 static olap_store *unwrap(napi_env env, napi_value v) {
   void *p = nullptr;
-  if (napi_unwrap(env, v, &p) != napi_ok || !p) {
+  if (napi_unwrap(env, v, &p) != napi_ok || !p || !((StoreBox *)p)->store) {
     napi_throw_type_error(env, nullptr, "not a Store");
     return nullptr;
   }
-  return (olap_store *)p;
+  return ((StoreBox *)p)->store;
 }
 
 static napi_value wrap_new_store(napi_env env, olap_store *s) {
@@ -75,14 +144,20 @@ static napi_value StoreNew(napi_env env, napi_callback_info info) {
     int rc = olap_store_create(&s, (uint64_t)size, dtype, def);
     if (rc) return throw_olap(env, rc);
   }
-  if (napi_wrap(env, self, s, finalize_store, nullptr, nullptr) != napi_ok) {
+  static unsigned since_sweep = 0;
+  if (g_held > gc_budget() || ++since_sweep >= 1024) {
+    sweep_boxes(env);
+    since_sweep = 0;
+  }
+  StoreBox *box = new StoreBox{s, nullptr, false};
+  if (napi_wrap(env, self, box, finalize_store, nullptr, &box->ref) != napi_ok) {
     olap_store_destroy(s);
+    delete box;
     napi_throw_error(env, nullptr, "napi_wrap failed");
     return nullptr;
   }
-  // let the GC know how much device memory hangs off this small object
-  int64_t adj;
-  napi_adjust_external_memory(env, (int64_t)olap_store_byte_length(s), &adj);
+  g_boxes.push_back(box);
+  account(env, (int64_t)olap_store_byte_length(s));
   return self;
 }
 
@@ -525,6 +600,8 @@ static napi_value MethodFromName(napi_env env, napi_callback_info info) {
 }
 
 static napi_value DeviceCount(napi_env env, napi_callback_info) { return num(env, olap_device_count()); }
+// bytes of device memory currently owned by live Store objects (diagnostics)
+static napi_value HeldBytes(napi_env env, napi_callback_info) { return num(env, (double)g_held); }
 static napi_value AbiVersion(napi_env env, napi_callback_info) { return num(env, olap_abi_version()); }
 
 static napi_value SetDevice(napi_env env, napi_callback_info info) {
@@ -571,6 +648,7 @@ static napi_value Init(napi_env env, napi_value exports) {
       {"evalFormula", nullptr, EvalFormula, nullptr, nullptr, nullptr, napi_default, nullptr},
       {"storeFromSparse", nullptr, StoreFromSparse, nullptr, nullptr, nullptr, napi_default, nullptr},
       {"methodFromName", nullptr, MethodFromName, nullptr, nullptr, nullptr, napi_default, nullptr},
+      {"heldBytes", nullptr, HeldBytes, nullptr, nullptr, nullptr, napi_default, nullptr},
       {"deviceCount", nullptr, DeviceCount, nullptr, nullptr, nullptr, napi_default, nullptr},
       {"abiVersion", nullptr, AbiVersion, nullptr, nullptr, nullptr, napi_default, nullptr},
       {"setDevice", nullptr, SetDevice, nullptr, nullptr, nullptr, napi_default, nullptr},
