@@ -1,20 +1,23 @@
 'use strict';
 /*
- * Base of the dimension objects the store consumes.  The store needs exactly five things from a
+ * Common part of the dimension classes.  A store operation reads exactly five things from a
  * dimension (in-memory.js:141-147, :196, :216-223, :268-273, :347-352): numItems, getItems(),
- * getItemsToIdx(), rootAttribute and getGroupIndexFromRootIndexMap(attr).
- * Contract mirrored from /root/reference/src/dimension/abstract.js.
+ * getItemsToIdx(), rootAttribute and getGroupIndexFromRootIndexMap(attribute); the rest are the
+ * item <-> index <-> group conversions of the public API (contract of
+ * /root/reference/src/dimension/abstract.js).  Subclasses provide getItems(attribute),
+ * attributes, getGroupIndexFromRootIndex(attribute, rootIndex) and the drill/dice operations.
  */
+const mustOverride = (name) =>
+  function () {
+    throw new Error(`Override me (${name})`);
+  };
+
 class AbstractDimension {
   constructor(id, rootAttribute, label = null) {
     this.id = id;
     this._rootAttribute = rootAttribute;
     this._label = label;
-    this._indexOfItem = {}; // attribute -> { item: index }
-  }
-
-  get numItems() {
-    return this.getItems().length;
+    this._positions = new Map(); // attribute -> plain object { item: index }, built on demand
   }
 
   get rootAttribute() {
@@ -25,47 +28,27 @@ class AbstractDimension {
     return this._label;
   }
 
-  get attributes() {
-    throw new Error('Override me');
+  get numItems() {
+    return this.getItems().length;
   }
 
-  getItems(_attribute = null) {
-    throw new Error('Override me');
-  }
-
-  drillUp(_attribute) {
-    throw new Error('Override me');
-  }
-
-  dice(_attribute, _items, _reorder = false) {
-    throw new Error('Override me');
-  }
-
-  diceRange(_attribute, _start, _end) {
-    throw new Error('Override me');
-  }
-
-  getGroupIndexFromRootIndex(_attribute, _rootIndex) {
-    throw new Error('Override me');
-  }
-
-  /** { item -> index } of one attribute's items, cached. */
+  /** Lookup table item -> index for one attribute (the root attribute by default). */
   getItemsToIdx(attribute = null) {
-    const attr = attribute || this._rootAttribute;
-    let table = this._indexOfItem[attr];
-    if (!table) {
-      table = {};
-      this.getItems(attr).forEach((item, i) => {
-        table[item] = i;
-      });
-      this._indexOfItem[attr] = table;
+    const key = attribute || this._rootAttribute;
+    if (!this._positions.has(key)) {
+      const table = {};
+      const items = this.getItems(key);
+      // a repeated item keeps its LAST position, as in the reference (src/dimension/abstract.js:66)
+      for (let index = 0; index < items.length; ++index) table[items[index]] = index;
+      this._positions.set(key, table);
     }
-    return table;
+    return this._positions.get(key);
   }
 
+  /** -1 when the item is not a root item */
   getRootIndexFromRootItem(rootItem) {
-    const index = this.getItemsToIdx()[rootItem];
-    return index === undefined ? -1 : index;
+    const at = this.getItemsToIdx()[rootItem];
+    return at === undefined ? -1 : at;
   }
 
   getGroupIndexFromRootItem(attribute, rootItem) {
@@ -77,16 +60,24 @@ class AbstractDimension {
   }
 
   getGroupItemFromRootItem(attribute, rootItem) {
-    return this.getItems(attribute)[this.getGroupIndexFromRootItem(attribute, rootItem)];
+    return this.getGroupItemFromRootIndex(attribute, this.getRootIndexFromRootItem(rootItem));
+  }
+
+  _forgetPositions(attribute) {
+    this._positions.delete(attribute);
   }
 
   _checkRootIndex(index) {
-    if (index < 0 || index >= this.numItems) throw new Error(`rootIndex ${index} out of bounds [0, ${this.numItems}[`);
+    const n = this.numItems;
+    if (!(index >= 0 && index < n)) throw new Error(`rootIndex ${index} out of bounds [0, ${n}[`);
   }
 
   _checkAttribute(attribute) {
-    if (!this.attributes.includes(attribute)) throw new Error(`No attribute ${attribute} was found on dimension ${this.id}`);
+    if (this.attributes.indexOf(attribute) === -1) throw new Error(`No attribute ${attribute} was found on dimension ${this.id}`);
   }
 }
+
+for (const name of ['getItems', 'drillUp', 'dice', 'diceRange', 'getGroupIndexFromRootIndex']) AbstractDimension.prototype[name] = mustOverride(name);
+Object.defineProperty(AbstractDimension.prototype, 'attributes', { get: mustOverride('attributes'), configurable: true });
 
 module.exports = AbstractDimension;

@@ -63,7 +63,7 @@ class GenericDimension extends AbstractDimension {
       map[root] = seen[group];
     }
     this._attr[newAttribute] = { items, map, labels };
-    delete this._indexOfItem[newAttribute];
+    this._forgetPositions(newAttribute);
   }
 
   renameItem(oldItem, newItem, newLabel = null) {
@@ -76,11 +76,7 @@ class GenericDimension extends AbstractDimension {
         entry.labels[newItem] = newLabel || newItem;
         delete entry.labels[oldItem];
       }
-      const cache = this._indexOfItem[attr];
-      if (cache && cache[oldItem] !== undefined) {
-        cache[newItem] = cache[oldItem];
-        delete cache[oldItem];
-      }
+      this._forgetPositions(attr);
     }
   }
 

@@ -1,15 +1,25 @@
 'use strict';
 /*
- * Entry point of the Node.js host: the reference's public names (src/index.js:1-6) for the
- * aggregation path.  `getParser` returns the formula parser of computed measures (./formula.js).
+ * Package entry of the Node.js host.  Carries the four names of the reference's entry point
+ * (Cube, GenericDimension, TimeDimension, getParser — /root/reference/src/index.js) plus what is
+ * specific to this implementation: the device store class, the calendar and the wire codec.
  */
-const Cube = require('./cube');
-const GenericDimension = require('./dimension/generic');
-const TimeDimension = require('./dimension/time');
-const HipStore = require('./store/hip');
-const TimeSlot = require('./calendar');
-const wire = require('./wire');
+const lazy = (file, pick) => {
+  let loaded;
+  return () => {
+    if (loaded === undefined) loaded = pick ? require(file)[pick] : require(file);
+    return loaded;
+  };
+};
 
-const { getParser } = require('./formula');
+const entries = {
+  Cube: lazy('./cube'),
+  GenericDimension: lazy('./dimension/generic'),
+  TimeDimension: lazy('./dimension/time'),
+  getParser: lazy('./formula', 'getParser'),
+  HipStore: lazy('./store/hip'),
+  TimeSlot: lazy('./calendar'),
+  wire: lazy('./wire'),
+};
 
-module.exports = { Cube, GenericDimension, TimeDimension, getParser, HipStore, TimeSlot, wire };
+for (const name of Object.keys(entries)) Object.defineProperty(exports, name, { enumerable: true, get: entries[name] });
