@@ -202,7 +202,10 @@ int olap_total(const void *values, const int32_t *status, uint64_t n, int dtype,
 /* ------------------------------------------------------------------------------------------
  * Store handles: device-resident cells owned by the library, for hosts that cannot hold device
  * pointers (the Node.js addon).  One handle = one measure's InMemoryStore (in-memory.js:7-64).
- * Calls are synchronous (they return when the result is ready), like the reference API.
+ * Bulk operations are enqueued on the library's (null) stream and return at once; they are ordered
+ * behind each other, and every call that hands data to the host (get_*, total, to_sparse, ...) is
+ * a blocking copy on that stream, so the API behaves synchronously like the reference's.  Plans
+ * built for handles are cached (LRU) and device buffers come from a pool.
  * ---------------------------------------------------------------------------------------- */
 typedef struct olap_store olap_store;
 

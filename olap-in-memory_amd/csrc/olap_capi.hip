@@ -49,7 +49,7 @@ static int hip_fail(hipError_t e, const char *what) {
 // hipMalloc / hipFree cost milliseconds for buffers of tens of MB (and hipFree synchronises the
 // device), which would dwarf a 70 us kernel: every query allocates its result store.  Freed blocks
 // are therefore kept in per-size free lists and handed out again; sizes are rounded up to 1/8-octave
-// steps (<= 12.5 % slack).  OLAP_POOL_BYTES caps what may sit idle in the lists (default 16 GiB);
+// steps (<= 12.5 % slack).  OLAP_POOL_BYTES caps what may sit idle in the lists (default 32 GiB);
 // beyond it blocks go back to the driver.
 #include <map>
 #include <mutex>
@@ -61,7 +61,7 @@ struct DevicePool {
   std::multimap<std::pair<int, size_t>, void *> idle;          // (device, rounded bytes) -> block
   std::unordered_map<void *, std::pair<int, size_t>> live;     // block -> (device, rounded bytes)
   size_t idle_bytes = 0;
-  size_t cap = 16ull << 30;
+  size_t cap = 32ull << 30;
   DevicePool() {
     if (const char *e = getenv("OLAP_POOL_BYTES")) cap = (size_t)strtoull(e, nullptr, 10);
   }
@@ -1812,16 +1812,71 @@ extern "C" int olap_store_from_sparse(olap_store **store, uint64_t size, int dty
 // values cannot; everywhere else the kernels derive "set" from the value and skip the mask read.
 static const int32_t *mask_needed(const olap_store *s) { return mask_is_primary(s) ? s->status : nullptr; }
 
+// ---- plan cache of the handle layer ------------------------------------------------------------
+// A dashboard issues the same few queries over and over; building a plan costs two or three small
+// blocking uploads (~25 us), as much as a small kernel.  Plans made for store handles are kept in
+// an LRU keyed by everything that defines them (kind, cell type, default, method, lengths, tables).
+namespace {
+struct PlanKey {
+  std::string bytes;
+  void raw(const void *p, size_t n) { bytes.append((const char *)p, n); }
+  void i32(int32_t v) { raw(&v, sizeof v); }
+  void u64(uint64_t v) { raw(&v, sizeof v); }
+  void u32s(const uint32_t *p, size_t n) {
+    u64(n);
+    if (n) raw(p, n * sizeof(uint32_t));
+  }
+  void tables(const uint32_t *const *t, const uint32_t *lens, int ndim) {
+    for (int d = 0; d < ndim; ++d) u32s(t[d], lens[d]);
+  }
+};
+struct PlanCache {
+  std::mutex mu;
+  std::unordered_map<std::string, std::pair<olap_plan *, uint64_t>> map;  // key -> (plan, last use)
+  uint64_t tick = 0;
+  static constexpr size_t kMax = 128;
+  olap_plan *find(const std::string &key) {
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = map.find(key);
+    if (it == map.end()) return nullptr;
+    it->second.second = ++tick;
+    return it->second.first;
+  }
+  void insert(const std::string &key, olap_plan *plan) {
+    olap_plan *evicted = nullptr;
+    {
+      std::lock_guard<std::mutex> lock(mu);
+      if (map.size() >= kMax) {
+        auto oldest = map.begin();
+        for (auto it = map.begin(); it != map.end(); ++it)
+          if (it->second.second < oldest->second.second) oldest = it;
+        evicted = oldest->second.first;
+        map.erase(oldest);
+      }
+      map[key] = {plan, ++tick};
+    }
+    if (evicted) olap_plan_destroy(evicted);
+  }
+};
+PlanCache &plan_cache() {
+  static PlanCache *c = new PlanCache();  // leaked on purpose, like the pool
+  return *c;
+}
+}  // namespace
+
+// Runs a (cached) plan into a freshly allocated store.  Everything is enqueued on the null stream
+// and NOT waited for: later operations are ordered behind it by the stream and every host read is a
+// blocking copy on that stream.  Only a drillDown with distributions is waited for, because its
+// data-dependent error (in-memory.js:397-398) must surface from this call.
 static int run_to_new_store(olap_plan *plan, const olap_store *in, olap_store **out) {
   olap_store *o = nullptr;
   int rc = store_alloc(&o, olap_plan_out_cells(plan), in->dtype, in->default_kind);
   if (!rc) rc = olap_plan_run(plan, in->values, mask_needed(in), o->values, o->status, nullptr);
-  if (!rc) {
+  if (!rc && plan->kind == PLAN_DRILLDOWN && plan->dd.dist) {
     hipError_t e = hipStreamSynchronize(nullptr);
     if (e != hipSuccess) rc = hip_fail(e, "plan_run");
+    if (!rc) rc = olap_plan_status(plan);
   }
-  if (!rc) rc = olap_plan_status(plan);
-  olap_plan_destroy(plan);
   if (rc) {
     olap_store_destroy(o);
     return rc;
@@ -1836,18 +1891,39 @@ static int check_store_cells(const olap_store *s, const olap_plan *plan) {
   return OLAP_OK;
 }
 
+static bool bad_dims(int ndim, const void *a, const void *b) { return ndim < 0 || ndim > OLAP_MAX_DIMS || (ndim > 0 && (!a || !b)); }
+
 extern "C" int olap_store_drillup(const olap_store *s, olap_store **out, int ndim, const uint32_t *old_len,
                                   const uint32_t *new_len, const uint32_t *const *maps, int method) {
   if (!s || !out) return fail(OLAP_ERR_INVALID_ARGUMENT, "store is NULL");
   *out = nullptr;
   olap_plan *plan = nullptr;
-  int rc = olap_drillup_plan(&plan, s->dtype, s->default_kind, method, ndim, old_len, new_len, maps);
-  if (rc) return rc;
-  if ((rc = check_store_cells(s, plan))) {
-    olap_plan_destroy(plan);
-    return rc;
+  PlanKey key;
+  const bool keyable = !bad_dims(ndim, old_len, new_len) && (ndim == 0 || maps);
+  if (keyable) {
+    bool ok = true;
+    for (int d = 0; d < ndim; ++d) ok = ok && (old_len[d] == 0 || maps[d]);
+    if (ok) {
+      key.i32('U');
+      key.i32(s->dtype), key.i32(s->default_kind), key.i32(method), key.i32(ndim);
+      key.u32s(old_len, ndim), key.u32s(new_len, ndim);
+      key.tables(maps, old_len, ndim);
+      plan = plan_cache().find(key.bytes);
+    }
   }
-  return run_to_new_store(plan, s, out);
+  if (!plan) {
+    int rc = olap_drillup_plan(&plan, s->dtype, s->default_kind, method, ndim, old_len, new_len, maps);
+    if (rc) return rc;
+    if (!key.bytes.empty()) plan_cache().insert(key.bytes, plan);
+    else {
+      rc = check_store_cells(s, plan);
+      if (!rc) rc = run_to_new_store(plan, s, out);
+      olap_plan_destroy(plan);
+      return rc;
+    }
+  }
+  int rc = check_store_cells(s, plan);
+  return rc ? rc : run_to_new_store(plan, s, out);
 }
 
 extern "C" int olap_store_drilldown(const olap_store *s, olap_store **out, int ndim, const uint32_t *old_len,
@@ -1855,14 +1931,14 @@ extern "C" int olap_store_drilldown(const olap_store *s, olap_store **out, int n
                                     const double *distributions, uint64_t n_dist) {
   if (!s || !out) return fail(OLAP_ERR_INVALID_ARGUMENT, "store is NULL");
   *out = nullptr;
+  // not cached: plans with distributions carry a per-run error word, and drillDown is rare
   olap_plan *plan = nullptr;
   int rc = olap_drilldown_plan(&plan, s->dtype, s->default_kind, method, ndim, old_len, new_len, maps, distributions, n_dist);
   if (rc) return rc;
-  if ((rc = check_store_cells(s, plan))) {
-    olap_plan_destroy(plan);
-    return rc;
-  }
-  return run_to_new_store(plan, s, out);
+  rc = check_store_cells(s, plan);
+  if (!rc) rc = run_to_new_store(plan, s, out);
+  olap_plan_destroy(plan);
+  return rc;
 }
 
 extern "C" int olap_store_dice(const olap_store *s, olap_store **out, int ndim, const uint32_t *old_len,
@@ -1870,13 +1946,31 @@ extern "C" int olap_store_dice(const olap_store *s, olap_store **out, int ndim, 
   if (!s || !out) return fail(OLAP_ERR_INVALID_ARGUMENT, "store is NULL");
   *out = nullptr;
   olap_plan *plan = nullptr;
-  int rc = olap_dice_plan(&plan, s->dtype, s->default_kind, ndim, old_len, new_len, sel);
-  if (rc) return rc;
-  if ((rc = check_store_cells(s, plan))) {
-    olap_plan_destroy(plan);
-    return rc;
+  PlanKey key;
+  if (!bad_dims(ndim, old_len, new_len) && (ndim == 0 || sel)) {
+    bool ok = true;
+    for (int d = 0; d < ndim; ++d) ok = ok && (new_len[d] == 0 || sel[d]);
+    if (ok) {
+      key.i32('D');
+      key.i32(s->dtype), key.i32(s->default_kind), key.i32(ndim);
+      key.u32s(old_len, ndim), key.u32s(new_len, ndim);
+      key.tables((const uint32_t *const *)sel, new_len, ndim);
+      plan = plan_cache().find(key.bytes);
+    }
   }
-  return run_to_new_store(plan, s, out);
+  if (!plan) {
+    int rc = olap_dice_plan(&plan, s->dtype, s->default_kind, ndim, old_len, new_len, sel);
+    if (rc) return rc;
+    if (!key.bytes.empty()) plan_cache().insert(key.bytes, plan);
+    else {
+      rc = check_store_cells(s, plan);
+      if (!rc) rc = run_to_new_store(plan, s, out);
+      olap_plan_destroy(plan);
+      return rc;
+    }
+  }
+  int rc = check_store_cells(s, plan);
+  return rc ? rc : run_to_new_store(plan, s, out);
 }
 
 extern "C" int olap_store_dice_drillup(const olap_store *s, olap_store **out, int ndim, const uint32_t *old_len,
@@ -1885,13 +1979,32 @@ extern "C" int olap_store_dice_drillup(const olap_store *s, olap_store **out, in
   if (!s || !out) return fail(OLAP_ERR_INVALID_ARGUMENT, "store is NULL");
   *out = nullptr;
   olap_plan *plan = nullptr;
-  int rc = olap_dice_drillup_plan(&plan, s->dtype, s->default_kind, method, ndim, old_len, mid_len, new_len, sel, maps);
-  if (rc) return rc;
-  if ((rc = check_store_cells(s, plan))) {
-    olap_plan_destroy(plan);
-    return rc;
+  PlanKey key;
+  if (!bad_dims(ndim, old_len, mid_len) && !bad_dims(ndim, mid_len, new_len) && (ndim == 0 || (sel && maps))) {
+    bool ok = true;
+    for (int d = 0; d < ndim; ++d) ok = ok && (mid_len[d] == 0 || (sel[d] && maps[d]));
+    if (ok) {
+      key.i32('F');
+      key.i32(s->dtype), key.i32(s->default_kind), key.i32(method), key.i32(ndim);
+      key.u32s(old_len, ndim), key.u32s(mid_len, ndim), key.u32s(new_len, ndim);
+      key.tables((const uint32_t *const *)sel, mid_len, ndim);
+      key.tables(maps, mid_len, ndim);
+      plan = plan_cache().find(key.bytes);
+    }
   }
-  return run_to_new_store(plan, s, out);
+  if (!plan) {
+    int rc = olap_dice_drillup_plan(&plan, s->dtype, s->default_kind, method, ndim, old_len, mid_len, new_len, sel, maps);
+    if (rc) return rc;
+    if (!key.bytes.empty()) plan_cache().insert(key.bytes, plan);
+    else {
+      rc = check_store_cells(s, plan);
+      if (!rc) rc = run_to_new_store(plan, s, out);
+      olap_plan_destroy(plan);
+      return rc;
+    }
+  }
+  int rc = check_store_cells(s, plan);
+  return rc ? rc : run_to_new_store(plan, s, out);
 }
 
 extern "C" int olap_store_reorder(const olap_store *s, olap_store **out, int ndim, const uint32_t *old_len,
@@ -1899,13 +2012,26 @@ extern "C" int olap_store_reorder(const olap_store *s, olap_store **out, int ndi
   if (!s || !out) return fail(OLAP_ERR_INVALID_ARGUMENT, "store is NULL");
   *out = nullptr;
   olap_plan *plan = nullptr;
-  int rc = olap_reorder_plan(&plan, s->dtype, s->default_kind, ndim, old_len, perm);
-  if (rc) return rc;
-  if ((rc = check_store_cells(s, plan))) {
-    olap_plan_destroy(plan);
-    return rc;
+  PlanKey key;
+  if (!bad_dims(ndim, old_len, perm)) {
+    key.i32('R');
+    key.i32(s->dtype), key.i32(s->default_kind), key.i32(ndim);
+    key.u32s(old_len, ndim), key.u32s((const uint32_t *)perm, ndim);
+    plan = plan_cache().find(key.bytes);
   }
-  return run_to_new_store(plan, s, out);
+  if (!plan) {
+    int rc = olap_reorder_plan(&plan, s->dtype, s->default_kind, ndim, old_len, perm);
+    if (rc) return rc;
+    if (!key.bytes.empty()) plan_cache().insert(key.bytes, plan);
+    else {
+      rc = check_store_cells(s, plan);
+      if (!rc) rc = run_to_new_store(plan, s, out);
+      olap_plan_destroy(plan);
+      return rc;
+    }
+  }
+  int rc = check_store_cells(s, plan);
+  return rc ? rc : run_to_new_store(plan, s, out);
 }
 
 extern "C" int olap_store_load(olap_store *s, const olap_store *other, int ndim, const uint32_t *my_len,
@@ -1921,10 +2047,6 @@ extern "C" int olap_store_load(olap_store *s, const olap_store *other, int ndim,
   }
   drop_lazy_status(s);
   rc = olap_plan_run(plan, other->values, mask_needed(other), s->values, s->status, nullptr);
-  if (!rc) {
-    hipError_t e = hipStreamSynchronize(nullptr);
-    if (e != hipSuccess) rc = hip_fail(e, "load");
-  }
-  olap_plan_destroy(plan);
+  olap_plan_destroy(plan);  // waits for the launch (its tables go back to the pool)
   return rc;
 }

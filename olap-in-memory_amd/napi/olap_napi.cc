@@ -34,27 +34,35 @@ static napi_value throw_olap(napi_env env, int code) {
 }
 
 // Device memory and the JS garbage collector.  Telling V8 about every result store
-// (napi_adjust_external_memory) makes it start an incremental mark-sweep for each 40 MB result: a
+// (napi_adjust_external_memory) makes it run incremental mark-sweep steps for each 40 MB result: a
 // drillUp then costs ~9 ms of GC around a 70 us kernel.  Telling it nothing would let dead stores
-// pile up until the JS heap itself needs collecting.  So only what is held BEYOND a budget is
-// reported (OLAP_NAPI_GC_BYTES, default 64 GiB of the 288 GB): below it V8 is left alone, above it
-// every new store adds pressure until finalizers have brought the total back under the budget.
-static int64_t g_held = 0, g_reported = 0;
+// pile up until the JS heap itself needs collecting.  So V8 is left alone while the stores held by
+// live wrappers stay under a budget (OLAP_NAPI_GC_BYTES, default 16 GiB of the 288 GB; keep it
+// below the pool's OLAP_POOL_BYTES so that what a collection frees is recycled, not hipFree'd).  When the
+// budget is crossed, ONE large external-memory report makes V8 do a full collection right there
+// (its hard limit for external memory is far below the amount reported), the report is taken back,
+// and the wrappers found dead are swept (below).  The next such collection is not asked for before
+// another quarter of the budget has been allocated, so live data above the budget does not thrash.
+static int64_t g_held = 0;
+static int64_t g_next_gc_at = 0;
 static int64_t gc_budget() {
   static int64_t b = -1;
   if (b < 0) {
     const char *e = getenv("OLAP_NAPI_GC_BYTES");
-    b = e ? (int64_t)strtoll(e, nullptr, 10) : ((int64_t)64 << 30);
+    b = e ? (int64_t)strtoll(e, nullptr, 10) : ((int64_t)16 << 30);
   }
   return b;
 }
+static void sweep_boxes(napi_env env);
 static void account(napi_env env, int64_t delta) {
   g_held += delta;
-  const int64_t target = g_held > gc_budget() ? g_held - gc_budget() : 0;
-  if (target != g_reported) {
+  if (delta > 0 && g_held > gc_budget() && g_held >= g_next_gc_at) {
     int64_t total;
-    napi_adjust_external_memory(env, target - g_reported, &total);
-    g_reported = target;
+    const int64_t nudge = (int64_t)8 << 30;
+    napi_adjust_external_memory(env, nudge, &total);   // V8 collects synchronously in here
+    napi_adjust_external_memory(env, -nudge, &total);
+    sweep_boxes(env);
+    g_next_gc_at = g_held + gc_budget() / 4;
   }
 }
 
@@ -145,7 +153,7 @@ static napi_value StoreNew(napi_env env, napi_callback_info info) {
     if (rc) return throw_olap(env, rc);
   }
   static unsigned since_sweep = 0;
-  if (g_held > gc_budget() || ++since_sweep >= 1024) {
+  if (++since_sweep >= 1024) {  // housekeeping: drop the boxes of finalized wrappers
     sweep_boxes(env);
     since_sweep = 0;
   }

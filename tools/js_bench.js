@@ -10,10 +10,16 @@ function cubeOf(nDims, size) {
   return cube;
 }
 
+// Operations are enqueued on the device stream and not waited for, so the loop is closed by a
+// one-cell read of the last result (a blocking copy behind everything queued): the figure is the
+// sustained time per operation, not just the enqueue time.
 function time(label, fn, iters) {
-  for (let i = 0; i < 3; ++i) fn();
+  const wait = (r) => (r && r.storedMeasures ? Object.values(r.storedMeasures)[0].getValue(0) : r);
+  for (let i = 0; i < 3; ++i) wait(fn());
   const t0 = process.hrtime.bigint();
-  for (let i = 0; i < iters; ++i) fn();
+  let last;
+  for (let i = 0; i < iters; ++i) last = fn();
+  wait(last);
   const us = Number(process.hrtime.bigint() - t0) / 1e3 / iters;
   console.log(`${label.padEnd(58)} ${us.toFixed(1).padStart(10)} us`);
   return us;
