@@ -7,6 +7,8 @@
 // Instantiated once per cell type in olap_kernels_{f32,f64,i32,u32}.hip.
 #pragma once
 
+#include <cstdlib>
+
 #include "olap_device.hpp"
 
 namespace olap {
@@ -894,7 +896,7 @@ struct Brick {
 __device__ __forceinline__ uint32_t lds_pad(uint32_t e) { return e + (e >> 5); }
 
 template <typename T, bool HAS_STATUS>
-__global__ __launch_bounds__(kBlock) void reorder_brick_kernel(const T *__restrict__ in,
+__global__ __launch_bounds__(1024) void reorder_brick_kernel(const T *__restrict__ in,
                                                                const int32_t *__restrict__ st_in,
                                                                T *__restrict__ out,
                                                                int32_t *__restrict__ st_out, const Brick b) {
@@ -936,12 +938,13 @@ __global__ __launch_bounds__(kBlock) void reorder_brick_kernel(const T *__restri
   // both phases are latency chains (table entry -> address -> data), so each lane keeps UB of them
   // in flight
   constexpr int UB = 8;
-  for (uint32_t e0 = threadIdx.x; e0 < b.elems; e0 += kBlock * UB) {
+  const uint32_t nthreads = blockDim.x;  // 256 for small bricks, 1024 for large ones (occupancy)
+  for (uint32_t e0 = threadIdx.x; e0 < b.elems; e0 += nthreads * UB) {
     uint32_t off[UB];
     bool ok[UB];
 #pragma unroll
     for (int u = 0; u < UB; ++u) {
-      const uint32_t e = e0 + u * kBlock;
+      const uint32_t e = e0 + u * nthreads;
       ok[u] = e < b.elems;
       if (ok[u] && partial) ok[u] = inside(b.rd_dig[e]);
       off[u] = ok[u] ? b.rd_off[e] : 0u;
@@ -958,7 +961,7 @@ __global__ __launch_bounds__(kBlock) void reorder_brick_kernel(const T *__restri
 #pragma unroll
     for (int u = 0; u < UB; ++u) {
       if (ok[u]) {
-        const uint32_t e = e0 + u * kBlock;
+        const uint32_t e = e0 + u * nthreads;
         tile[lds_pad(e)] = x[u];
         if constexpr (HAS_STATUS) stile[lds_pad(e)] = sx[u];
       }
@@ -967,12 +970,12 @@ __global__ __launch_bounds__(kBlock) void reorder_brick_kernel(const T *__restri
   __syncthreads();
   T *dst = out + base_out;
   int32_t *sdst = st_out ? st_out + base_out : nullptr;
-  for (uint32_t f0 = threadIdx.x; f0 < b.elems; f0 += kBlock * UB) {
+  for (uint32_t f0 = threadIdx.x; f0 < b.elems; f0 += nthreads * UB) {
     uint32_t off[UB], pos[UB];
     bool ok[UB];
 #pragma unroll
     for (int u = 0; u < UB; ++u) {
-      const uint32_t f = f0 + u * kBlock;
+      const uint32_t f = f0 + u * nthreads;
       ok[u] = f < b.elems;
       if (ok[u] && partial) ok[u] = inside(b.wr_dig[f]);
       off[u] = ok[u] ? b.wr_off[f] : 0u;
@@ -1696,8 +1699,10 @@ hipError_t Launch<T>::reorder_brick(bool has_status, const T *in, const int32_t 
   if (n_bricks == 0) return hipSuccess;
   const size_t cells = lds_pad_host(b.elems);
   const size_t lds = ((cells * sizeof(T) + 15) & ~(size_t)15) + (has_status ? cells * 4 : 0);
-  if (has_status) hipLaunchKernelGGL((reorder_brick_kernel<T, true>), (unsigned)n_bricks, kBlock, lds, stream, in, st_in, out, st_out, b);
-  else hipLaunchKernelGGL((reorder_brick_kernel<T, false>), (unsigned)n_bricks, kBlock, lds, stream, in, st_in, out, st_out, b);
+  unsigned threads = kBlock;  // larger workgroups for larger bricks bought nothing (tools/sweep.py)
+  if (const char *e = getenv("OLAP_BRICK_THREADS")) threads = (unsigned)atoi(e);
+  if (has_status) hipLaunchKernelGGL((reorder_brick_kernel<T, true>), (unsigned)n_bricks, threads, lds, stream, in, st_in, out, st_out, b);
+  else hipLaunchKernelGGL((reorder_brick_kernel<T, false>), (unsigned)n_bricks, threads, lds, stream, in, st_in, out, st_out, b);
   return hipGetLastError();
 }
 

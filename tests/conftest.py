@@ -18,6 +18,12 @@ def load_package():
     name = "olap_in_memory_amd"
     if name in sys.modules:
         return sys.modules[name]
+    # torch bundles its own HIP runtime: a process that uses both must load torch's FIRST, so that
+    # libolapgpu.so binds to the runtime already in the process (two runtimes cannot share the GPU)
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
     pkg_dir = os.path.join(ROOT, "olap-in-memory_amd")
     spec = importlib.util.spec_from_file_location(
         name, os.path.join(pkg_dir, "__init__.py"), submodule_search_locations=[pkg_dir])

@@ -471,3 +471,39 @@ def test_empty_and_degenerate_shapes():
     assert zero.get_data().size == 0 and zero.keys().size == 0
     idx, vals = zero.to_sparse()
     assert idx.size == 0 and vals.size == 0
+
+
+def test_plans_replay_inside_a_hip_graph():
+    """olap_plan_run is pure kernel launches on the given stream, so a chain of plans can be
+    captured once into a hipGraph (through torch.cuda.CUDAGraph) and replayed: collapse() of a
+    6-dimensional cube = six drillUps, one graph launch."""
+    import torch
+
+    shape = [10] * 6
+    n = 10 ** 6
+    vals, _ = config_cube(n, 5, 1.0)
+    dev = torch.device("cuda:0")
+    src = torch.from_numpy(vals).to(dev)
+    plans, bufs, lens = [], [src], list(shape)
+    for axis in range(6):
+        new = list(lens)
+        new[axis] = 1
+        maps = [np.zeros(l, np.uint32) if i == axis else np.arange(l, dtype=np.uint32) for i, l in enumerate(lens)]
+        plans.append(pkg.Plan.drillup("float32", 0.0, "sum", lens, new, maps))
+        bufs.append(torch.empty(int(np.prod(new)), dtype=torch.float32, device=dev))
+        lens = new
+    stream = torch.cuda.Stream()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(stream):
+        for p, a, b in zip(plans, bufs[:-1], bufs[1:]):  # warm-up outside capture
+            p.run(a.data_ptr(), None, b.data_ptr(), None, stream.cuda_stream)
+        stream.synchronize()
+        with torch.cuda.graph(graph, stream=stream):
+            for p, a, b in zip(plans, bufs[:-1], bufs[1:]):
+                p.run(a.data_ptr(), None, b.data_ptr(), None, torch.cuda.current_stream().cuda_stream)
+    eager = bufs[-1].clone()
+    src.mul_(2.0)  # new input, same graph
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.allclose(bufs[-1], eager * 2, rtol=1e-6)
+    assert abs(float(eager.item()) - float(vals.astype(np.float64).sum())) <= 1e-5 * float(vals.sum())
