@@ -121,20 +121,23 @@ class ShardedStore:
         out._keepalive = op
         return out
 
-    def plan_drillup_dim0(self, row_map, n_groups, method="sum"):
+    def plan_drillup_dim0(self, row_map, n_groups, method="sum", always_collective=False):
         """Prepares drillUp of the sharded axis: row_map[global row] -> group (< n_groups)."""
-        return Dim0DrillUp(self, row_map, n_groups, method)
+        return Dim0DrillUp(self, row_map, n_groups, method, always_collective)
 
 
 class Dim0DrillUp:
     """Reusable step: local partial + one collective.  `step()` is what bench.py times at N > 1."""
 
-    def __init__(self, store, row_map, n_groups, method="sum"):
+    def __init__(self, store, row_map, n_groups, method="sum", always_collective=False):
         import torch.distributed as dist
 
         self.dist = dist
         self.s = s = store
         self.method = method
+        # always_collective: run the collective even in a one-rank group (lets a single-GPU box
+        # exercise the RCCL code path; with one rank every collective is the identity)
+        self.collective = store.world > 1 or always_collective
         row_map = np.asarray(row_map, dtype=np.uint32)
         if row_map.size != s.lens[0]:
             raise ValueError("row_map must have one entry per row of dimension 0")
@@ -146,16 +149,16 @@ class Dim0DrillUp:
         w = s.world
         self.n_out = n_groups * s.inner0
         self.additive = method in ("sum", "average")
-        local_method = capi.PARTIAL_AVERAGE if (method == "average" and w > 1) else method
+        local_method = capi.PARTIAL_AVERAGE if (method == "average" and self.collective) else method
         self.local = eng.make_drillup(s.dtype, s.default, local_method, old_len, new_len, maps)
         self.partial = eng.empty(self.n_out, s.dtype)
         # `sum` over a zero default: the mask is a function of the value (set <=> value != 0), so the
         # path neither writes nor ships it.  `average` ships contribution counts in its place.
         zero_default = not (s.default != s.default)
         self.partial_status = None if (method == "sum" and zero_default) else eng.empty(self.n_out, "int32")
-        self.scatter = self.additive and w > 1 and self.n_out % w == 0
-        self.staged = w > 1 and dist.get_backend(s.group) == "gloo" and getattr(self.partial, "is_cuda", False)
-        if w == 1:
+        self.scatter = self.additive and self.collective and self.n_out % w == 0
+        self.staged = self.collective and dist.get_backend(s.group) == "gloo" and getattr(self.partial, "is_cuda", False)
+        if not self.collective:
             self.result, self.result_status = self.partial, self.partial_status
         elif self.additive:
             n_res = self.n_out // w if self.scatter else self.n_out
@@ -203,7 +206,7 @@ class Dim0DrillUp:
         local reduction of query i+1 runs on the compute stream.  Returns the result tensor of THIS
         query; it is complete after its work handle (or flush()) has been waited for."""
         s, dist = self.s, self.dist
-        if s.world == 1 or self.method != "sum" or self.partial_status is not None or self.staged:
+        if not self.collective or self.method != "sum" or self.partial_status is not None or self.staged:
             return self.step()
         if not hasattr(self, "_pipe"):
             eng = s.engine
@@ -248,7 +251,7 @@ class Dim0DrillUp:
     def step(self):
         s, dist = self.s, self.dist
         self.local.run(s.values, None, self.partial, self.partial_status)
-        if s.world == 1:
+        if not self.collective:
             return self.result
         if self.additive:
             self._sum_across_ranks(self.partial, self.result)

@@ -80,3 +80,13 @@ def test_sharded_drillup_gloo_cpu(tmp_path):
 @pytest.mark.gpu
 def test_sharded_drillup_gloo_gpu(tmp_path):
     check(run_workers("hip", tmp_path))
+
+
+@pytest.mark.gpu
+def test_rccl_code_path_single_rank():
+    """The exact torch.distributed / RCCL calls bench.py makes at N > 1 (reduce_scatter_tensor sync and
+    async, all_reduce, all_gather_into_tensor), on a one-rank nccl group: catches API misuse that the
+    gloo rehearsal cannot (device tensors, stream semantics) before the driver's 8-GPU run."""
+    r = subprocess.run([sys.executable, os.path.join(HERE, "_rccl_single_rank.py")], stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert r.returncode == 0 and "rccl single-rank ok" in r.stdout, r.stdout[-4000:]
