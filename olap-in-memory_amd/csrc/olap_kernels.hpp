@@ -1479,7 +1479,13 @@ static hipError_t drillup_axis_launch(const T *in, const int32_t *st_in, T *out,
   const bool contig = a.order == nullptr;
   const uint64_t row_blocks = a.outer * a.G * a.blocks_per_row;
   const bool rows = a.n_vec >= 128 && row_blocks < 0x7FFFFFFFull;
-  constexpr int U = 4;  // rows in flight per lane (tools/microbench.hip: U=2..10 within 2 %)
+  // Rows in flight per lane.  With full 16 B lanes and rows that fill whole workgroups ONE is
+  // fastest for the plain streaming forms (tools/microbench.hip, profiles/microbench_r01.txt: 67 us
+  // against 70-71 us at 2..10 on the 10^8 cube): 32 waves per CU already keep 32 KiB in flight and
+  // the waves sweep the K rows together.  Narrow lanes or short rows (e.g. inner = 274) need the
+  // depth back, and so does the heavier exact state machine.
+  constexpr int U = 4;
+  const bool shallow = (kAdditive || IsPick<METHOD>::value) && VEC * sizeof(T) >= 16 && a.n_vec >= 1024;
   if (!rows) {
     // LDS tile regime for small `inner` (below 16 B per lane the flat regime's accesses waste most
     // of every cache line): whole rows of K*inner cells staged per workgroup, kTileBytes of cells
@@ -1512,10 +1518,21 @@ static hipError_t drillup_axis_launch(const T *in, const int32_t *st_in, T *out,
     }
   }
 #define OLAP_ROWS(C, F) hipLaunchKernelGGL((drillup_rows_kernel<T, METHOD, HS, VEC, U, C, F>), (unsigned)row_blocks, kBlock, 0, stream, in, st_in, out, st_out, a)
+#define OLAP_ROWS1(C, F) hipLaunchKernelGGL((drillup_rows_kernel<T, METHOD, HS, VEC, 1, C, F>), (unsigned)row_blocks, kBlock, 0, stream, in, st_in, out, st_out, a)
 #define OLAP_FLAT(F) hipLaunchKernelGGL((drillup_flat_kernel<T, METHOD, HS, VEC, F>), grid_for(a.total), kBlock, 0, stream, in, st_in, out, st_out, a)
   if (rows) {
     if constexpr (kAdditive && !HS) {
-      if (fast) { if (contig) OLAP_ROWS(true, true); else OLAP_ROWS(false, true); return hipGetLastError(); }
+      if (fast) {
+        if (shallow) { if (contig) OLAP_ROWS1(true, true); else OLAP_ROWS1(false, true); }
+        else { if (contig) OLAP_ROWS(true, true); else OLAP_ROWS(false, true); }
+        return hipGetLastError();
+      }
+    }
+    if constexpr (IsPick<METHOD>::value && !HS) {
+      if (shallow) {
+        if (contig) OLAP_ROWS1(true, false); else OLAP_ROWS1(false, false);
+        return hipGetLastError();
+      }
     }
     if (contig) OLAP_ROWS(true, false); else OLAP_ROWS(false, false);
   } else {
@@ -1525,6 +1542,7 @@ static hipError_t drillup_axis_launch(const T *in, const int32_t *st_in, T *out,
     OLAP_FLAT(false);
   }
 #undef OLAP_ROWS
+#undef OLAP_ROWS1
 #undef OLAP_FLAT
   return hipGetLastError();
 }

@@ -99,6 +99,12 @@ int main(int argc, char **argv) {
   CK(hipMalloc(&in, N * 4));
   CK(hipMalloc(&out, N * 4));  // big enough for the copy test
   CK(hipMalloc(&st_out, inner * 4));
+  int32_t *st_in;
+  CK(hipMalloc(&st_in, N * 4));
+  {
+    std::vector<int32_t> hs(N, 2);
+    CK(hipMemcpy(st_in, hs.data(), N * 4, hipMemcpyHostToDevice));
+  }
   CK(hipMalloc(&sink, 4));
   {
     std::vector<float> h(N);
@@ -136,17 +142,33 @@ int main(int argc, char **argv) {
   vs.push_back({"copy 2048 blocks (r+w)", [&] { hipLaunchKernelGGL(copy_kernel, 2048, 256, 0, 0, (const float4 *)in, (float4 *)out, N / 4); }, N * 8.0, {}});
   vs.push_back({"colsum_f32<10> value-only", [&] { hipLaunchKernelGGL(colsum_f32_kernel<10>, rows_grid, 256, 0, 0, (const float4 *)in, (float4 *)out, inner / 4); }, N * 4.0 + inner * 4.0, {}});
 #define ROWS(U, FAST, NT, ST, NAME) vs.push_back({NAME, [&] { hipLaunchKernelGGL((drillup_rows_kernel<float, OLAP_SUM, false, 4, U, true, FAST, NT>), rows_grid, 256, 0, 0, in, nullptr, out, ST, a); }, (ST) ? alg : N * 4.0 + inner * 4.0, {}})
-  ROWS(8, true, false, st_out, "rows U=8 fast plain");
-  ROWS(8, true, true, st_out, "rows U=8 fast nt");
-  ROWS(4, true, true, st_out, "rows U=4 fast nt");
-  ROWS(2, true, true, st_out, "rows U=2 fast nt");
-  ROWS(10, true, true, st_out, "rows U=10 fast nt");
-  ROWS(8, false, true, st_out, "rows U=8 exact nt");
-  ROWS(8, true, true, (int32_t *)nullptr, "rows U=8 fast nt, values only");
-  ROWS(4, true, true, (int32_t *)nullptr, "rows U=4 fast nt, values only");
-  ROWS(2, true, true, (int32_t *)nullptr, "rows U=2 fast nt, values only");
-  ROWS(10, true, true, (int32_t *)nullptr, "rows U=10 fast nt, values only");
-  vs.push_back({"flat U=4 fast", [&] { hipLaunchKernelGGL((drillup_flat_kernel<float, OLAP_SUM, false, 4, true>), grid_for(a.total), 256, 0, 0, in, nullptr, out, st_out, a); }, alg, {}});
+  ROWS(8, true, true, (int32_t *)nullptr, "rows U=8 nt values only");
+  ROWS(4, true, true, (int32_t *)nullptr, "rows U=4 nt values only (product)");
+  ROWS(2, true, true, (int32_t *)nullptr, "rows U=2 nt values only");
+  ROWS(1, true, true, (int32_t *)nullptr, "rows U=1 nt values only");
+  ROWS(5, true, true, (int32_t *)nullptr, "rows U=5 nt values only");
+  ROWS(10, true, true, (int32_t *)nullptr, "rows U=10 nt values only");
+  {
+    static DrillUpAxis a8 = a;
+    a8.n_vec = inner / 8;
+    a8.total = a8.n_vec;
+    a8.blocks_per_row = (a8.n_vec + 255) / 256;
+    const unsigned g8 = (unsigned)a8.blocks_per_row;
+    vs.push_back({"rows VEC=8 U=4 nt values only", [&, g8] { hipLaunchKernelGGL((drillup_rows_kernel<float, OLAP_SUM, false, 8, 4, true, true, true>), g8, 256, 0, 0, in, nullptr, out, (int32_t *)nullptr, a8); }, N * 4.0 + inner * 4.0, {}});
+    vs.push_back({"rows VEC=8 U=2 nt values only", [&, g8] { hipLaunchKernelGGL((drillup_rows_kernel<float, OLAP_SUM, false, 8, 2, true, true, true>), g8, 256, 0, 0, in, nullptr, out, (int32_t *)nullptr, a8); }, N * 4.0 + inner * 4.0, {}});
+  }
+  ROWS(4, true, true, st_out, "rows U=4 nt + status out");
+  ROWS(1, true, true, st_out, "rows U=1 nt + status out");
+  ROWS(1, false, true, (int32_t *)nullptr, "rows U=1 exact");
+  ROWS(2, false, true, (int32_t *)nullptr, "rows U=2 exact");
+  ROWS(4, false, true, (int32_t *)nullptr, "rows U=4 exact");
+#define ROWS_ST(U, NAME) vs.push_back({NAME, [&] { hipLaunchKernelGGL((drillup_rows_kernel<float, OLAP_SUM, true, 4, U, true, false, true>), rows_grid, 256, 0, 0, in, st_in, out, st_out, a); }, 2 * alg, {}})
+  ROWS_ST(1, "rows U=1 mask in+out");
+  ROWS_ST(2, "rows U=2 mask in+out");
+  ROWS_ST(4, "rows U=4 mask in+out");
+#define ROWS_HI(U, NAME) vs.push_back({NAME, [&] { hipLaunchKernelGGL((drillup_rows_kernel<float, OLAP_HIGHEST, false, 4, U, true, false, true>), rows_grid, 256, 0, 0, in, nullptr, out, (int32_t *)nullptr, a); }, N * 4.0 + inner * 4.0, {}})
+  ROWS_HI(1, "rows U=1 highest");
+  ROWS_HI(4, "rows U=4 highest");
 
   Timer t;
   for (auto &v : vs) t.run(v.fn, 3);  // warm-up
