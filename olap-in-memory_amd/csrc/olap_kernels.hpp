@@ -1487,7 +1487,7 @@ static hipError_t drillup_axis_launch(const T *in, const int32_t *st_in, T *out,
   constexpr int U = 4;
   const bool shallow = (kAdditive || IsPick<METHOD>::value) && VEC * sizeof(T) >= 16 && a.n_vec >= 1024;
   if (!rows) {
-    // LDS tile regime for small `inner` (below 16 B per lane the flat regime's accesses waste most
+    // LDS tile regime for small `inner` (short row pieces make the flat regime's accesses waste much
     // of every cache line): whole rows of K*inner cells staged per workgroup, kTileBytes of cells
     const uint64_t row_elems = a.K * a.inner;
     const uint64_t budget = kTileBytes / sizeof(T);
@@ -1497,7 +1497,9 @@ static hipError_t drillup_axis_launch(const T *in, const int32_t *st_in, T *out,
     constexpr uint64_t V = 16 / sizeof(T);
     if (R >= 4) R &= ~3ull;
     while (R > 0 && (R * row_elems) % V != 0) --R;
-    if (a.aligned16 && a.inner < 16 && R > 0 && csr_bytes <= 16 * 1024 && a.G * a.inner <= 0xFFFFFFFFull) {
+    uint64_t tile_max_inner = 128;  // tools/sweep3.py: the LDS form wins up to ~100 cells per row piece
+    if (const char *e = getenv("OLAP_TILE_MAX_INNER")) tile_max_inner = (uint64_t)atoll(e);
+    if (a.aligned16 && a.inner < tile_max_inner && R > 0 && csr_bytes <= 16 * 1024 && a.G * a.inner <= 0xFFFFFFFFull) {
       DrillUpTile tl;
       tl.rows_per_tile = (uint32_t)R;
       tl.row_elems = (uint32_t)row_elems;
