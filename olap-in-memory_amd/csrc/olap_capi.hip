@@ -231,6 +231,8 @@ struct olap_plan {
   GatherReduce gr{};
   DrillUpReduce reduce{};                  // S > 0: reduce regime of the one-axis drillUp
   bool dd_two_pass = false;                // float cells, no distributions: scale + broadcast
+  bool dd_rows = false;                    // one refined axis, wide rows: drilldown_rows_kernel (uses `axis`)
+  uint32_t dd_longest = 0;                 // children of the largest parent
   void *dev_tab2 = nullptr;                // second table set (two-pass drillDown)
   void *dev_tmp = nullptr;                 // quotients of the two-pass drillDown (old cells)
   std::vector<void *> owned;               // further device allocations freed with the plan
@@ -1066,7 +1068,53 @@ extern "C" int olap_drilldown_plan(olap_plan **out, int dtype, int default_kind,
   sc.total = p->in_cells;
   sc.def_nan = p->def_nan;
   sc.divide = method == OLAP_SUM;
-  p->dd_two_pass = !distributions && (dtype == OLAP_FLOAT32 || dtype == OLAP_FLOAT64);
+  // One refined axis and rows wide enough to fill workgroups: the row form (children streamed
+  // from one read of the parent row).
+  {
+    int n_changed = 0, changed = -1;
+    for (int d = 0; d < ndim; ++d)
+      if (!is_identity_u32(maps[d], new_len[d], old_len[d])) {
+        ++n_changed;
+        changed = d;
+      }
+    if (!distributions && n_changed == 1) {
+      DrillUpAxis &ax = p->axis;
+      ax.outer = product(new_len, changed);
+      ax.K = new_len[changed];   // children side
+      ax.G = old_len[changed];   // parents side
+      ax.inner = product(new_len + changed + 1, ndim - changed - 1);
+      const int vec = vec_for(dtype, ax.inner);
+      if (ax.inner / (uint64_t)vec >= 128 && ax.outer * (uint64_t)ax.K * ((ax.inner / vec + kBlock - 1) / kBlock) < 0x3FFFFFFFull) {
+        // CSR of the children of every parent, ascending
+        const uint32_t K = new_len[changed], G = old_len[changed];
+        std::vector<uint32_t> gstart((size_t)G + 1, 0), order(K);
+        for (uint32_t k = 0; k < K; ++k) gstart[maps[changed][k] + 1]++;
+        for (uint32_t gg = 0; gg < G; ++gg) gstart[gg + 1] += gstart[gg];
+        {
+          std::vector<uint32_t> cur(gstart.begin(), gstart.end() - 1);
+          for (uint32_t k = 0; k < K; ++k) order[cur[maps[changed][k]]++] = k;
+        }
+        bool contiguous = true;
+        for (uint32_t k = 0; k < K; ++k) contiguous = contiguous && order[k] == k;
+        for (uint32_t gg = 0; gg < G; ++gg) p->dd_longest = std::max(p->dd_longest, gstart[gg + 1] - gstart[gg]);
+        std::vector<uint32_t> csr(gstart);
+        const size_t order_at = csr.size();
+        if (!contiguous) csr.insert(csr.end(), order.begin(), order.end());
+        void *dev = nullptr;
+        if ((rc = upload(&dev, csr.data(), csr.size() * sizeof(uint32_t)))) {
+          olap_plan_destroy(p);
+          return rc;
+        }
+        p->owned.push_back(dev);
+        ax.gstart = (const uint32_t *)dev;
+        ax.order = contiguous ? nullptr : (const uint32_t *)dev + order_at;
+        ax.def_nan = p->def_nan;
+        p->vec = vec;
+        p->dd_rows = true;
+      }
+    }
+  }
+  p->dd_two_pass = !p->dd_rows && !distributions && (dtype == OLAP_FLOAT32 || dtype == OLAP_FLOAT64);
   if (p->dd_two_pass) {
     if ((rc = finish_remap(p, bcast, p->out_cells, true))) {  // uploads p->dev_tab (int64 offsets)
       olap_plan_destroy(p);
@@ -1123,7 +1171,7 @@ extern "C" int olap_drilldown_plan(olap_plan **out, int dtype, int default_kind,
     p->dev_err = (unsigned long long *)ev;
     a.err = p->dev_err;
   }
-  p->kernel_name = p->dd_two_pass ? "drilldown_scale_kernel+gather_kernel" : "drilldown_kernel";
+  p->kernel_name = p->dd_rows ? "drilldown_rows_kernel" : (p->dd_two_pass ? "drilldown_scale_kernel+gather_kernel" : "drilldown_kernel");
   *out = p;
   return OLAP_OK;
 }
@@ -1184,6 +1232,16 @@ static int run_typed(olap_plan *p, const void *in_v, const int32_t *in_s, void *
       break;
     }
     case PLAN_DRILLDOWN: {
+      if (p->dd_rows) {
+        DrillUpAxis a = p->axis;
+        int vec = p->vec;
+        a.aligned16 = aligned16(in) && aligned16(out) && (!in_s || aligned16(in_s)) && (!out_s || aligned16(out_s));
+        if (!a.aligned16) vec = 1;
+        a.n_vec = a.inner / (uint64_t)vec;
+        a.blocks_per_row = (a.n_vec + kBlock - 1) / kBlock;
+        e = Launch<T>::drilldown_rows(hs, vec, in, in_s, out, out_s, a, p->method == OLAP_SUM, p->dd.use_rounding, p->dd_longest, stream);
+        break;
+      }
       if (p->dd_two_pass) {
         T *q = (T *)p->dev_tmp;
         e = Launch<T>::drilldown_scale(hs, in, in_s, q, p->dds, stream);

@@ -707,7 +707,9 @@ struct Remap {
 // dice (in-memory.js:213-263) and reorder (:178-211): iterate the DESTINATION, gather from the
 // source.  Destination cells without a source stay unset.  VEC > 1 only when the innermost
 // collapsed dim is contiguous in both (plan guarantees divisibility).
-template <typename T, bool HAS_STATUS, int VEC>
+// IDX: uint32_t when every index of the launch fits 32 bits (the usual case: 64-bit divisions are
+// several times dearer and the decode is most of this kernel's instruction count), else uint64_t.
+template <typename T, bool HAS_STATUS, int VEC, typename IDX = uint64_t>
 __global__ __launch_bounds__(kBlock) void gather_kernel(const T *__restrict__ in,
                                                         const int32_t *__restrict__ st_in,
                                                         T *__restrict__ out,
@@ -715,14 +717,15 @@ __global__ __launch_bounds__(kBlock) void gather_kernel(const T *__restrict__ in
   const uint64_t t = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
   if (t >= r.total) return;
   const bool def_nan = r.def_nan != 0;
-  uint64_t c = t * VEC;
+  IDX c = (IDX)(t * VEC);
   uint64_t src = 0;
   bool ok = true;
 #pragma unroll
   for (int d = kMaxDims - 1; d >= 0; --d) {
     if (d < r.nd) {
-      const uint32_t digit = (uint32_t)(c % r.len[d]);
-      c /= r.len[d];
+      const IDX q = c / (IDX)r.len[d];
+      const uint32_t digit = (uint32_t)(c - q * (IDX)r.len[d]);
+      c = q;
       if (r.tab_off[d] < 0) {
         src += (uint64_t)digit * r.stride[d];
       } else {
@@ -735,6 +738,8 @@ __global__ __launch_bounds__(kBlock) void gather_kernel(const T *__restrict__ in
   Vec<T, VEC> ov;
   Vec<int32_t, VEC> os;
   if (ok) {
+    // the source may be re-read (a drillDown broadcast reads each parent many times): cached loads;
+    // the destination is written once: streaming stores
     const Vec<T, VEC> v = load_vec<T, VEC>(in + src);
     Vec<int32_t, VEC> s;
     if constexpr (HAS_STATUS) s = load_vec<int32_t, VEC>(st_in + src);
@@ -751,8 +756,8 @@ __global__ __launch_bounds__(kBlock) void gather_kernel(const T *__restrict__ in
       os.v[e] = 0;
     }
   }
-  store_vec<T, VEC>(out + t * VEC, ov);
-  if (st_out) store_vec<int32_t, VEC>(st_out + t * VEC, os);
+  store_stream<T, VEC>(out + t * VEC, ov);
+  if (st_out) store_stream<int32_t, VEC>(st_out + t * VEC, os);
 }
 
 // K5: fused dice -> drillUp.  Iterates the OUTPUT cube; the source offset of an output cell is the
@@ -1079,6 +1084,77 @@ __global__ __launch_bounds__(kBlock) void drilldown_kernel(const T *__restrict__
   emit_cell<T>(r, has, def_nan, ov, os);
   out[t] = ov;
   if (st_out) st_out[t] = os;
+}
+
+// One refined axis (what Cube.drillDown / addDimension ask for, src/cube.js:971, :919-927), no
+// distributions: the mirror image of drillup_rows_kernel.  View [outer, G, inner] -> [outer, K, inner];
+// a workgroup owns 256 adjacent VEC-wide slots of ONE parent row (outer, g), reads them once, and
+// streams the children's values to each of the group's rows — every parent cell is read once and
+// every store is a full 16 B per lane.  n = number of children (uniform per workgroup); the integer
+// remainder spreading needs only the child's ordinal, which is its position in the group's list.
+constexpr uint32_t kChildrenPerBlock = 8;  // children rows written by one workgroup
+
+template <typename T, bool HAS_STATUS, int VEC>
+__global__ __launch_bounds__(kBlock) void drilldown_rows_kernel(const T *__restrict__ in,
+                                                                const int32_t *__restrict__ st_in,
+                                                                T *__restrict__ out,
+                                                                int32_t *__restrict__ st_out,
+                                                                const DrillUpAxis a, int divide, int use_rounding,
+                                                                uint32_t segments) {
+  // blockIdx.x = ((og * segments) + seg) * blocks_per_row + chunk   (uniform math)
+  const uint32_t bpr = (uint32_t)a.blocks_per_row;
+  const uint64_t ogs = blockIdx.x / bpr;
+  const uint32_t chunk = blockIdx.x - (uint32_t)ogs * bpr;
+  const uint32_t seg = (uint32_t)(ogs % segments);
+  const uint64_t og = ogs / segments;
+  const uint64_t g = og % a.G;
+  const uint64_t o = og / a.G;
+  const uint32_t gbeg = a.gstart[g], gend = a.gstart[g + 1];
+  const uint32_t jbeg = gbeg + seg * kChildrenPerBlock;
+  if (jbeg >= gend) return;  // this group has fewer children than the longest one (whole workgroup leaves)
+  const uint32_t jend = jbeg + kChildrenPerBlock < gend ? jbeg + kChildrenPerBlock : gend;
+  const uint64_t iv = (uint64_t)chunk * kBlock + threadIdx.x;
+  if (iv >= a.n_vec) return;
+  const uint64_t i0 = iv * VEC;
+  const bool def_nan = a.def_nan != 0;
+  const uint64_t pidx = (o * a.G + g) * a.inner + i0;
+  const Vec<T, VEC> pv = load_vec<T, VEC>(in + pidx);
+  Vec<int32_t, VEC> ps;
+  if constexpr (HAS_STATUS) ps = load_vec<int32_t, VEC>(st_in + pidx);
+  const double n = (double)(gend - gbeg);
+  double base[VEC], one_over[VEC];
+  bool has[VEC];
+  Vec<T, VEC> same_v;     // the value every child receives when no remainder is spread
+  Vec<int32_t, VEC> same_s;
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) {
+    const double old_value = Cell<T>::to_f64(pv.v[e]);
+    // `if (!oldValue) continue` (in-memory.js:386-387): unset, 0, -0 and NaN parents give nothing
+    has[e] = cell_is_set<T>(pv.v[e], HAS_STATUS ? ps.v[e] : OLAP_STATUS_SET, HAS_STATUS, def_nan) && old_value == old_value &&
+             old_value != 0.0;
+    base[e] = divide ? (use_rounding ? floor(floor(old_value / n)) : old_value / n) : old_value;  // :404, :419, :422
+    one_over[e] = fmod(old_value, n) / n;                                                          // :405-407
+    emit_cell<T>(base[e], has[e] && !is_default_f64(base[e], def_nan), def_nan, same_v.v[e], same_s.v[e]);
+  }
+  T *orow = out + (o * a.K) * a.inner + i0;
+  int32_t *srow = st_out ? st_out + (o * a.K) * a.inner + i0 : nullptr;
+  const bool spread = divide && use_rounding;
+  for (uint32_t j = jbeg; j < jend; ++j) {
+    const uint64_t k = a.order ? (uint64_t)a.order[j] : (uint64_t)j;
+    Vec<T, VEC> ov = same_v;
+    Vec<int32_t, VEC> os = same_s;
+    if (spread) {  // :403-417, replayed with the same float64 operations; cid = the child's ordinal
+      const double cid = (double)(j - gbeg);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        const bool last_is_same = floor(cid * one_over[e]) == floor((cid - 1.0) * one_over[e]);
+        const double r = last_is_same ? base[e] : base[e] + 1.0;
+        emit_cell<T>(r, has[e] && !is_default_f64(r, def_nan), def_nan, ov.v[e], os.v[e]);
+      }
+    }
+    store_stream<T, VEC>(orow + k * a.inner, ov);
+    if (srow) store_stream<int32_t, VEC>(srow + k * a.inner, os);
+  }
 }
 
 // Float cells, no distributions: every child of a parent receives the SAME value (old / n, or a
@@ -1434,6 +1510,8 @@ struct Launch {
                                  const Remap &r, hipStream_t stream);
   static hipError_t drilldown(bool has_status, const T *in, const int32_t *st_in, T *out, int32_t *st_out,
                               const DrillDown &a, hipStream_t stream);
+  static hipError_t drilldown_rows(bool has_status, int vec, const T *in, const int32_t *st_in, T *out, int32_t *st_out,
+                                   const DrillUpAxis &a, int divide, int use_rounding, uint32_t longest_group, hipStream_t stream);
   static hipError_t drilldown_scale(bool has_status, const T *in, const int32_t *st_in, T *q, const DrillDownScale &a,
                                     hipStream_t stream);
   static hipError_t canonicalize(T *values, int32_t *status, uint64_t n, int def_nan, int use_status,
@@ -1662,7 +1740,12 @@ hipError_t Launch<T>::gather(bool has_status, int vec, const T *in, const int32_
                              const Remap &r, hipStream_t stream) {
   if (r.total == 0) return hipSuccess;
   const unsigned grid = grid_for(r.total);
-#define OLAP_G(HS, V) hipLaunchKernelGGL((gather_kernel<T, HS, V>), grid, kBlock, 0, stream, in, st_in, out, st_out, r)
+  const bool idx32 = r.total * (uint64_t)vec < 0xFFFFFFFFull;
+#define OLAP_G(HS, V)                                                                                                        \
+  do {                                                                                                                       \
+    if (idx32) hipLaunchKernelGGL((gather_kernel<T, HS, V, uint32_t>), grid, kBlock, 0, stream, in, st_in, out, st_out, r);  \
+    else hipLaunchKernelGGL((gather_kernel<T, HS, V, uint64_t>), grid, kBlock, 0, stream, in, st_in, out, st_out, r);        \
+  } while (0)
   if (has_status) {
     if (vec == 4) OLAP_G(true, 4); else if (vec == 2) OLAP_G(true, 2); else OLAP_G(true, 1);
   } else {
@@ -1743,6 +1826,23 @@ hipError_t Launch<T>::drilldown(bool has_status, const T *in, const int32_t *st_
   const unsigned grid = grid_for(a.total);
   if (has_status) hipLaunchKernelGGL((drilldown_kernel<T, true>), grid, kBlock, 0, stream, in, st_in, out, st_out, a);
   else hipLaunchKernelGGL((drilldown_kernel<T, false>), grid, kBlock, 0, stream, in, st_in, out, st_out, a);
+  return hipGetLastError();
+}
+
+template <typename T>
+hipError_t Launch<T>::drilldown_rows(bool has_status, int vec, const T *in, const int32_t *st_in, T *out, int32_t *st_out,
+                                     const DrillUpAxis &a, int divide, int use_rounding, uint32_t longest_group, hipStream_t stream) {
+  const uint32_t segments = (longest_group + kChildrenPerBlock - 1) / kChildrenPerBlock;
+  const uint64_t blocks = a.outer * a.G * a.blocks_per_row * segments;
+  if (blocks == 0) return hipSuccess;
+  if (blocks >= 0x7FFFFFFFull) return hipErrorInvalidValue;
+#define OLAP_DD(HS, V) hipLaunchKernelGGL((drilldown_rows_kernel<T, HS, V>), (unsigned)blocks, kBlock, 0, stream, in, st_in, out, st_out, a, divide, use_rounding, segments)
+  if (has_status) {
+    if (vec == 4) OLAP_DD(true, 4); else if (vec == 2) OLAP_DD(true, 2); else OLAP_DD(true, 1);
+  } else {
+    if (vec == 4) OLAP_DD(false, 4); else if (vec == 2) OLAP_DD(false, 2); else OLAP_DD(false, 1);
+  }
+#undef OLAP_DD
   return hipGetLastError();
 }
 

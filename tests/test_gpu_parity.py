@@ -507,3 +507,34 @@ def test_plans_replay_inside_a_hip_graph():
     torch.cuda.synchronize()
     assert torch.allclose(bufs[-1], eager * 2, rtol=1e-6)
     assert abs(float(eager.item()) - float(vals.astype(np.float64).sum())) <= 1e-5 * float(vals.sum())
+
+
+@pytest.mark.parametrize("type_name,default", [("float32", 0.0), ("float32", float("nan")), ("int32", 0.0), ("uint32", float("nan")), ("float64", 0.0)])
+@pytest.mark.parametrize("method", ["sum", "average"])
+def test_drilldown_row_form(type_name, default, method):
+    """One refined axis with wide rows (drilldown_rows_kernel): contiguous and interleaved child lists,
+    integer remainder spreading by child ordinal, unset / zero / NaN parents skipped."""
+    rng = np.random.default_rng(21)
+    for child_map in (np.repeat(np.arange(4), [3, 1, 5, 3]), np.arange(12) % 4):
+        old_len, new_len = [3, 4, 520], [3, 12, 520]
+        n_old = int(np.prod(old_len))
+        vals = rng.integers(-40, 90, size=n_old).astype(np.float64)
+        if type_name == "uint32":
+            vals = np.abs(vals)
+        if type_name.startswith("float"):
+            vals = vals * 0.5
+        dense = np.where(rng.random(n_old) < 0.25, default, vals)
+        maps = [np.arange(3, dtype=np.uint32), child_map.astype(np.uint32), np.arange(520, dtype=np.uint32)]
+        plan = pkg.Plan.drilldown(type_name, default, method, old_len, new_len, maps)
+        assert plan.kernel_name == "drilldown_rows_kernel"
+        o = OracleStore(n_old, type_name, default)
+        typed = to_typed(dense, type_name).astype(np.float64)
+        if type_name in ("int32", "uint32") and default != default:
+            typed = np.where(np.isnan(dense), np.nan, typed)
+        o.set_data(typed)
+        ev, es = expected_typed(o.drill_down(old_len, new_len, maps, method))
+        g = pkg.HipStore(n_old, type_name, default)
+        g.set_data_f64(dense)
+        out = g.drill_down(old_len, new_len, maps, method)
+        assert np.array_equal(out.get_status(), es)
+        assert same_typed(out.get_data(), ev)

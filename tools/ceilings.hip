@@ -65,6 +65,15 @@ __global__ __launch_bounds__(256) void copy_tile(const f4 *__restrict__ in, f4 *
   }
 }
 
+template <bool NT>
+__global__ __launch_bounds__(256) void write_tile(f4 *__restrict__ out, uint64_t n4) {
+  const f4 v = {1.f, 2.f, 3.f, 4.f};
+  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (uint64_t)gridDim.x * 256) {
+    if constexpr (NT) __builtin_nontemporal_store(v, out + i);
+    else out[i] = v;
+  }
+}
+
 struct V {
   std::string name;
   std::function<void()> fn;
@@ -101,6 +110,13 @@ int main() {
   ADD_READ(1, false) ADD_READ(2, false) ADD_READ(4, false) ADD_READ(8, false)
   ADD_READ(2, true) ADD_READ(4, true)
   ADD_COPY(1, false) ADD_COPY(2, false) ADD_COPY(4, false) ADD_COPY(4, true)
+  for (unsigned g : {2048u, 8192u, 97657u}) {
+    char nm[96];
+    snprintf(nm, sizeof nm, "write nt=0 grid=%u", g);
+    vs.push_back({nm, [=] { hipLaunchKernelGGL((write_tile<false>), g, 256, 0, 0, (f4 *)out, n4); }, N * 4.0, {}});
+    snprintf(nm, sizeof nm, "write nt=1 grid=%u", g);
+    vs.push_back({nm, [=] { hipLaunchKernelGGL((write_tile<true>), g, 256, 0, 0, (f4 *)out, n4); }, N * 4.0, {}});
+  }
   auto run = [&](V &v, int iters) {
     CK(hipEventRecord(e0));
     for (int i = 0; i < iters; ++i) v.fn();
