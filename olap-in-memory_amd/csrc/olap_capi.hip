@@ -1171,7 +1171,9 @@ extern "C" int olap_drilldown_plan(olap_plan **out, int dtype, int default_kind,
     p->dev_err = (unsigned long long *)ev;
     a.err = p->dev_err;
   }
-  p->kernel_name = p->dd_rows ? "drilldown_rows_kernel" : (p->dd_two_pass ? "drilldown_scale_kernel+gather_kernel" : "drilldown_kernel");
+  const bool dd_lines = p->dd_rows && !(method == OLAP_SUM && p->dd.use_rounding) && (size_t)p->vec * olap_dtype_size(dtype) == 16 &&
+                        (p->axis.inner * olap_dtype_size(dtype)) % 128 != 0;
+  p->kernel_name = p->dd_rows ? (dd_lines ? "drilldown_rows_lines_kernel" : "drilldown_rows_kernel") : (p->dd_two_pass ? "drilldown_scale_kernel+gather_kernel" : "drilldown_kernel");
   *out = p;
   return OLAP_OK;
 }
@@ -1239,7 +1241,13 @@ static int run_typed(olap_plan *p, const void *in_v, const int32_t *in_s, void *
         if (!a.aligned16) vec = 1;
         a.n_vec = a.inner / (uint64_t)vec;
         a.blocks_per_row = (a.n_vec + kBlock - 1) / kBlock;
-        e = Launch<T>::drilldown_rows(hs, vec, in, in_s, out, out_s, a, p->method == OLAP_SUM, p->dd.use_rounding, p->dd_longest, stream);
+        const bool divide = p->method == OLAP_SUM;
+        const bool spread = divide && p->dd.use_rounding;
+        // rows off the 128-byte grid: store line-aligned windows from LDS (drilldown_rows_lines_kernel)
+        if (!spread && vec * sizeof(T) == 16 && (a.inner * sizeof(T)) % 128 != 0 && !getenv("OLAP_DD_NO_LINES"))
+          e = Launch<T>::drilldown_rows_lines(hs, in, in_s, out, out_s, a, divide, p->dd_longest, stream);
+        else
+          e = Launch<T>::drilldown_rows(hs, vec, in, in_s, out, out_s, a, divide, p->dd.use_rounding, p->dd_longest, stream);
         break;
       }
       if (p->dd_two_pass) {

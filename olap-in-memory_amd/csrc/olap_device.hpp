@@ -223,6 +223,18 @@ __device__ __forceinline__ bool cell_is_set(T v, int32_t st, bool has_status, bo
   return (!has_status || (st & OLAP_STATUS_SET)) && !Cell<T>::is_default(v, def_nan);
 }
 
+// Workgroups are dealt to the 8 XCDs round-robin (workgroup b runs on XCD b % 8) and each XCD has its own
+// L2.  Mapping b -> logical id so that every XCD owns one CONTIGUOUS range of logical ids keeps
+// neighbouring tiles (which share the 128-byte lines at their edges whenever a row is not line-aligned)
+// inside one L2, where partial-line writes merge instead of reaching HBM twice.
+__device__ __forceinline__ uint32_t xcd_contiguous(uint32_t b, uint32_t n) {
+  constexpr uint32_t kXcd = 8;
+  const uint32_t q = n / kXcd, r = n % kXcd;
+  const uint32_t x = b % kXcd, i = b / kXcd;
+  return x * q + (x < r ? x : r) + i;
+}
+
+
 // mulberry32 at stream position n (1-based draw index): state = seed + n * 0x6D2B79F5
 __device__ __host__ __forceinline__ double mulberry32_at(uint32_t seed, uint64_t n) {
   uint32_t a = seed + (uint32_t)(n * 0x6D2B79F5ull);

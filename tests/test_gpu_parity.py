@@ -515,8 +515,13 @@ def test_drilldown_row_form(type_name, default, method):
     """One refined axis with wide rows (drilldown_rows_kernel): contiguous and interleaved child lists,
     integer remainder spreading by child ordinal, unset / zero / NaN parents skipped."""
     rng = np.random.default_rng(21)
-    for child_map in (np.repeat(np.arange(4), [3, 1, 5, 3]), np.arange(12) % 4):
-        old_len, new_len = [3, 4, 520], [3, 12, 520]
+    # inner 520 / 2600: rows off the 128-byte grid (float cells take drilldown_rows_lines_kernel, one and
+    # several windows per row); 1024: line-aligned rows; 19 children: more than one segment per parent
+    cases = [(np.repeat(np.arange(4), [3, 1, 5, 3]), 520), (np.arange(12) % 4, 520), (np.arange(12) % 4, 2600),
+             (np.repeat(np.arange(4), [3, 1, 5, 3]), 1024), (np.repeat(np.arange(2), [19, 2]), 2056)]
+    for child_map, inner in cases:
+        G, K = int(child_map.max()) + 1, len(child_map)
+        old_len, new_len = [3, G, inner], [3, K, inner]
         n_old = int(np.prod(old_len))
         vals = rng.integers(-40, 90, size=n_old).astype(np.float64)
         if type_name == "uint32":
@@ -524,9 +529,10 @@ def test_drilldown_row_form(type_name, default, method):
         if type_name.startswith("float"):
             vals = vals * 0.5
         dense = np.where(rng.random(n_old) < 0.25, default, vals)
-        maps = [np.arange(3, dtype=np.uint32), child_map.astype(np.uint32), np.arange(520, dtype=np.uint32)]
+        maps = [np.arange(3, dtype=np.uint32), child_map.astype(np.uint32), np.arange(inner, dtype=np.uint32)]
         plan = pkg.Plan.drilldown(type_name, default, method, old_len, new_len, maps)
-        assert plan.kernel_name == "drilldown_rows_kernel"
+        lines = type_name.startswith("float") and (inner * np.dtype(type_name).itemsize) % 128 != 0
+        assert plan.kernel_name == ("drilldown_rows_lines_kernel" if lines else "drilldown_rows_kernel")
         o = OracleStore(n_old, type_name, default)
         typed = to_typed(dense, type_name).astype(np.float64)
         if type_name in ("int32", "uint32") and default != default:
