@@ -1197,6 +1197,7 @@ static int run_typed(olap_plan *p, const void *in_v, const int32_t *in_s, void *
       a.n_vec = a.inner / (uint64_t)vec;
       a.total = a.outer * a.G * a.n_vec;
       a.blocks_per_row = (a.n_vec + kBlock - 1) / kBlock;
+      { const char *x = getenv("OLAP_XCD_ORDER"); a.xcd_order = x ? atoi(x) : 1; }  // 0: A/B against the dispatch order
       if (p->reduce.S > 0) {
         e = Launch<T>::drillup_reduce(p->method, hs, in, in_s, out, out_s, a, p->reduce, stream);
         break;

@@ -29,6 +29,7 @@ struct DrillUpAxis {
   const uint32_t *gstart; // device
   int def_nan;
   int aligned16;          // every buffer of this launch is 16 B aligned
+  int xcd_order;          // row regime: walk workgroups in XCD-contiguous order
 };
 
 // Per-lane accumulator of VEC adjacent output cells.  Additive/product methods run Agg<> in
@@ -114,8 +115,9 @@ __global__ __launch_bounds__(kBlock) void drillup_rows_kernel(const T *__restric
                                                               const DrillUpAxis a) {
   // blocks_per_row = ceil(n_vec / kBlock); blockIdx.x = og * blocks_per_row + chunk  (uniform math)
   const uint32_t bpr = (uint32_t)a.blocks_per_row;
-  const uint64_t og = blockIdx.x / bpr;
-  const uint32_t chunk = blockIdx.x - (uint32_t)og * bpr;
+  const uint32_t bid = a.xcd_order ? xcd_contiguous(blockIdx.x, gridDim.x) : blockIdx.x;
+  const uint64_t og = bid / bpr;
+  const uint32_t chunk = bid - (uint32_t)og * bpr;
   const uint64_t g = og % a.G;
   const uint64_t o = og / a.G;
   const uint64_t iv = (uint64_t)chunk * kBlock + threadIdx.x;

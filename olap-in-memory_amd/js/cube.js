@@ -161,7 +161,7 @@ class Cube {
       return new Array(this.storeSize).fill(expression.evaluate(params));
     }
     const program = expression.compile(inputs, scalars);
-    return Array.from(backend.load().evalFormula(program.code, program.consts, stores, Float64Array.from(totals)));
+    return HipStore.toPlainArray(backend.load().evalFormula(program.code, program.consts, stores, Float64Array.from(totals)));
   }
 
   copyStoredMeasure(measureId, copyMeasureId) {

@@ -1,0 +1,28 @@
+#!/bin/bash
+# Runs on the GPU box (gpurun -- 'bash tools/evidence.sh'): GPU parity tests, smoke, the default bench line,
+# and the three rocprofv3 passes the roofline object is checked against (kernel trace + stats, then
+# FETCH_SIZE and WRITE_SIZE each in their own --pmc pass).  Everything lands in gpurun_out/;
+# `python tools/summarize_profiles.py <tag>` condenses it into profiles/ afterwards.
+set -o pipefail
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+O=$R/gpurun_out
+mkdir -p "$O"
+rm -rf "$O/prof_kt" "$O/prof_fetch" "$O/prof_write"
+cd "$R" || exit 1
+timeout -k 10 600 python -m pytest tests -m gpu -x -q > "$O/pytest_gpu.log" 2>&1 || { tail -20 "$O/pytest_gpu.log"; exit 1; }
+tail -1 "$O/pytest_gpu.log"
+timeout -k 10 120 python -c 'import __graft_entry__ as g; g.smoke(); print("smoke ok")' > "$O/smoke.log" 2>&1 || { tail -20 "$O/smoke.log"; exit 1; }
+tail -1 "$O/smoke.log"
+timeout -k 10 120 node tests/js/gpu_test.js > "$O/js_gpu.log" 2>&1 || { tail -20 "$O/js_gpu.log"; exit 1; }
+tail -1 "$O/js_gpu.log"
+timeout -k 10 400 python bench.py > "$O/bench.json" 2> "$O/bench_err.log" || { tail -20 "$O/bench_err.log"; exit 1; }
+cat "$O/bench.json"
+cd /tmp && export TMPDIR=/tmp
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof_kt" -- python3 "$R/bench.py" --steps 100 --warmup 10 --no-cpu-baseline > "$O/prof_kt.log" 2>&1 || { tail -5 "$O/prof_kt.log"; exit 1; }
+timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$O/prof_fetch" -- python3 "$R/bench.py" --steps 20 --warmup 2 --no-cpu-baseline > "$O/prof_fetch.log" 2>&1 || { tail -5 "$O/prof_fetch.log"; exit 1; }
+timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$O/prof_write" -- python3 "$R/bench.py" --steps 20 --warmup 2 --no-cpu-baseline > "$O/prof_write.log" 2>&1 || { tail -5 "$O/prof_write.log"; exit 1; }
+cd "$R"
+timeout -k 10 300 python tools/sweep.py > "$O/sweep.txt" 2>&1 && tail -3 "$O/sweep.txt"
+timeout -k 10 200 python tools/dd_bench.py > "$O/dd_bench.txt" 2>&1 && tail -5 "$O/dd_bench.txt"
+timeout -k 10 200 node tools/js_bench.js > "$O/js_bench.txt" 2>&1 && tail -5 "$O/js_bench.txt"
+echo evidence done

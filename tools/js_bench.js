@@ -48,6 +48,7 @@ console.log(`[10]^8 collapse(): ${(Number(process.hrtime.bigint() - t) / 1e3).to
 const small = cubeOf(10, 4); // the reference benchmark's cube: 4^10 cells
 small.fillData('measure0', 1);
 time('4^10 slice(dimension0, all, all)   [test/cube-benchmark.js:38]', () => small.slice('dimension0', 'all', 'all'), 200);
-time('4^10 dice(dimension2, 2 of 4)      [test/cube-benchmark.js:83]', () => small.dice('dimension2', 'root', ['dimension2-item2', 'dimension2-item3']).getData('measure0').length, 50);
+time('4^10 dice(dimension2, 2 of 4)      [test/cube-benchmark.js:83]', () => small.dice('dimension2', 'root', ['dimension2-item2', 'dimension2-item3']).getTotal('measure0'), 50);
+time('4^10 dice(...).getData() -> plain Array of 524288 numbers     ', () => small.dice('dimension2', 'root', ['dimension2-item2', 'dimension2-item3']).getData('measure0').length, 20);
 time('4^10 collapse()                    [test/cube-benchmark.js:59]', () => small.collapse(), 50);
 time('4^10 reorderDimensions(reverse)    [test/cube-benchmark.js:71]', () => small.reorderDimensions(small.dimensionIds.slice().reverse()), 50);

@@ -33,10 +33,12 @@ rows = list(csv.DictReader(open(trace)))
 HEAD_KT, HEAD_PMC = 10 + 2 * 100, 2 + 2 * 20
 big = {}
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+# the headline kernel instantiation = the first 10^8-cell drillUp launch bench.py issues
+HEADNAME = next(r["Kernel_Name"] for r in rows if int(r["Grid_Size_X"]) == BIG_GRID and "drillup_rows_kernel" in r["Kernel_Name"])
 for r in rows:
     if int(r["Grid_Size_X"]) == BIG_GRID and "drillup_rows_kernel" in r["Kernel_Name"]:
         lst = big.setdefault(r["Kernel_Name"], [])
-        if len(lst) < (HEAD_KT if "false, 4, 4, true, true" in r["Kernel_Name"] else 10 ** 9):
+        if len(lst) < (HEAD_KT if r["Kernel_Name"] == HEADNAME else 10 ** 9):
             lst.append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
 lines = ["rocprofv3 --kernel-trace, dispatches of the 10^8-cell drillUp (grid %d lanes), ns" % BIG_GRID]
 summary = {}
@@ -54,7 +56,7 @@ def counter(dirname, name):
     for r in recs:
         if r["Counter_Name"] == name and int(r["Grid_Size"]) == BIG_GRID:
             lst = per.setdefault(r["Kernel_Name"], [])
-            if len(lst) < (HEAD_PMC if "false, 4, 4, true, true" in r["Kernel_Name"] else 10 ** 9):
+            if len(lst) < (HEAD_PMC if r["Kernel_Name"] == HEADNAME else 10 ** 9):
                 lst.append(float(r["Counter_Value"]))
     return {k: statistics.median(v) for k, v in per.items()}
 
@@ -64,7 +66,7 @@ traffic = {}
 for k in fetch:
     traffic[k] = {"FETCH_SIZE_KiB": fetch[k], "WRITE_SIZE_KiB": write.get(k),
                   "hbm_bytes": 2 * fetch[k] * 1024 + write.get(k, 0) * 1024}
-head = [k for k in traffic if "false, 4, 4, true, true" in k]
+head = [k for k in traffic if k == HEADNAME]
 doc = {"note": "HBM bytes per launch = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 (separate --pmc passes, gfx950 FETCH_SIZE x2 correction)",
        "kernels": traffic, "hbm_bytes_per_launch": traffic[head[0]]["hbm_bytes"] if head else None}
 json.dump(doc, open(os.path.join(PROF, "traffic_%s.json" % tag), "w"), indent=1)
