@@ -22,10 +22,17 @@ PROF = os.path.join(ROOT, "profiles")
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 BIG_GRID = 2500096  # ceil(10^8/10/4/256) workgroups x 256 lanes
 
+
+
+def newest(pattern):
+    """gpurun merges every call's files into gpurun_out/, so earlier runs' outputs linger: take the latest."""
+    return max(glob.glob(pattern), key=os.path.getmtime)
+
+
 os.makedirs(PROF, exist_ok=True)
-stats = glob.glob(os.path.join(OUT, "prof_kt", "*", "*_kernel_stats.csv"))[0]
+stats = newest(os.path.join(OUT, "prof_kt", "*", "*_kernel_stats.csv"))
 shutil.copy(stats, os.path.join(PROF, "kernel_stats_%s.csv" % tag))
-trace = glob.glob(os.path.join(OUT, "prof_kt", "*", "*_kernel_trace.csv"))[0]
+trace = newest(os.path.join(OUT, "prof_kt", "*", "*_kernel_trace.csv"))
 rows = list(csv.DictReader(open(trace)))
 # bench.py issues the headline launches first: warmup + steps (timed loop) + steps (kernel-only loop);
 # later launches of the same kernel (config 3 / config 5 extras) can share the grid size, so only
@@ -50,7 +57,7 @@ print("\n".join(lines))
 
 
 def counter(dirname, name):
-    f = glob.glob(os.path.join(OUT, dirname, "*", "*_counter_collection.csv"))[0]
+    f = newest(os.path.join(OUT, dirname, "*", "*_counter_collection.csv"))
     per = {}
     recs = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
     for r in recs:
