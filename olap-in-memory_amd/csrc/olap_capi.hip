@@ -392,6 +392,7 @@ extern "C" int olap_drillup_plan(olap_plan **out, int dtype, int default_kind, i
         uint64_t S;
         if (a.inner <= 128) {
           const uint64_t groups = a.outer * a.G;
+          // measured (tools/sweep2.py): more, shorter segments lose to the per-unit epilogue, fewer leave CUs idle
           const uint64_t by_grid = (4096 + groups - 1) / groups;                              // >= ~4 K units
           const uint64_t by_work = std::max<uint64_t>(1, (uint64_t)longest * a.inner / 8192);  // >= 8 K cells each
           S = std::max<uint64_t>(1, std::min(by_grid, by_work));
@@ -428,7 +429,7 @@ extern "C" int olap_drillup_plan(olap_plan **out, int dtype, int default_kind, i
       }
     }
     if (p->reduce.S > 0)
-      p->kernel_name = p->reduce.vec4   ? "drillup_reduce4_kernel+drillup_merge_kernel"
+      p->kernel_name = p->reduce.vec4   ? (p->reduce.S == 1 ? "drillup_reduce4_kernel" : "drillup_reduce4_kernel+drillup_merge_kernel")
                        : p->reduce.rows ? "drillup_reduce_kernel+drillup_merge_kernel"
                                         : "drillup_split_kernel+drillup_merge_kernel";
     else if (a.inner / (uint64_t)p->vec >= 128) p->kernel_name = "drillup_rows_kernel";

@@ -385,6 +385,61 @@ struct DrillUpReduce {
   Partial *part;      // [outer*G*inner * S]
 };
 
+// Partial state -> output cell (what drillup_merge_kernel does after merging the segments).
+template <typename T, int METHOD>
+__device__ __forceinline__ void partial_finish(const Partial &p, bool def_nan, T &ov, int32_t &os) {
+  Agg<METHOD> agg;
+  agg.acc = p.acc;
+  agg.has = (p.meta & 0x80000000u) != 0;
+  agg.count = p.meta & 0x7FFFFFFFu;
+  agg.finish(def_nan);
+  emit_cell<T>(agg.acc, agg.has, def_nan, ov, os);
+  if constexpr (METHOD == OLAP_PARTIAL_AVERAGE) os = (int32_t)agg.count;
+}
+
+// Lane-to-lane merge step of the reduce regime.  FAST (sum / average over a 0 default, no mask): the
+// state is (running sum, count of non-zero contributions) and merging is two adds — the `set` bit
+// is derived once at the end (partial_seal).  A wave64 VALU instruction costs 4 cycles and a unit
+// runs 6-8 of these levels per element, so the generic partial_merge (~40 instructions) is kept
+// for the methods that need it.
+template <int METHOD, bool FAST>
+__device__ __forceinline__ void partial_merge_lane(Partial &a, uint32_t delta, bool def_nan) {
+  Partial q;
+  q.acc = __shfl_down(a.acc, delta, 64);
+  q.meta = __shfl_down(a.meta, delta, 64);
+  if constexpr (METHOD == OLAP_FIRST || METHOD == OLAP_LAST) q.pos = __shfl_down(a.pos, delta, 64);
+  else q.pos = 0;
+  if constexpr (FAST) {
+    a.acc += q.acc;
+    a.meta += q.meta;
+  } else {
+    partial_merge<METHOD>(a, q, def_nan);
+  }
+}
+
+template <int METHOD, bool FAST>
+__device__ __forceinline__ void partial_merge_fast(Partial &a, const Partial &q, bool def_nan) {
+  if constexpr (FAST) {
+    a.acc += q.acc;
+    a.meta += q.meta;
+  } else {
+    partial_merge<METHOD>(a, q, def_nan);
+  }
+}
+
+// FAST accumulators count contributions without the `set` bit; this adds it.
+__device__ __forceinline__ void partial_seal(Partial &p) {
+  p.meta = (p.meta & 0x7FFFFFFFu) | ((p.meta != 0 && p.acc != 0.0) ? 0x80000000u : 0u);
+}
+
+__device__ __forceinline__ Partial partial_shfl_down(const Partial &p, uint32_t delta) {
+  Partial q;
+  q.acc = __shfl_down(p.acc, delta, 64);
+  q.meta = __shfl_down(p.meta, delta, 64);
+  q.pos = __shfl_down(p.pos, delta, 64);
+  return q;
+}
+
 // One UNIT (a wavefront for short segments, a whole workgroup for long ones) per (outer, group,
 // segment); its lanes cover `rows` consecutive members x `inner` cells per step, i.e. consecutive
 // memory for contiguous groups: coalesced however small `inner` is.
@@ -461,6 +516,7 @@ __global__ __launch_bounds__(kBlock) void drillup_reduce_kernel(const T *__restr
 template <typename T, int METHOD, bool HAS_STATUS, bool FAST>
 __global__ __launch_bounds__(kBlock) void drillup_reduce4_kernel(const T *__restrict__ in,
                                                                  const int32_t *__restrict__ st_in,
+                                                                 T *__restrict__ out, int32_t *__restrict__ st_out,
                                                                  const DrillUpAxis a, const DrillUpReduce rd) {
   __shared__ Partial lds[kBlock * 4];
   const uint32_t inner = (uint32_t)a.inner;
@@ -515,26 +571,111 @@ __global__ __launch_bounds__(kBlock) void drillup_reduce4_kernel(const T *__rest
       }
     }
   }
+  // When rows line up with lanes (inner a multiple of 4, or 1 / 2) the rows of a step are merged
+  // lane to lane: row r + s of a step sits s*inner/4 lanes further on.  Distances below 64 are wave
+  // shuffles; a workgroup-wide unit first folds its upper waves through LDS (two levels at most).
+  // Idle lanes hold the identity.  With one segment per group the result is final and leaves from here.
+  const bool by_shuffle = inner % 4 == 0 || inner <= 2;
+  if (by_shuffle) {
+    uint32_t m, top;  // lanes per row, rows spread over the unit's lanes
+    uint32_t ne = 4;  // accumulators per lane still in play
+    if (inner <= 2) {
+      if (inner == 1) {
+        partial_merge_fast<METHOD, FAST>(p[0], p[1], def_nan);
+        partial_merge_fast<METHOD, FAST>(p[2], p[3], def_nan);
+        partial_merge_fast<METHOD, FAST>(p[0], p[2], def_nan);
+      } else {
+        partial_merge_fast<METHOD, FAST>(p[0], p[2], def_nan);
+        partial_merge_fast<METHOD, FAST>(p[1], p[3], def_nan);
+      }
+      m = 1;
+      top = rd.unit;
+      ne = inner;
+    } else {
+      m = inner / 4;
+      top = rd.rows;
+    }
+    for (uint32_t s = top >> 1; s > 0; s >>= 1) {
+      const uint32_t d = s * m;
+      if (d >= 64) {  // only for rd.unit == kBlock: the whole workgroup is one unit
 #pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    if constexpr (FAST) p[e].meta = (p[e].meta & 0x7FFFFFFFu) | ((p[e].meta != 0 && p[e].acc != 0.0) ? 0x80000000u : 0u);
-    lds[lds_base + lane * 4 + e] = p[e];
+        for (int e = 0; e < 4; ++e)
+          if ((uint32_t)e < ne) lds[threadIdx.x * 4 + e] = p[e];
+        __syncthreads();
+        if (threadIdx.x < d) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if ((uint32_t)e < ne) partial_merge_fast<METHOD, FAST>(p[e], lds[(threadIdx.x + d) * 4 + e], def_nan);
+        }
+        __syncthreads();
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if ((uint32_t)e < ne) partial_merge_lane<METHOD, FAST>(p[e], d, def_nan);
+      }
+    }
+    if constexpr (FAST) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) partial_seal(p[e]);
+    }
+    if (live && lane * 4 < inner) {
+      if (rd.S == 1) {
+        if (inner % 4 == 0) {
+          Vec<T, 4> ov;
+          Vec<int32_t, 4> os;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) partial_finish<T, METHOD>(p[e], def_nan, ov.v[e], os.v[e]);
+          store_vec<T, 4>(out + o * a.inner + lane * 4, ov);
+          if (st_out) store_vec<int32_t, 4>(st_out + o * a.inner + lane * 4, os);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {  // constant indices: p[] must stay in registers
+            if ((uint32_t)e < inner) {
+              T ov;
+              int32_t os;
+              partial_finish<T, METHOD>(p[e], def_nan, ov, os);
+              out[o * a.inner + e] = ov;
+              if (st_out) st_out[o * a.inner + e] = os;
+            }
+          }
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (lane * 4 + e < inner) rd.part[(o * a.inner + lane * 4 + e) * rd.S + seg] = p[e];
+      }
+    }
+    return;  // the whole workgroup takes this path
   }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) lds[lds_base + lane * 4 + e] = p[e];
   __syncthreads();
   // tree over the rows of a step: flat slot f = r*inner + i
   for (uint32_t s = rd.rows >> 1; s > 0; s >>= 1) {
     if (live) {
       for (uint32_t f = lane; f < s * inner; f += rd.unit) {
         Partial x = lds[lds_base + f];
-        const Partial y = lds[lds_base + f + s * inner];
-        partial_merge<METHOD>(x, y, def_nan);
+        partial_merge_fast<METHOD, FAST>(x, lds[lds_base + f + s * inner], def_nan);
         lds[lds_base + f] = x;
       }
     }
     __syncthreads();
   }
-  if (live)
-    for (uint32_t i = lane; i < inner; i += rd.unit) rd.part[(o * a.inner + i) * rd.S + seg] = lds[lds_base + i];
+  if (live) {
+    for (uint32_t i = lane; i < inner; i += rd.unit) {
+      Partial x = lds[lds_base + i];
+      if constexpr (FAST) partial_seal(x);
+      if (rd.S == 1) {
+        T ov;
+        int32_t os;
+        partial_finish<T, METHOD>(x, def_nan, ov, os);
+        out[o * a.inner + i] = ov;
+        if (st_out) st_out[o * a.inner + i] = os;
+      } else {
+        rd.part[(o * a.inner + i) * rd.S + seg] = x;
+      }
+    }
+  }
 }
 
 // Lane-per-(cell, segment) form for wide `inner` (> 128): lanes along `inner` are already coalesced.
@@ -606,18 +747,67 @@ __global__ __launch_bounds__(kBlock) void drillup_merge_kernel(T *__restrict__ o
     partial_merge<METHOD>(p, q, def_nan);
   }
   if (lane == 0) {
-    Agg<METHOD> agg;
-    agg.acc = p.acc;
-    agg.has = (p.meta & 0x80000000u) != 0;
-    agg.count = p.meta & 0x7FFFFFFFu;
-    agg.finish(def_nan);
     T ov;
     int32_t os;
-    emit_cell<T>(agg.acc, agg.has, def_nan, ov, os);
-    if constexpr (METHOD == OLAP_PARTIAL_AVERAGE) os = (int32_t)agg.count;
+    partial_finish<T, METHOD>(p, def_nan, ov, os);
     out[cell] = ov;
     if (st_out) st_out[cell] = os;
   }
+}
+
+// Many segments (S >= 512, i.e. very few output cells): one WORKGROUP per output cell, 4 partials in
+// flight per lane — a single wavefront walking 4096 partials 64 at a time is a 30 us latency chain.
+template <typename T, int METHOD>
+__global__ __launch_bounds__(kBlock) void drillup_merge_block_kernel(T *__restrict__ out, int32_t *__restrict__ st_out,
+                                                                     const DrillUpAxis a, const DrillUpReduce rd) {
+  __shared__ Partial wave_part[kBlock / 64];
+  const uint64_t cell = blockIdx.x;
+  const bool def_nan = a.def_nan != 0;
+  const Partial *src = rd.part + cell * rd.S;
+  Partial p = partial_identity<METHOD>();
+  constexpr uint32_t U = 4;
+  for (uint32_t s0 = threadIdx.x; s0 < rd.S; s0 += kBlock * U) {
+    Partial q[U];
+#pragma unroll
+    for (uint32_t u = 0; u < U; ++u) {
+      const uint32_t si = s0 + u * kBlock;
+      q[u] = si < rd.S ? src[si] : partial_identity<METHOD>();
+    }
+#pragma unroll
+    for (uint32_t u = 0; u < U; ++u) partial_merge<METHOD>(p, q[u], def_nan);
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const Partial q = partial_shfl_down(p, off);
+    partial_merge<METHOD>(p, q, def_nan);
+  }
+  if ((threadIdx.x & 63) == 0) wave_part[threadIdx.x >> 6] = p;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (uint32_t w = 1; w < kBlock / 64; ++w) partial_merge<METHOD>(p, wave_part[w], def_nan);
+    T ov;
+    int32_t os;
+    partial_finish<T, METHOD>(p, def_nan, ov, os);
+    out[cell] = ov;
+    if (st_out) st_out[cell] = os;
+  }
+}
+
+// Few segments (S <= 16): one LANE per output cell merges them in order; stores are coalesced.
+template <typename T, int METHOD>
+__global__ __launch_bounds__(kBlock) void drillup_merge_few_kernel(T *__restrict__ out, int32_t *__restrict__ st_out,
+                                                                   const DrillUpAxis a, const DrillUpReduce rd) {
+  const uint64_t cell = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (cell >= a.outer * a.G * a.inner) return;
+  const bool def_nan = a.def_nan != 0;
+  Partial p = rd.part[cell * rd.S];
+  for (uint32_t s = 1; s < rd.S; ++s) partial_merge<METHOD>(p, rd.part[cell * rd.S + s], def_nan);
+  T ov;
+  int32_t os;
+  partial_finish<T, METHOD>(p, def_nan, ov, os);
+  out[cell] = ov;
+  if (st_out) st_out[cell] = os;
 }
 
 // ======================================================================= K1g: drillUp, any maps
@@ -1748,9 +1938,10 @@ static hipError_t drillup_reduce_launch(bool has_status, const T *in, const int3
     const uint64_t upb = kBlock / rd.unit;
     const unsigned grid = (unsigned)((a.outer * a.G * rd.S + upb - 1) / upb);
     if (rd.vec4 && a.aligned16 && sizeof(T) == 4) {
-      if (has_status) hipLaunchKernelGGL((drillup_reduce4_kernel<T, METHOD, true, false>), grid, kBlock, 0, stream, in, st_in, a, rd);
-      else if (kAdditive && fast) hipLaunchKernelGGL((drillup_reduce4_kernel<T, METHOD, false, kAdditive>), grid, kBlock, 0, stream, in, st_in, a, rd);
-      else hipLaunchKernelGGL((drillup_reduce4_kernel<T, METHOD, false, false>), grid, kBlock, 0, stream, in, st_in, a, rd);
+      if (has_status) hipLaunchKernelGGL((drillup_reduce4_kernel<T, METHOD, true, false>), grid, kBlock, 0, stream, in, st_in, out, st_out, a, rd);
+      else if (kAdditive && fast) hipLaunchKernelGGL((drillup_reduce4_kernel<T, METHOD, false, kAdditive>), grid, kBlock, 0, stream, in, st_in, out, st_out, a, rd);
+      else hipLaunchKernelGGL((drillup_reduce4_kernel<T, METHOD, false, false>), grid, kBlock, 0, stream, in, st_in, out, st_out, a, rd);
+      if (rd.S == 1) return hipGetLastError();  // one segment per group: the result left from the reduction
     } else {
       DrillUpReduce r1 = rd;
       if (rd.vec4) {  // plan sized `rows` for 16 B lanes; the scalar form covers unit cells per step
@@ -1768,7 +1959,9 @@ static hipError_t drillup_reduce_launch(bool has_status, const T *in, const int3
     else if (kAdditive && fast) hipLaunchKernelGGL((drillup_split_kernel<T, METHOD, false, kAdditive>), grid, kBlock, 0, stream, in, st_in, a, rd);
     else hipLaunchKernelGGL((drillup_split_kernel<T, METHOD, false, false>), grid, kBlock, 0, stream, in, st_in, a, rd);
   }
-  hipLaunchKernelGGL((drillup_merge_kernel<T, METHOD>), grid_for(cells * 64), kBlock, 0, stream, out, st_out, a, rd);
+  if (rd.S <= 16) hipLaunchKernelGGL((drillup_merge_few_kernel<T, METHOD>), grid_for(cells), kBlock, 0, stream, out, st_out, a, rd);
+  else if (rd.S >= 512) hipLaunchKernelGGL((drillup_merge_block_kernel<T, METHOD>), (unsigned)cells, kBlock, 0, stream, out, st_out, a, rd);
+  else hipLaunchKernelGGL((drillup_merge_kernel<T, METHOD>), grid_for(cells * 64), kBlock, 0, stream, out, st_out, a, rd);
   return hipGetLastError();
 }
 

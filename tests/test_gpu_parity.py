@@ -394,6 +394,43 @@ def test_reduce_regime_shapes(lens, axis, method):
     assert same_typed(out.get_data(), ev)
 
 
+@pytest.mark.parametrize("lens,axis", [([5000, 300], 1), ([4200, 260, 4], 1), ([1000, 264, 8], 1), ([3, 40000, 2], 1), ([100000], 0),
+                                       ([2000000], 0), ([400000, 10], 0), ([2, 40000, 64], 1), ([70000, 128], 0), ([3, 1000, 12], 1)])
+@pytest.mark.parametrize("method", ["sum", "average", "first", "last", "highest", "lowest", "product"])
+@pytest.mark.parametrize("type_name,default", [("float32", 0.0), ("float32", float("nan")), ("uint32", float("nan"))])
+def test_reduce_regime_to_all(lens, axis, method, type_name, default):
+    """'-> all' roll-ups of contiguous rows with few output cells: the 16-byte cooperative form
+    (drillup_reduce4_kernel) in each of its geometries — wave-shuffle row merge (inner 1, 2, 4, 8, 12, 64)
+    and LDS tree (inner 10, 128), one segment per group (result written by the reduction itself), a few
+    segments (lane-per-cell merge) and hundreds (wave-per-cell merge), with and without the status mask."""
+    rng = np.random.default_rng(17)
+    n = int(np.prod(lens))
+    if method == "product":
+        vals = np.where(rng.random(n) < 0.5, 1.0, -1.0) if type_name == "float32" else np.ones(n)
+        vals = vals * np.where(rng.random(n) < 4.0 / lens[axis], 2.0, 1.0)
+    else:
+        vals = rng.integers(0 if type_name == "uint32" else -8, 9, size=n).astype(np.float64)
+        if type_name == "float32":
+            vals = vals * 0.5
+    dense = np.where(rng.random(n) < 0.4, default, vals)
+    new = list(lens)
+    new[axis] = 1
+    maps = [np.zeros(l, np.uint32) if i == axis else np.arange(l, dtype=np.uint32) for i, l in enumerate(lens)]
+    plan = pkg.Plan.drillup(type_name, default, method, lens, new, maps)
+    assert "reduce" in plan.kernel_name, plan.kernel_name
+    o = OracleStore(n, type_name, default)
+    typed = to_typed(dense, type_name).astype(np.float64)
+    if type_name == "uint32":
+        typed = np.where(np.isnan(dense), np.nan, typed)
+    o.set_data(typed)
+    ev, es = expected_typed(o.drill_up(lens, new, maps, method))
+    g = pkg.HipStore(n, type_name, default)
+    g.set_data_f64(dense)
+    out = g.drill_up(lens, new, maps, method)
+    assert np.array_equal(out.get_status(), es)
+    assert same_typed(out.get_data(), ev)
+
+
 @pytest.mark.parametrize("type_name,default", [("float32", 0.0), ("float32", float("nan")), ("uint32", float("nan")), ("float64", 0.0), ("int32", 0.0)])
 def test_sparse_form_round_trip(type_name, default):
     """Device-side stream compaction (the reference's serialised layout, in-memory.js:94-100) and back."""
