@@ -434,7 +434,7 @@ extern "C" int olap_drillup_plan(olap_plan **out, int dtype, int default_kind, i
                                         : "drillup_split_kernel+drillup_merge_kernel";
     else if (a.inner / (uint64_t)p->vec >= 128) p->kernel_name = "drillup_rows_kernel";
     else if (a.inner < 128 && a.K * a.inner <= (16 * 1024) / olap_dtype_size(dtype) && a.K * a.inner > 0 &&
-             (a.G + 1 + a.K) * 4 <= 16 * 1024)
+             (a.G + 1 + (contiguous ? 0 : a.K)) * 4 <= 16 * 1024)
       p->kernel_name = "drillup_tile_kernel";  // (the launcher re-checks alignment; may still pick the flat form)
     else p->kernel_name = "drillup_flat_kernel";
   } else {

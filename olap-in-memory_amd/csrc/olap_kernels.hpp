@@ -222,9 +222,11 @@ struct DrillUpTile {
 
 constexpr uint32_t kTileBytes = 16 * 1024;  // cells staged per workgroup: 8 workgroups (32 waves) per CU
 
-// ALL: one group holding every member in order (the '-> all' roll-ups of slice / removeDimension /
-// collapse): no table reads at all.  Otherwise the CSR is copied to LDS once per workgroup.
-template <typename T, int METHOD, bool HAS_STATUS, bool FAST, bool ALL>
+// MODE 1 (ALL): one group holding every member in order (the '-> all' roll-ups of slice /
+// removeDimension / collapse): no table reads at all.  MODE 2: groups are contiguous member runs
+// (calendars, attribute roll-ups of sorted items): only gstart[G+1] goes to LDS.  MODE 0: gstart and
+// the member list are copied to LDS once per workgroup.
+template <typename T, int METHOD, bool HAS_STATUS, bool FAST, int MODE>
 __global__ __launch_bounds__(kBlock) void drillup_tile_kernel(const T *__restrict__ in,
                                                               const int32_t *__restrict__ st_in,
                                                               T *__restrict__ out,
@@ -237,10 +239,11 @@ __global__ __launch_bounds__(kBlock) void drillup_tile_kernel(const T *__restric
   T *tile = reinterpret_cast<T *>(lds_raw);
   int32_t *stile = reinterpret_cast<int32_t *>(lds_raw + kTileBytes);
   uint32_t *csr = reinterpret_cast<uint32_t *>(lds_raw + kTileBytes + (HAS_STATUS ? kCells * 4 : 0));
+  constexpr bool ALL = MODE == 1;
   uint32_t *l_gstart = csr;                 // G + 1 entries
-  uint32_t *l_order = csr + a.G + 1;        // K entries (identity when a.order == nullptr)
+  uint32_t *l_order = csr + a.G + 1;        // K entries (MODE 0 only)
 
-  const uint64_t row0 = (uint64_t)blockIdx.x * tl.rows_per_tile;
+  const uint64_t row0 = (uint64_t)(a.xcd_order ? xcd_contiguous(blockIdx.x, gridDim.x) : blockIdx.x) * tl.rows_per_tile;
   const uint32_t rows = (uint32_t)((a.outer - row0) < tl.rows_per_tile ? (a.outer - row0) : tl.rows_per_tile);
   const uint32_t n_in = rows * tl.row_elems;
   const T *src = in + row0 * tl.row_elems;
@@ -261,7 +264,8 @@ __global__ __launch_bounds__(kBlock) void drillup_tile_kernel(const T *__restric
   }
   if constexpr (!ALL) {
     for (uint32_t i = threadIdx.x; i <= a.G; i += kBlock) l_gstart[i] = a.gstart[i];
-    for (uint32_t i = threadIdx.x; i < a.K; i += kBlock) l_order[i] = a.order ? a.order[i] : i;
+    if constexpr (MODE == 0)
+      for (uint32_t i = threadIdx.x; i < a.K; i += kBlock) l_order[i] = a.order[i];
   }
 #pragma unroll
   for (int u = 0; u < NL; ++u) {
@@ -296,7 +300,7 @@ __global__ __launch_bounds__(kBlock) void drillup_tile_kernel(const T *__restric
     for (; j + UJ <= jend; j += UJ) {
 #pragma unroll
       for (int u = 0; u < UJ; ++u) {
-        const uint32_t k = ALL ? (j + u) : l_order[j + u];
+        const uint32_t k = MODE == 0 ? l_order[j + u] : (j + u);
         x[u].v[0] = tile[base + k * tl.inner];
         sx[u].v[0] = HAS_STATUS ? stile[base + k * tl.inner] : OLAP_STATUS_SET;
       }
@@ -304,7 +308,7 @@ __global__ __launch_bounds__(kBlock) void drillup_tile_kernel(const T *__restric
       for (int u = 0; u < UJ; ++u) lane.add_row(x[u], sx[u], def_nan);
     }
     for (; j < jend; ++j) {
-      const uint32_t k = ALL ? j : l_order[j];
+      const uint32_t k = MODE == 0 ? l_order[j] : j;
       x[0].v[0] = tile[base + k * tl.inner];
       sx[0].v[0] = HAS_STATUS ? stile[base + k * tl.inner] : OLAP_STATUS_SET;
       lane.add_row(x[0], sx[0], def_nan);
@@ -1839,7 +1843,7 @@ static hipError_t drillup_axis_launch(const T *in, const int32_t *st_in, T *out,
     // of every cache line): whole rows of K*inner cells staged per workgroup, kTileBytes of cells
     const uint64_t row_elems = a.K * a.inner;
     const uint64_t budget = kTileBytes / sizeof(T);
-    const uint64_t csr_bytes = (a.G + 1 + a.K) * 4;
+    const uint64_t csr_bytes = (a.G + 1 + (contig ? 0 : a.K)) * 4;
     // rows per tile: as many as fit; every tile must start 16 B aligned, i.e. R*row_elems % V == 0
     uint64_t R = row_elems ? budget / row_elems : 0;
     constexpr uint64_t V = 16 / sizeof(T);
@@ -1857,11 +1861,14 @@ static hipError_t drillup_axis_launch(const T *in, const int32_t *st_in, T *out,
       const bool all = contig && a.G == 1;
       const size_t lds = kTileBytes + (HS ? budget * 4 : 0) + (all ? 0 : csr_bytes);
       if (tiles < 0x7FFFFFFFull) {
-#define OLAP_TILE(F, A) hipLaunchKernelGGL((drillup_tile_kernel<T, METHOD, HS, F, A>), (unsigned)tiles, kBlock, lds, stream, in, st_in, out, st_out, a, tl)
+#define OLAP_TILE(F, M) hipLaunchKernelGGL((drillup_tile_kernel<T, METHOD, HS, F, M>), (unsigned)tiles, kBlock, lds, stream, in, st_in, out, st_out, a, tl)
         if constexpr (kAdditive && !HS) {
-          if (fast) { if (all) OLAP_TILE(true, true); else OLAP_TILE(true, false); return hipGetLastError(); }
+          if (fast) {
+            if (all) OLAP_TILE(true, 1); else if (contig) OLAP_TILE(true, 2); else OLAP_TILE(true, 0);
+            return hipGetLastError();
+          }
         }
-        if (all) OLAP_TILE(false, true); else OLAP_TILE(false, false);
+        if (all) OLAP_TILE(false, 1); else if (contig) OLAP_TILE(false, 2); else OLAP_TILE(false, 0);
 #undef OLAP_TILE
         return hipGetLastError();
       }
