@@ -799,14 +799,46 @@ extern "C" int olap_reorder_plan(olap_plan **out, int dtype, int default_kind, i
     for (int d = 0; d < n; ++d) by_in[d] = by_out[d] = d;
     std::sort(by_in.begin(), by_in.end(), [&](int x, int y) { return m[x].stride < m[y].stride; });
     std::sort(by_out.begin(), by_out.end(), [&](int x, int y) { return out_stride[x] < out_stride[y]; });
+    // First choice, the 16-byte form (reorder_brick4_kernel): on each side take whole dimensions from
+    // the fastest one until the contiguous run is >= 64 cells and a multiple of 4 (the last one taken
+    // may be a divisor of its dimension), so no brick is ragged and every run is whole 16 B groups.
+    std::vector<uint32_t> chunk(n, 1);
+    bool quad_chunks = olap_dtype_size(dtype) == 4 && !getenv("OLAP_BRICK_NO_QUAD");
+    if (quad_chunks) {
+      auto grow_quad = [&](const std::vector<int> &order) {
+        uint64_t prod = 1;
+        for (int d : order) {
+          if (prod >= 64 && prod % 4 == 0) break;
+          uint32_t pick = m[d].len;
+          for (uint32_t c = 1; c <= m[d].len && c <= 4096; ++c)
+            if (m[d].len % c == 0 && prod * c >= 64 && (prod * c) % 4 == 0) {
+              pick = c;
+              break;
+            }
+          chunk[d] = std::max(chunk[d], pick);
+          prod *= chunk[d];
+          if (chunk[d] != m[d].len) break;  // a partial dimension ends the contiguous run
+        }
+        return prod >= 16 && prod % 4 == 0;
+      };
+      quad_chunks = grow_quad(by_in) && grow_quad(by_out);
+      uint64_t e = 1;
+      int active = 0;
+      for (int d = 0; d < n; ++d) {
+        e *= chunk[d];
+        active += chunk[d] > 1;
+        if (m[d].len % chunk[d] != 0) quad_chunks = false;
+      }
+      if (e > 12288 || active > 4) quad_chunks = false;  // 48 KiB of cells per brick (54 KiB padded)
+    }
     // tuning knobs (developer use): OLAP_BRICK_TARGET = run length aimed at in both orders,
     // OLAP_BRICK_CAP = cells per brick
     uint64_t cap = (32 * 1024) / olap_dtype_size(dtype) / 2;  // 16 KiB of float32
     uint32_t first_target = 64;
     if (const char *e = getenv("OLAP_BRICK_TARGET")) first_target = (uint32_t)std::max(4, atoi(e));
     if (const char *e = getenv("OLAP_BRICK_CAP")) cap = (uint64_t)std::max(64, atoi(e));
-    std::vector<uint32_t> chunk(n, 1);
-    for (uint32_t target = first_target; target >= 4; target /= 2) {
+    if (quad_chunks) cap = 12288;
+    for (uint32_t target = first_target; target >= 4 && !quad_chunks; target /= 2) {
       std::fill(chunk.begin(), chunk.end(), 1u);
       auto grow = [&](const std::vector<int> &order) {
         uint64_t prod = 1;
@@ -856,7 +888,7 @@ extern "C" int olap_reorder_plan(olap_plan **out, int dtype, int default_kind, i
       span_in += (uint64_t)(chunk[d] - 1) * m[d].stride;
       span_out += (uint64_t)(chunk[d] - 1) * out_stride[d];
     }
-    if (bricks < 0x7FFFFFFFull && elems <= cap && act_rd.size() <= 4 && small_chunks && span_in < 0xFFFFFFFFull &&
+    if (bricks < 0x7FFFFFFFull && elems <= cap && act_rd.size() <= 4 && (small_chunks || !ragged) && span_in < 0xFFFFFFFFull &&
         span_out < 0xFFFFFFFFull) {
       b.n_act = (int)act_rd.size();
       for (int k = 0; k < 4; ++k) b.act_dim[k] = k < b.n_act ? act_rd[k] : -1;
@@ -906,6 +938,30 @@ extern "C" int olap_reorder_plan(olap_plan **out, int dtype, int default_kind, i
         wr_dig[f] = dig;
         wr_lds[f] = pos;
       }
+      // 16-byte form: groups of 4 cells adjacent and aligned on both sides, for every brick
+      bool quad = quad_chunks && !ragged && elems % 4 == 0 && lds_stride.size() > 0;
+      for (int d = 0; d < n && quad; ++d)
+        if (b.nblk[d] > 1 && (((uint64_t)chunk[d] * m[d].stride) % 4 != 0 || ((uint64_t)chunk[d] * out_stride[d]) % 4 != 0)) quad = false;
+      for (uint64_t q = 0; q < elems / 4 && quad; ++q)
+        for (uint32_t j = 0; j < 4; ++j)
+          if (rd_off[4 * q] % 4 != 0 || rd_off[4 * q + j] != rd_off[4 * q] + j || wr_off[4 * q] % 4 != 0 || wr_off[4 * q + j] != wr_off[4 * q] + j) quad = false;
+      const size_t scalar_words = tabs.size();
+      if (quad) {
+        auto pad4 = [](uint32_t e) { return e + ((e >> 5) << 2); };
+        if (pad4((uint32_t)elems) > 0xFFFFu) quad = false;
+        else {
+          tabs.resize(scalar_words + (elems / 4) * 4);  // rd_off4, wr_off4, wr_pos4 (2 words each)
+          uint32_t *base = tabs.data();
+          uint32_t *rd4 = base + scalar_words, *wr4 = rd4 + elems / 4, *pos4 = wr4 + elems / 4;
+          for (uint64_t q = 0; q < elems / 4; ++q) {
+            rd4[q] = base[4 * q];                // rd_off
+            wr4[q] = base[elems + 4 * q];        // wr_off
+            const uint32_t *lp = base + 2 * elems + 4 * q;  // wr_lds
+            pos4[2 * q] = pad4(lp[0]) | (pad4(lp[1]) << 16);
+            pos4[2 * q + 1] = pad4(lp[2]) | (pad4(lp[3]) << 16);
+          }
+        }
+      }
       if ((rc = upload(&p->dev_tab, tabs.data(), tabs.size() * sizeof(uint32_t)))) {
         olap_plan_destroy(p);
         return rc;
@@ -916,9 +972,13 @@ extern "C" int olap_reorder_plan(olap_plan **out, int dtype, int default_kind, i
       b.wr_lds = dev + 2 * elems;
       b.rd_dig = dev + 3 * elems;
       b.wr_dig = dev + 4 * elems;
+      b.quad = quad ? 1 : 0;
+      b.rd_off4 = quad ? dev + scalar_words : nullptr;
+      b.wr_off4 = quad ? dev + scalar_words + elems / 4 : nullptr;
+      b.wr_pos4 = quad ? (const uint2 *)(dev + scalar_words + 2 * (elems / 4)) : nullptr;
       p->kind = PLAN_BRICK;
       p->n_bricks = bricks;
-      p->kernel_name = "reorder_brick_kernel";
+      p->kernel_name = quad ? "reorder_brick4_kernel" : "reorder_brick_kernel";
       *out = p;
       return OLAP_OK;
     }

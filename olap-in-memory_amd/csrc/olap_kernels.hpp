@@ -1092,6 +1092,12 @@ struct Brick {
   const uint32_t *wr_lds;   // [elems] read-order position e of cell f (where it sits in LDS)
   const uint32_t *rd_dig;   // [elems] digits of cell e in the active dims, one byte each
   const uint32_t *wr_dig;   // [elems] same for cell f
+  // 16-byte form (reorder_brick4_kernel): every source run and every destination run of a brick is
+  // a whole number of aligned 4-cell groups and no brick is ragged
+  int quad;
+  const uint32_t *rd_off4;  // [elems/4] source offset of read group q (cells 4q..4q+3 in read order)
+  const uint32_t *wr_off4;  // [elems/4] destination offset of write group f
+  const uint2 *wr_pos4;     // [elems/4] padded LDS positions of the 4 cells of write group f, 16 bits each
 };
 
 __device__ __forceinline__ uint32_t lds_pad(uint32_t e) { return e + (e >> 5); }
@@ -1189,6 +1195,94 @@ __global__ __launch_bounds__(1024) void reorder_brick_kernel(const T *__restrict
         const bool set = cell_is_set<T>(x, HAS_STATUS ? stile[lds_pad(pos[u])] : OLAP_STATUS_SET, HAS_STATUS, def_nan);
         dst[off[u]] = set ? x : Cell<T>::default_value(def_nan);
         if (sdst) sdst[off[u]] = set ? OLAP_STATUS_SET : 0;
+      }
+    }
+  }
+}
+
+// 16-byte form.  Cells 4q..4q+3 of the read order are adjacent in the source (one 16 B load, one
+// 16 B LDS store); a write group is 4 adjacent destination cells whose LDS positions come packed
+// from the table.  LDS position of read-order cell e: e + 4*(e/32) (keeps groups 16 B aligned and
+// rotates the banks every 32 cells).
+__device__ __forceinline__ uint32_t lds_pad4(uint32_t e) { return e + ((e >> 5) << 2); }
+
+template <typename T, bool HAS_STATUS>
+__global__ __launch_bounds__(1024) void reorder_brick4_kernel(const T *__restrict__ in,
+                                                                const int32_t *__restrict__ st_in,
+                                                                T *__restrict__ out,
+                                                                int32_t *__restrict__ st_out, const Brick b) {
+  static_assert(sizeof(T) == 4, "16-byte groups of 4 cells");
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  T *tile = reinterpret_cast<T *>(lds_raw);
+  int32_t *stile = reinterpret_cast<int32_t *>(lds_raw + (size_t)lds_pad4(b.elems) * 4);
+  uint64_t c = xcd_contiguous(blockIdx.x, gridDim.x), base_in = 0, base_out = 0;
+#pragma unroll
+  for (int d = kMaxDims - 1; d >= 0; --d) {
+    if (d < b.nd) {
+      const uint32_t origin = (uint32_t)(c % b.nblk[d]) * b.chunk[d];
+      c /= b.nblk[d];
+      base_in += (uint64_t)origin * b.in_stride[d];
+      base_out += (uint64_t)origin * b.out_stride[d];
+    }
+  }
+  const bool def_nan = b.def_nan != 0;
+  const T *src = in + base_in;
+  const int32_t *ssrc = HAS_STATUS ? st_in + base_in : nullptr;
+  const uint32_t nq = b.elems >> 2;
+  constexpr int UB = 4;
+  const uint32_t nthreads = blockDim.x;  // 512: a 10^4-cell brick leaves room for 3 workgroups per CU, so each must bring many waves
+  for (uint32_t q0 = threadIdx.x; q0 < nq; q0 += nthreads * UB) {
+    uint32_t off[UB];
+    Vec<T, 4> x[UB];
+    Vec<int32_t, 4> sx[UB];
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+      const uint32_t q = q0 + u * nthreads;
+      off[u] = q < nq ? b.rd_off4[q] : 0u;
+    }
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+      if (q0 + u * nthreads < nq) {
+        x[u] = load_stream<T, 4>(src + off[u]);
+        if constexpr (HAS_STATUS) sx[u] = load_stream<int32_t, 4>(ssrc + off[u]);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+      const uint32_t q = q0 + u * nthreads;
+      if (q < nq) {
+        *reinterpret_cast<Vec<T, 4> *>(tile + lds_pad4(q * 4)) = x[u];
+        if constexpr (HAS_STATUS) *reinterpret_cast<Vec<int32_t, 4> *>(stile + lds_pad4(q * 4)) = sx[u];
+      }
+    }
+  }
+  __syncthreads();
+  T *dst = out + base_out;
+  int32_t *sdst = st_out ? st_out + base_out : nullptr;
+  for (uint32_t f0 = threadIdx.x; f0 < nq; f0 += nthreads * UB) {
+    uint32_t off[UB];
+    uint2 pk[UB];
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+      const uint32_t f = f0 + u * nthreads;
+      off[u] = f < nq ? b.wr_off4[f] : 0u;
+      pk[u] = f < nq ? b.wr_pos4[f] : make_uint2(0u, 0u);
+    }
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+      if (f0 + u * nthreads < nq) {
+        const uint32_t pos[4] = {pk[u].x & 0xFFFFu, pk[u].x >> 16, pk[u].y & 0xFFFFu, pk[u].y >> 16};
+        Vec<T, 4> ov;
+        Vec<int32_t, 4> os;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const T x = tile[pos[e]];
+          const bool set = cell_is_set<T>(x, HAS_STATUS ? stile[pos[e]] : OLAP_STATUS_SET, HAS_STATUS, def_nan);
+          ov.v[e] = set ? x : Cell<T>::default_value(def_nan);
+          os.v[e] = set ? OLAP_STATUS_SET : 0;
+        }
+        store_stream<T, 4>(dst + off[u], ov);
+        if (sdst) store_stream<int32_t, 4>(sdst + off[u], os);
       }
     }
   }
@@ -1891,6 +1985,10 @@ static hipError_t drillup_axis_launch(const T *in, const int32_t *st_in, T *out,
         return hipGetLastError();
       }
     }
+    if (HS && shallow) {  // values + mask: two wide streams per row already, one row in flight (155 -> 147 us)
+      if (contig) OLAP_ROWS1(true, false); else OLAP_ROWS1(false, false);
+      return hipGetLastError();
+    }
     if (contig) OLAP_ROWS(true, false); else OLAP_ROWS(false, false);
   } else {
     if constexpr (kAdditive && !HS) {
@@ -2080,10 +2178,41 @@ template <typename T>
 hipError_t Launch<T>::reorder_brick(bool has_status, const T *in, const int32_t *st_in, T *out, int32_t *st_out,
                                     const Brick &b, uint64_t n_bricks, hipStream_t stream) {
   if (n_bricks == 0) return hipSuccess;
+  if constexpr (sizeof(T) == 4) {
+    const bool aligned = (((uintptr_t)in | (uintptr_t)out | (uintptr_t)st_in | (uintptr_t)st_out) & 15u) == 0;
+    if (b.quad && aligned) {
+      const size_t padded = (size_t)(b.elems + ((b.elems >> 5) << 2)) * 4;
+      const size_t lds4 = padded * (has_status ? 2 : 1);
+      // above 64 KiB of dynamic LDS the kernel has to be told once (bricks of 10^4 cells with the mask: 90 KiB)
+      static bool raised = false;
+      if (!raised) {
+        hipError_t e1 = hipFuncSetAttribute((const void *)reorder_brick4_kernel<T, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+        hipError_t e2 = hipFuncSetAttribute((const void *)reorder_brick4_kernel<T, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+        if (e1 != hipSuccess) return e1;
+        if (e2 != hipSuccess) return e2;
+        raised = true;
+      }
+      unsigned threads4 = b.elems >= 4096 ? 512 : kBlock;
+      if (const char *e = getenv("OLAP_BRICK_THREADS")) threads4 = (unsigned)atoi(e);
+      if (has_status) hipLaunchKernelGGL((reorder_brick4_kernel<T, true>), (unsigned)n_bricks, threads4, lds4, stream, in, st_in, out, st_out, b);
+      else hipLaunchKernelGGL((reorder_brick4_kernel<T, false>), (unsigned)n_bricks, threads4, lds4, stream, in, st_in, out, st_out, b);
+      return hipGetLastError();
+    }
+  }
   const size_t cells = lds_pad_host(b.elems);
   const size_t lds = ((cells * sizeof(T) + 15) & ~(size_t)15) + (has_status ? cells * 4 : 0);
   unsigned threads = kBlock;  // larger workgroups for larger bricks bought nothing (tools/sweep.py)
   if (const char *e = getenv("OLAP_BRICK_THREADS")) threads = (unsigned)atoi(e);
+  if (lds > 48 * 1024) {  // bricks sized for the 16-byte form, run here because a buffer is not 16 B aligned
+    static bool raised_scalar = false;
+    if (!raised_scalar) {
+      hipError_t e1 = hipFuncSetAttribute((const void *)reorder_brick_kernel<T, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+      hipError_t e2 = hipFuncSetAttribute((const void *)reorder_brick_kernel<T, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+      if (e1 != hipSuccess) return e1;
+      if (e2 != hipSuccess) return e2;
+      raised_scalar = true;
+    }
+  }
   if (has_status) hipLaunchKernelGGL((reorder_brick_kernel<T, true>), (unsigned)n_bricks, threads, lds, stream, in, st_in, out, st_out, b);
   else hipLaunchKernelGGL((reorder_brick_kernel<T, false>), (unsigned)n_bricks, threads, lds, stream, in, st_in, out, st_out, b);
   return hipGetLastError();

@@ -431,6 +431,44 @@ def test_reduce_regime_to_all(lens, axis, method, type_name, default):
     assert same_typed(out.get_data(), ev)
 
 
+REORDER_CASES = [
+    ([10] * 6, [5, 4, 3, 2, 1, 0], "reorder_brick4_kernel"),          # runs of 100 cells on both sides
+    ([12, 7, 20], [2, 1, 0], "reorder_brick4_kernel"),                # one brick = the whole cube
+    ([64, 48], [1, 0], "reorder_brick4_kernel"),                      # partial dimension on the read side
+    ([1000, 1000], [1, 0], "reorder_brick4_kernel"),                  # 100 x 100 bricks
+    ([50, 100, 1000], [2, 0, 1], None),
+    ([37, 53], [1, 0], "reorder_brick_kernel"),                       # odd extents: ragged scalar bricks
+    ([6, 1, 5, 4], [3, 0, 2, 1], None),
+    ([3, 250, 9, 30], [1, 3, 0, 2], None),
+    ([20, 30, 40], [0, 2, 1], None),                                  # leading dimension untouched
+    ([20, 30, 40], [1, 0, 2], "gather(reorder)"),                     # fastest dimension untouched: 16 B gather
+]
+
+
+@pytest.mark.parametrize("lens,perm,kernel", REORDER_CASES)
+@pytest.mark.parametrize("type_name,default", [("float32", 0.0), ("int32", 0.0), ("uint32", float("nan")), ("float64", float("nan"))])
+def test_reorder_forms(lens, perm, kernel, type_name, default):
+    """reorder (in-memory.js:178-211) against numpy's transpose: the 16-byte brick form, the scalar
+    (ragged) brick form and the gather form, with and without the status mask."""
+    rng = np.random.default_rng(29)
+    n = int(np.prod(lens))
+    vals = rng.integers(1, 1000, size=n).astype(np.float64)
+    unset = rng.random(n) < 0.3
+    dense = np.where(unset, default, vals)
+    plan = pkg.Plan.reorder(type_name, default, lens, perm)
+    if kernel is not None and (type_name != "float64" or "brick4" not in kernel):
+        assert plan.kernel_name == kernel, plan.kernel_name
+    if type_name == "float64":
+        assert plan.kernel_name != "reorder_brick4_kernel"
+    g = pkg.HipStore(n, type_name, default)
+    g.set_data_f64(dense)
+    out = g.reorder(lens, perm)
+    moved = lambda a: np.ascontiguousarray(a.reshape(lens).transpose(perm)).ravel()  # noqa: E731
+    assert np.array_equal(out.get_status(), moved(g.get_status()))
+    assert same_typed(out.get_data(), moved(g.get_data()))
+    assert np.array_equal(out.get_status() == 2, moved(~unset))
+
+
 @pytest.mark.parametrize("type_name,default", [("float32", 0.0), ("float32", float("nan")), ("uint32", float("nan")), ("float64", 0.0), ("int32", 0.0)])
 def test_sparse_form_round_trip(type_name, default):
     """Device-side stream compaction (the reference's serialised layout, in-memory.js:94-100) and back."""

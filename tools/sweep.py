@@ -87,6 +87,12 @@ ms, gbs, k = bench(lambda: pkg.Plan.reorder("float32", 0.0, shape, [7, 6, 5, 4, 
 rows.append(("reorder reverse [10]^8", ms, gbs, k))
 ms, gbs, k = bench(lambda: pkg.Plan.reorder("float32", 0.0, shape, [1, 0, 2, 3, 4, 5, 6, 7]), n, n)
 rows.append(("reorder swap dim0/1", ms, gbs, k))
+ms, gbs, k = bench(lambda: pkg.Plan.reorder("float32", 0.0, [10000, 10000], [1, 0]), n, n)
+rows.append(("reorder transpose [1e4,1e4]", ms, gbs, k))
+ms, gbs, k = bench(lambda: pkg.Plan.reorder("float32", 0.0, [3652, 100, 274], [2, 1, 0]), n5, n5)
+rows.append(("reorder C5 [3652,100,274] reversed", ms, gbs, k))
+if "--only-reorder" in sys.argv:
+    rows = [r for r in rows if r[0].startswith("reorder")]
 month_of_day = day_to_month
 ms, gbs, k = bench(lambda: pkg.Plan.drilldown("float32", 0.0, "sum", [G, 100, 274], s5, [month_of_day, ident(100), ident(274)]), G * 27400, n5)
 rows.append(("drillDown month->day", ms, gbs, k))
