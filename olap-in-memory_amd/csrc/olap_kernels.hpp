@@ -1206,7 +1206,7 @@ __global__ __launch_bounds__(1024) void reorder_brick_kernel(const T *__restrict
 // rotates the banks every 32 cells).
 __device__ __forceinline__ uint32_t lds_pad4(uint32_t e) { return e + ((e >> 5) << 2); }
 
-template <typename T, bool HAS_STATUS>
+template <typename T, bool HAS_STATUS, int UB>
 __global__ __launch_bounds__(1024) void reorder_brick4_kernel(const T *__restrict__ in,
                                                                 const int32_t *__restrict__ st_in,
                                                                 T *__restrict__ out,
@@ -1229,7 +1229,6 @@ __global__ __launch_bounds__(1024) void reorder_brick4_kernel(const T *__restric
   const T *src = in + base_in;
   const int32_t *ssrc = HAS_STATUS ? st_in + base_in : nullptr;
   const uint32_t nq = b.elems >> 2;
-  constexpr int UB = 4;
   const uint32_t nthreads = blockDim.x;  // 512: a 10^4-cell brick leaves room for 3 workgroups per CU, so each must bring many waves
   for (uint32_t q0 = threadIdx.x; q0 < nq; q0 += nthreads * UB) {
     uint32_t off[UB];
@@ -2186,16 +2185,17 @@ hipError_t Launch<T>::reorder_brick(bool has_status, const T *in, const int32_t 
       // above 64 KiB of dynamic LDS the kernel has to be told once (bricks of 10^4 cells with the mask: 90 KiB)
       static bool raised = false;
       if (!raised) {
-        hipError_t e1 = hipFuncSetAttribute((const void *)reorder_brick4_kernel<T, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-        hipError_t e2 = hipFuncSetAttribute((const void *)reorder_brick4_kernel<T, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+        hipError_t e1 = hipFuncSetAttribute((const void *)reorder_brick4_kernel<T, true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+        hipError_t e2 = hipFuncSetAttribute((const void *)reorder_brick4_kernel<T, false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
         if (e1 != hipSuccess) return e1;
         if (e2 != hipSuccess) return e2;
         raised = true;
       }
-      unsigned threads4 = b.elems >= 4096 ? 512 : kBlock;
+      unsigned threads4 = kBlock;  // measured: 512 and 1024 lanes lose on the [10]^8 reversal, 512 gains 7 % on a 2-D transpose
       if (const char *e = getenv("OLAP_BRICK_THREADS")) threads4 = (unsigned)atoi(e);
-      if (has_status) hipLaunchKernelGGL((reorder_brick4_kernel<T, true>), (unsigned)n_bricks, threads4, lds4, stream, in, st_in, out, st_out, b);
-      else hipLaunchKernelGGL((reorder_brick4_kernel<T, false>), (unsigned)n_bricks, threads4, lds4, stream, in, st_in, out, st_out, b);
+      // groups in flight per lane: 2, 4 and 10 measure the same (the 400-byte runs, not latency, set the pace)
+      if (has_status) hipLaunchKernelGGL((reorder_brick4_kernel<T, true, 4>), (unsigned)n_bricks, threads4, lds4, stream, in, st_in, out, st_out, b);
+      else hipLaunchKernelGGL((reorder_brick4_kernel<T, false, 4>), (unsigned)n_bricks, threads4, lds4, stream, in, st_in, out, st_out, b);
       return hipGetLastError();
     }
   }
