@@ -80,6 +80,22 @@ function effectiveSelection(sel) {
   return Int32Array.from(sel, (old, j) => (old >= 0 && last.get(old) === j ? old : -1));
 }
 
+/**
+ * A pending selection keeps every dimension of its SOURCE store; the cube may meanwhile have
+ * dropped dimensions that were reduced to one item (slice = dice to one item + removeDimension).
+ * Returns, for each dimension the caller still sees, its position among the pending ones — the
+ * others are the dropped single-item dimensions — or null when the extents do not line up.
+ */
+function visibleDims(pending, lengths) {
+  const at = [];
+  let v = 0;
+  for (let d = 0; d < pending.midLen.length; ++d) {
+    if (v < lengths.length && pending.midLen[d] === lengths[v]) at[v++] = d;
+    else if (pending.midLen[d] !== 1) return null;
+  }
+  return v === lengths.length ? at : null;
+}
+
 class HipStore {
   /**
    * `native` is the addon Store, or — for the result of dice() — a pending selection
@@ -95,6 +111,7 @@ class HipStore {
     this._type = type;
     this._defaultValue = defaultValue;
     this._pending = null;
+    this._lent = false; // a pending dice elsewhere still reads this store's device buffer
     if (native && native.source) {
       this._pending = native;
       this._nativeStore = null;
@@ -110,6 +127,20 @@ class HipStore {
       const p = this._pending;
       this._nativeStore = p.source.dice(p.oldLen, p.midLen, p.sel);
       this._pending = null;
+    }
+    return this._nativeStore;
+  }
+
+  /**
+   * The device store for writing.  Pending dices read their source lazily, and the reference's
+   * dice() returns an independent copy: a store whose buffer has been lent out writes to a fresh
+   * copy and leaves the lent one to its readers (copy-on-write, at most once per lending).
+   */
+  get _writable() {
+    const native = this._native;
+    if (this._lent) {
+      this._nativeStore = native.clone();
+      this._lent = false;
     }
     return this._nativeStore;
   }
@@ -138,12 +169,12 @@ class HipStore {
   set data(values) {
     if (this._size !== values.length) throw new Error(`value length is invalid: ${this._size} !== ${values.length}`);
     if (ArrayBuffer.isView(values) && !(values instanceof Float64Array) && values.constructor.name.toLowerCase().startsWith(this._type)) {
-      this._native.setData(values); // a typed array of the store's own element type: no conversion
+      this._writable.setData(values); // a typed array of the store's own element type: no conversion
       return;
     }
     const d = this._defaultValue;
     // undefined / null unset the cell, exactly like the default value does (in-memory.js:122-133)
-    this._native.setData(toFloat64(values, d));
+    this._writable.setData(toFloat64(values, d));
   }
 
   clone() {
@@ -156,23 +187,35 @@ class HipStore {
   }
 
   setValue(index, value) {
-    this._native.setValue(index, value);
+    this._writable.setValue(index, value);
   }
 
   fill(value) {
-    if (value === undefined || value === null) this._native.fill(this._defaultValue);
-    else this._native.fill(value);
+    if (value === undefined || value === null) this._writable.fill(this._defaultValue);
+    else this._writable.fill(value);
   }
 
   /** in-memory.js:265-334 */
   drillUp(oldDimensions, newDimensions, method = 'sum') {
     const code = backend.load().methodFromName(method); // throws 'Unsupported aggregation method: <m>'
     const maps = newDimensions.map((dim, i) => Uint32Array.from(oldDimensions[i].getGroupIndexFromRootIndexMap(dim.rootAttribute)));
-    if (this._pending) {
+    const at = this._pending ? visibleDims(this._pending, lengthsOf(oldDimensions)) : null;
+    if (at) {
       const rolled = maps.filter((map, i) => map.length !== newDimensions[i].numItems || map.some((g, k) => g !== k)).length;
+      const p = this._pending;
+      // every group has exactly its own single member (e.g. the roll-up to 'all' of a dimension that
+      // a slice diced down to one item): the cells do not change, the selection stays pending and
+      // keeps composing — slice(...).dice(...).drillUp(...) becomes ONE launch over the source cube
+      if (rolled === 0) return new HipStore(this._size, this._type, this._defaultValue, { source: p.source, oldLen: p.oldLen, midLen: p.midLen, sel: p.sel });
       if (rolled <= 1) {
-        const p = this._pending;
-        return this._wrap(p.source.diceDrillUp(p.oldLen, p.midLen, lengthsOf(newDimensions), p.sel, maps, code));
+        // dimensions the cube has dropped keep their single item
+        const newLen = Uint32Array.from(p.midLen, () => 1);
+        const allMaps = Array.from(p.midLen, () => Uint32Array.of(0));
+        at.forEach((d, v) => {
+          newLen[d] = newDimensions[v].numItems;
+          allMaps[d] = maps[v];
+        });
+        return this._wrap(p.source.diceDrillUp(p.oldLen, p.midLen, newLen, p.sel, allMaps, code));
       }
     }
     return this._wrap(this._native.drillUp(lengthsOf(oldDimensions), lengthsOf(newDimensions), maps, code));
@@ -192,17 +235,23 @@ class HipStore {
       return Int32Array.from(dim.getItems(), (item) => (position[item] === undefined ? -1 : position[item]));
     });
     const midLen = lengthsOf(newDimensions);
-    let source = this._nativeStore;
-    let oldLen = lengthsOf(oldDimensions);
+    const size = midLen.reduce((n, l) => n * l, 1);
     let composed = sel.map(effectiveSelection);
-    if (this._pending) {
+    const at = this._pending ? visibleDims(this._pending, lengthsOf(oldDimensions)) : null;
+    if (at) {
       // dice of a pending dice: compose the selections, still nothing is materialised
       const p = this._pending;
-      source = p.source;
-      oldLen = p.oldLen;
-      composed = composed.map((s, d) => Int32Array.from(s, (j) => (j < 0 ? -1 : p.sel[d][j])));
+      const all = p.sel.slice();
+      const allLen = Uint32Array.from(p.midLen);
+      at.forEach((d, v) => {
+        all[d] = Int32Array.from(composed[v], (j) => (j < 0 ? -1 : p.sel[d][j]));
+        allLen[d] = midLen[v];
+      });
+      return new HipStore(size, this._type, this._defaultValue, { source: p.source, oldLen: p.oldLen, midLen: allLen, sel: all });
     }
-    return new HipStore(midLen.reduce((n, l) => n * l, 1), this._type, this._defaultValue, { source, oldLen, midLen, sel: composed });
+    const source = this._native; // (materialises a pending selection whose dimensions no longer line up)
+    this._lent = true;
+    return new HipStore(size, this._type, this._defaultValue, { source, oldLen: lengthsOf(oldDimensions), midLen, sel: composed });
   }
 
   /** in-memory.js:178-211 */
@@ -223,7 +272,7 @@ class HipStore {
       retyped.data = otherStore.data;
       otherStore = retyped;
     }
-    this._native.load(otherStore._native, lengthsOf(myDimensions), lengthsOf(hisDimensions), hisToMine);
+    this._writable.load(otherStore._native, lengthsOf(myDimensions), lengthsOf(hisDimensions), hisToMine);
   }
 
   /**

@@ -190,6 +190,29 @@ describe('pending dice (fused dice -> drillUp)', () => {
     const dup = cube.storedMeasures.antennas.dice(cube.dimensions, [new GenericDimension('location', 'city', ['paris', 'tokyo', 'paris']), cube.dimensions[1]]);
     assert.deepEqual(dup.data, [0, 0, 16, 32, 1, 2]);
   });
+  it('a slice stays pending and the whole slice -> dice -> drillUp chain is one selection over the source', () => {
+    const cube = testCube();
+    const winter = cube.slice('period', 'season', 'winter'); // dice to one item + roll-up of that single item
+    assert.ok(winter.storedMeasures.antennas._pending, 'the single-member roll-up moved no cells');
+    const chain = winter.dice('location', 'city', ['tokyo', 'paris']).drillUp('location', 'all');
+    assert.deepEqual(chain.getNestedArray('antennas'), [34]);
+    assert.deepEqual(winter.getNestedArray('antennas'), [2, 8, 32]);
+    assert.deepEqual(cube.slice('location', 'city', 'toledo').slice('period', 'season', 'summer').getNestedArray('routers'), 4);
+  });
+  it('a diced cube is independent of later writes to its source (copy-on-write of the lent buffer)', () => {
+    const cube = testCube();
+    const diced = cube.dice('location', 'city', ['paris', 'tokyo']);
+    const sliced = cube.slice('period', 'season', 'summer');
+    cube.setNestedArray('antennas', [[100, 200], [300, 400], [500, 600]]);
+    cube.storedMeasures.routers.setValue(0, 77);
+    assert.deepEqual(diced.getNestedArray('antennas'), [[1, 2], [16, 32]]);
+    assert.deepEqual(diced.getNestedArray('routers'), [[3, 2], [16, 32]]);
+    assert.deepEqual(sliced.getNestedArray('antennas'), [1, 4, 16]);
+    assert.deepEqual(cube.getNestedArray('antennas'), [[100, 200], [300, 400], [500, 600]]);
+    assert.deepEqual(cube.dice('location', 'city', ['toledo']).getNestedArray('antennas'), [[300, 400]]);
+    cube.fillData('antennas', 9);
+    assert.deepEqual(cube.getNestedArray('antennas'), [[9, 9], [9, 9], [9, 9]]);
+  });
 });
 
 describe('dimensions', () => {
