@@ -381,6 +381,44 @@ extern "C" int olap_drillup_plan(olap_plan **out, int dtype, int default_kind, i
     }
     a.gstart = (const uint32_t *)p->dev_tab;
     a.order = contiguous ? nullptr : (const uint32_t *)p->dev_tab + order_off;
+    // group-tile regime (drillup_gtile_kernel): contiguous groups, short row pieces, rows too long for
+    // the row-tile regime; the group list is cut into tiles of whole groups that fit kTileBytes
+    bool gtile_ok = false;
+    a.gtile = nullptr;
+    a.n_gtile = 0;
+    {
+      const uint64_t budget = kTileBytes / olap_dtype_size(dtype);
+      const uint64_t vcells = 16 / olap_dtype_size(dtype);
+      if (contiguous && a.G > 1 && a.inner > 0 && a.inner / (uint64_t)p->vec < 128 && a.K * a.inner > budget && !getenv("OLAP_NO_GTILE")) {
+        std::vector<uint32_t> cut{0};
+        uint64_t cells = 0;
+        uint32_t groups = 0;
+        bool fits = true;
+        for (uint32_t g = 0; g < a.G && fits; ++g) {
+          const uint64_t c = (uint64_t)(gstart[g + 1] - gstart[g]) * a.inner;
+          if (c > budget - vcells) fits = false;
+          if (cells + c > budget - vcells || groups == 1024) {
+            cut.push_back(g);
+            cells = 0;
+            groups = 0;
+          }
+          cells += c;
+          ++groups;
+        }
+        cut.push_back((uint32_t)a.G);
+        if (fits && a.outer * (cut.size() - 1) < 0x7FFFFFFFull) {
+          void *dev_cut = nullptr;
+          if ((rc = upload(&dev_cut, cut.data(), cut.size() * sizeof(uint32_t)))) {
+            olap_plan_destroy(p);
+            return rc;
+          }
+          p->owned.push_back(dev_cut);
+          a.gtile = (const uint32_t *)dev_cut;
+          a.n_gtile = (uint32_t)(cut.size() - 1);
+          gtile_ok = true;
+        }
+      }
+    }
     // few output cells and long groups: cooperative reduction of S segments per group (workspace
     // in the plan), see DrillUpReduce
     {
@@ -433,6 +471,7 @@ extern "C" int olap_drillup_plan(olap_plan **out, int dtype, int default_kind, i
                        : p->reduce.rows ? "drillup_reduce_kernel+drillup_merge_kernel"
                                         : "drillup_split_kernel+drillup_merge_kernel";
     else if (a.inner / (uint64_t)p->vec >= 128) p->kernel_name = "drillup_rows_kernel";
+    else if (gtile_ok) p->kernel_name = "drillup_gtile_kernel";
     else if (a.inner < 128 && a.K * a.inner <= (16 * 1024) / olap_dtype_size(dtype) && a.K * a.inner > 0 &&
              (a.G + 1 + (contiguous ? 0 : a.K)) * 4 <= 16 * 1024)
       p->kernel_name = "drillup_tile_kernel";  // (the launcher re-checks alignment; may still pick the flat form)

@@ -30,6 +30,8 @@ struct DrillUpAxis {
   int def_nan;
   int aligned16;          // every buffer of this launch is 16 B aligned
   int xcd_order;          // row regime: walk workgroups in XCD-contiguous order
+  const uint32_t *gtile;  // device, or nullptr: group-tile regime, first group of every tile [n_gtile + 1]
+  uint32_t n_gtile;
 };
 
 // Per-lane accumulator of VEC adjacent output cells.  Additive/product methods run Agg<> in
@@ -311,6 +313,102 @@ __global__ __launch_bounds__(kBlock) void drillup_tile_kernel(const T *__restric
       const uint32_t k = MODE == 0 ? l_order[j] : j;
       x[0].v[0] = tile[base + k * tl.inner];
       sx[0].v[0] = HAS_STATUS ? stile[base + k * tl.inner] : OLAP_STATUS_SET;
+      lane.add_row(x[0], sx[0], def_nan);
+    }
+    lane.template finish_and_store<false>(def_nan, dst, sdst, idx);
+  }
+}
+
+// Group-tile regime: contiguous groups (calendars) whose rows K*inner do not fit LDS — e.g. day ->
+// month on [100, 3652, 30].  The members of consecutive groups are consecutive memory, so a tile is a
+// run of whole GROUPS of one outer row (the plan cuts the group list into tiles of <= kTileBytes of
+// cells, table `gtile`), staged with 16 B loads from the aligned address below its first cell; the
+// reduction and the store are those of the row-tile kernel.
+template <typename T, int METHOD, bool HAS_STATUS, bool FAST>
+__global__ __launch_bounds__(kBlock) void drillup_gtile_kernel(const T *__restrict__ in,
+                                                               const int32_t *__restrict__ st_in,
+                                                               T *__restrict__ out,
+                                                               int32_t *__restrict__ st_out,
+                                                               const DrillUpAxis a, const uint64_t n_cells) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  constexpr int V = 16 / sizeof(T);
+  constexpr uint32_t kCells = kTileBytes / sizeof(T);
+  constexpr int NL = kCells / V / kBlock;
+  constexpr uint32_t kMaxGroups = 1024;  // groups per tile (plan-side limit)
+  T *tile = reinterpret_cast<T *>(lds_raw);
+  int32_t *stile = reinterpret_cast<int32_t *>(lds_raw + kTileBytes);
+  uint32_t *l_gstart = reinterpret_cast<uint32_t *>(lds_raw + kTileBytes + (HAS_STATUS ? kCells * 4 : 0));  // kMaxGroups + 1
+
+  const uint32_t bid = a.xcd_order ? xcd_contiguous(blockIdx.x, gridDim.x) : blockIdx.x;
+  const uint32_t t = bid % a.n_gtile;
+  const uint64_t o = bid / a.n_gtile;
+  const uint32_t g0 = a.gtile[t], g1 = a.gtile[t + 1];
+  const uint32_t ng = g1 - g0;
+  const uint32_t k0 = a.gstart[g0], k1 = a.gstart[g1];
+  const uint32_t inner = (uint32_t)a.inner;
+  const uint64_t first = (o * a.K + k0) * a.inner;        // first cell of the tile
+  const uint32_t n_in = (k1 - k0) * inner;                 // <= kCells - V
+  const uint64_t base = first & ~(uint64_t)(V - 1);        // 16 B aligned cell below it
+  const uint32_t shift = (uint32_t)(first - base);
+  const uint32_t n_vec = (shift + n_in + V - 1) / V;       // <= kCells / V
+  const bool def_nan = a.def_nan != 0;
+
+  Vec<T, V> v[NL];
+  Vec<int32_t, V> sv[NL];
+#pragma unroll
+  for (int u = 0; u < NL; ++u) {
+    const uint32_t i = threadIdx.x + u * kBlock;
+    if (i < n_vec) {
+      const uint64_t at = base + (uint64_t)i * V;
+      if (at + V <= n_cells) {
+        v[u] = load_stream<T, V>(in + at);
+        if constexpr (HAS_STATUS) sv[u] = load_stream<int32_t, V>(st_in + at);
+      } else {  // the very end of the buffer: cell by cell
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+          v[u].v[e] = at + e < n_cells ? in[at + e] : T(0);
+          if constexpr (HAS_STATUS) sv[u].v[e] = at + e < n_cells ? st_in[at + e] : 0;
+        }
+      }
+    }
+  }
+  for (uint32_t i = threadIdx.x; i <= ng; i += kBlock) l_gstart[i] = a.gstart[g0 + i] - k0;
+#pragma unroll
+  for (int u = 0; u < NL; ++u) {
+    const uint32_t i = threadIdx.x + u * kBlock;
+    if (i < n_vec) {
+      *reinterpret_cast<Vec<T, V> *>(tile + i * V) = v[u];
+      if constexpr (HAS_STATUS) *reinterpret_cast<Vec<int32_t, V> *>(stile + i * V) = sv[u];
+    }
+  }
+  __syncthreads();
+
+  const uint32_t n_out = ng * inner;
+  T *dst = out + (o * a.G + g0) * a.inner;
+  int32_t *sdst = st_out ? st_out + (o * a.G + g0) * a.inner : nullptr;
+  for (uint32_t idx = threadIdx.x; idx < n_out; idx += kBlock) {
+    const uint32_t g = idx / inner;
+    const uint32_t i = idx - g * inner;
+    const uint32_t at0 = shift + i;
+    Lane<T, METHOD, HAS_STATUS, 1, FAST> lane;
+    lane.init();
+    uint32_t j = l_gstart[g];
+    const uint32_t jend = l_gstart[g + 1];
+    constexpr int UJ = 4;
+    Vec<T, 1> x[UJ];
+    Vec<int32_t, 1> sx[UJ];
+    for (; j + UJ <= jend; j += UJ) {
+#pragma unroll
+      for (int u = 0; u < UJ; ++u) {
+        x[u].v[0] = tile[at0 + (j + u) * inner];
+        sx[u].v[0] = HAS_STATUS ? stile[at0 + (j + u) * inner] : OLAP_STATUS_SET;
+      }
+#pragma unroll
+      for (int u = 0; u < UJ; ++u) lane.add_row(x[u], sx[u], def_nan);
+    }
+    for (; j < jend; ++j) {
+      x[0].v[0] = tile[at0 + j * inner];
+      sx[0].v[0] = HAS_STATUS ? stile[at0 + j * inner] : OLAP_STATUS_SET;
       lane.add_row(x[0], sx[0], def_nan);
     }
     lane.template finish_and_store<false>(def_nan, dst, sdst, idx);
@@ -1966,6 +2064,18 @@ static hipError_t drillup_axis_launch(const T *in, const int32_t *st_in, T *out,
         return hipGetLastError();
       }
     }
+  }
+  if (!rows && a.gtile && a.n_gtile > 0 && a.aligned16 && a.outer * a.n_gtile < 0x7FFFFFFFull) {
+    const size_t lds = kTileBytes + (HS ? kTileBytes / sizeof(T) * 4 : 0) + (1024 + 1) * 4;
+    const unsigned blocks = (unsigned)(a.outer * a.n_gtile);
+    const uint64_t n_cells = a.outer * a.K * a.inner;
+#define OLAP_GTILE(F) hipLaunchKernelGGL((drillup_gtile_kernel<T, METHOD, HS, F>), blocks, kBlock, lds, stream, in, st_in, out, st_out, a, n_cells)
+    if constexpr (kAdditive && !HS) {
+      if (fast) { OLAP_GTILE(true); return hipGetLastError(); }
+    }
+    OLAP_GTILE(false);
+#undef OLAP_GTILE
+    return hipGetLastError();
   }
 #define OLAP_ROWS(C, F) hipLaunchKernelGGL((drillup_rows_kernel<T, METHOD, HS, VEC, U, C, F>), (unsigned)row_blocks, kBlock, 0, stream, in, st_in, out, st_out, a)
 #define OLAP_ROWS1(C, F) hipLaunchKernelGGL((drillup_rows_kernel<T, METHOD, HS, VEC, 1, C, F>), (unsigned)row_blocks, kBlock, 0, stream, in, st_in, out, st_out, a)

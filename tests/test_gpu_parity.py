@@ -431,6 +431,56 @@ def test_reduce_regime_to_all(lens, axis, method, type_name, default):
     assert same_typed(out.get_data(), ev)
 
 
+@pytest.mark.parametrize("lens,sizes", [
+    ([7, 3652, 30], "calendar"),        # day -> month in the middle of the cube: rows of 109 560 cells
+    ([3, 3653, 5], "calendar"),         # cell count not a multiple of 4: the last tile ends at the buffer's end
+    ([5, 100000, 1], "thirty"),         # inner = 1, 3 334 groups: several tiles of up to 1 024 groups
+    ([2, 9000, 3], "ragged"),           # groups of 1..40 members, odd offsets
+    ([4, 5000, 127], "ragged30"),       # widest inner of the regime (groups of <= 30 members still fit a tile)
+])
+@pytest.mark.parametrize("method", ["sum", "average", "highest", "first", "last", "product"])
+@pytest.mark.parametrize("type_name,default", [("float32", 0.0), ("float64", float("nan")), ("uint32", float("nan"))])
+def test_group_tile_regime(lens, sizes, method, type_name, default):
+    """Contiguous groups whose rows do not fit LDS (drillup_gtile_kernel): tiles of whole groups."""
+    rng = np.random.default_rng(31)
+    K = lens[1]
+    if sizes == "calendar":
+        days = np.arange(np.datetime64("2010-01-01"), np.datetime64("2010-01-01") + K)
+        months = days.astype("datetime64[M]").astype(np.int64)
+        amap = (months - months[0]).astype(np.uint32)
+    elif sizes == "thirty":
+        amap = (np.arange(K) // 30).astype(np.uint32)
+    else:
+        amap = np.repeat(np.arange(K), rng.integers(1, 31 if sizes == "ragged30" else 41, size=K))[:K].astype(np.uint32)
+        amap = np.unique(amap, return_inverse=True)[1].astype(np.uint32)
+    n = int(np.prod(lens))
+    if method == "product":
+        vals = np.where(rng.random(n) < 0.5, 1.0, -1.0) if type_name != "uint32" else np.ones(n)
+        vals = vals * np.where(rng.random(n) < 0.05, 2.0, 1.0)
+    else:
+        vals = rng.integers(0 if type_name == "uint32" else -8, 9, size=n).astype(np.float64)
+        if type_name != "uint32":
+            vals = vals * 0.5
+    dense = np.where(rng.random(n) < 0.4, default, vals)
+    new = [lens[0], int(amap.max()) + 1, lens[2]]
+    maps = [np.arange(lens[0], dtype=np.uint32), amap, np.arange(lens[2], dtype=np.uint32)]
+    plan = pkg.Plan.drillup(type_name, default, method, lens, new, maps)
+    isz = np.dtype(type_name).itemsize
+    fits = int(np.bincount(amap).max()) * lens[2] <= 16384 // isz - 16 // isz  # every group fits a 16 KiB tile
+    assert plan.kernel_name == ("drillup_gtile_kernel" if fits else "drillup_flat_kernel"), plan.kernel_name
+    o = OracleStore(n, type_name, default)
+    typed = to_typed(dense, type_name).astype(np.float64)
+    if type_name == "uint32":
+        typed = np.where(np.isnan(dense), np.nan, typed)
+    o.set_data(typed)
+    ev, es = expected_typed(o.drill_up(lens, new, maps, method))
+    g = pkg.HipStore(n, type_name, default)
+    g.set_data_f64(dense)
+    out = g.drill_up(lens, new, maps, method)
+    assert np.array_equal(out.get_status(), es)
+    assert same_typed(out.get_data(), ev)
+
+
 REORDER_CASES = [
     ([10] * 6, [5, 4, 3, 2, 1, 0], "reorder_brick4_kernel"),          # runs of 100 cells on both sides
     ([12, 7, 20], [2, 1, 0], "reorder_brick4_kernel"),                # one brick = the whole cube

@@ -57,3 +57,7 @@ run("[1000,1000,100] axis1 -> 100 groups", [1000, 1000, 100], 1, np.arange(1000)
 run("[1000,1000,100] axis1 highest", [1000, 1000, 100], 1, np.arange(1000) % 100, "highest")
 run("[1000,1000,100] axis1 product", [1000, 1000, 100], 1, np.arange(1000) % 100, "product")
 run("[100,1e6] sum NaN-default n/a", [100, 10 ** 6], 0, np.zeros(100))
+run("[1000,1000,100] axis1 -> 100 contiguous groups", [1000, 1000, 100], 1, np.arange(1000) // 10)
+run("[900,3652,30] day in the middle -> month", [900, 3652, 30], 1, month)
+run("[274,3652,100] day in the middle -> month", [274, 3652, 100], 1, month)
+run("[274,3652,100] day in the middle -> month, first", [274, 3652, 100], 1, month, "first")
