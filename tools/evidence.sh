@@ -23,6 +23,9 @@ timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$O/prof_fet
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$O/prof_write" -- python3 "$R/bench.py" --steps 20 --warmup 2 --no-cpu-baseline > "$O/prof_write.log" 2>&1 || { tail -5 "$O/prof_write.log"; exit 1; }
 cd "$R"
 timeout -k 10 300 python tools/sweep.py > "$O/sweep.txt" 2>&1 && tail -3 "$O/sweep.txt"
+timeout -k 10 300 python tools/sweep2.py > "$O/sweep_awkward.txt" 2>&1 && tail -3 "$O/sweep_awkward.txt"
 timeout -k 10 200 python tools/dd_bench.py > "$O/dd_bench.txt" 2>&1 && tail -5 "$O/dd_bench.txt"
 timeout -k 10 200 node tools/js_bench.js > "$O/js_bench.txt" 2>&1 && tail -5 "$O/js_bench.txt"
+timeout -k 10 200 node tools/js_reference_benchmark.js > "$O/js_reference_benchmark.txt" 2>&1 && tail -3 "$O/js_reference_benchmark.txt"
+timeout -k 10 200 node tools/js_chain.js > "$O/js_chain.txt" 2>&1 && tail -3 "$O/js_chain.txt"
 echo evidence done
