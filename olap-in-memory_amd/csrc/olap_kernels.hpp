@@ -674,8 +674,9 @@ __global__ __launch_bounds__(kBlock) void drillup_reduce4_kernel(const T *__rest
     }
   }
   // When rows line up with lanes (inner a multiple of 4, or 1 / 2) the rows of a step are merged
-  // lane to lane: row r + s of a step sits s*inner/4 lanes further on.  Distances below 64 are wave
-  // shuffles; a workgroup-wide unit first folds its upper waves through LDS (two levels at most).
+  // lane to lane: row r + s of a step sits s*inner/4 lanes further on.  Distances up to 32 lanes stay
+  // inside the first wavefront and are wave shuffles; a workgroup-wide unit folds the longer ones
+  // through LDS first (three levels at most).
   // Idle lanes hold the identity.  With one segment per group the result is final and leaves from here.
   const bool by_shuffle = inner % 4 == 0 || inner <= 2;
   if (by_shuffle) {
@@ -699,7 +700,7 @@ __global__ __launch_bounds__(kBlock) void drillup_reduce4_kernel(const T *__rest
     }
     for (uint32_t s = top >> 1; s > 0; s >>= 1) {
       const uint32_t d = s * m;
-      if (d >= 64) {  // only for rd.unit == kBlock: the whole workgroup is one unit
+      if (d > 32) {  // partner lane l + d may sit in another wavefront (only for rd.unit == kBlock): fold through LDS
 #pragma unroll
         for (int e = 0; e < 4; ++e)
           if ((uint32_t)e < ne) lds[threadIdx.x * 4 + e] = p[e];

@@ -232,12 +232,12 @@ def test_full_size_properties(shape, axis):
     assert abs(out.total - s.total) <= 1e-6 * s.total
 
 
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", range(154))
 def test_fused_dice_drillup_equals_two_steps(seed):
     """olap_dice_drillup_plan == dice then drillUp of the oracle (selection with reordering, unknown
     items and duplicates; one rolled-up dimension; every method, type and default)."""
     rng = np.random.default_rng(1000 + seed)
-    shapes = [[6, 5, 8], [12], [3, 4, 5, 4], [7, 16], [5, 3, 64]]
+    shapes = [[6, 5, 8], [12], [3, 4, 5, 4], [7, 16], [5, 3, 64], [4, 6, 512], [3, 40, 129], [2, 3, 4096], [300, 8], [9, 1000], [2, 5, 3, 260]]
     old_len = shapes[seed % len(shapes)]
     nd = len(old_len)
     type_name = ["float32", "float64", "int32", "uint32"][seed % 4]
@@ -395,7 +395,8 @@ def test_reduce_regime_shapes(lens, axis, method):
 
 
 @pytest.mark.parametrize("lens,axis", [([5000, 300], 1), ([4200, 260, 4], 1), ([1000, 264, 8], 1), ([3, 40000, 2], 1), ([100000], 0),
-                                       ([2000000], 0), ([400000, 10], 0), ([2, 40000, 64], 1), ([70000, 128], 0), ([3, 1000, 12], 1)])
+                                       ([2000000], 0), ([400000, 10], 0), ([2, 40000, 64], 1), ([70000, 128], 0), ([3, 1000, 12], 1),
+                                       ([7, 4097, 100], 1), ([2, 9000, 68], 1), ([1, 50000, 24], 1)])
 @pytest.mark.parametrize("method", ["sum", "average", "first", "last", "highest", "lowest", "product"])
 @pytest.mark.parametrize("type_name,default", [("float32", 0.0), ("float32", float("nan")), ("uint32", float("nan"))])
 def test_reduce_regime_to_all(lens, axis, method, type_name, default):
@@ -479,6 +480,184 @@ def test_group_tile_regime(lens, sizes, method, type_name, default):
     out = g.drill_up(lens, new, maps, method)
     assert np.array_equal(out.get_status(), es)
     assert same_typed(out.get_data(), ev)
+
+
+def _boundary_cases():
+    """Seeded sample of one-axis drillUps whose extents sit on the boundaries between the kernel
+    regimes (vector width, 128 vector slots, the 16 KiB tile, 256-member groups, 131 072 outputs)."""
+    rng = np.random.default_rng(20240807)
+    inners = [1, 2, 3, 4, 5, 15, 16, 17, 31, 32, 33, 63, 64, 100, 127, 128, 129, 255, 256, 508, 511, 512, 513, 516, 1000, 1024, 4096, 5000]
+    ks = [1, 2, 3, 10, 30, 255, 256, 257, 1000, 4097]
+    outers = [1, 2, 3, 7, 64, 100]
+    cases = []
+    while len(cases) < 700:
+        inner, K, outer = int(rng.choice(inners)), int(rng.choice(ks)), int(rng.choice(outers))
+        if outer * K * inner > 3_000_000:
+            continue
+        kind = str(rng.choice(["all", "contiguous", "interleaved", "random", "identity"]))
+        method = str(rng.choice(["sum", "average", "highest", "lowest", "first", "last", "product"]))
+        type_name, default = [("float32", 0.0), ("float32", float("nan")), ("float64", 0.0), ("int32", 0.0), ("uint32", float("nan"))][int(rng.integers(0, 5))]
+        cases.append((outer, K, inner, kind, method, type_name, default, int(rng.integers(0, 2 ** 31))))
+    return cases
+
+
+@pytest.mark.parametrize("outer,K,inner,kind,method,type_name,default,seed", _boundary_cases())
+def test_drillup_regime_boundaries(outer, K, inner, kind, method, type_name, default, seed):
+    rng = np.random.default_rng(seed)
+    if kind == "all":
+        amap = np.zeros(K, np.uint32)
+    elif kind == "identity":
+        amap = np.arange(K, dtype=np.uint32)
+    elif kind == "contiguous":
+        amap = np.unique(np.sort(rng.integers(0, max(1, K // 3) + 1, size=K)), return_inverse=True)[1].astype(np.uint32)
+    elif kind == "interleaved":
+        amap = (np.arange(K) % max(1, min(K, int(rng.integers(1, 12))))).astype(np.uint32)
+    else:
+        amap = np.unique(rng.integers(0, max(1, K // 2) + 1, size=K), return_inverse=True)[1].astype(np.uint32)
+        # group ids must be numbered by first appearance, as GenericDimension.addAttribute does (generic.js:100-107)
+        first = {}
+        amap = np.array([first.setdefault(int(g), len(first)) for g in amap], dtype=np.uint32)
+    lens = [outer, K, inner]
+    new = [outer, int(amap.max()) + 1, inner]
+    n = outer * K * inner
+    if method == "product":
+        vals = np.where(rng.random(n) < 0.5, 1.0, -1.0) if type_name not in ("uint32",) else np.ones(n)
+        vals = vals * np.where(rng.random(n) < 2.0 / max(K, 2), 2.0, 1.0)
+    else:
+        vals = rng.integers(0 if type_name == "uint32" else -8, 9, size=n).astype(np.float64)
+        if type_name.startswith("float"):
+            vals = vals * 0.5
+    dense = np.where(rng.random(n) < 0.35, default, vals)
+    maps = [np.arange(outer, dtype=np.uint32), amap, np.arange(inner, dtype=np.uint32)]
+    plan = pkg.Plan.drillup(type_name, default, method, lens, new, maps)
+    o = OracleStore(n, type_name, default)
+    typed = to_typed(dense, type_name).astype(np.float64)
+    if type_name in ("int32", "uint32") and default != default:
+        typed = np.where(np.isnan(dense), np.nan, typed)
+    o.set_data(typed)
+    ev, es = expected_typed(o.drill_up(lens, new, maps, method))
+    g = pkg.HipStore(n, type_name, default)
+    g.set_data_f64(dense)
+    out = g.drill_up(lens, new, maps, method)
+    assert np.array_equal(out.get_status(), es), plan.kernel_name
+    assert same_typed(out.get_data(), ev), plan.kernel_name
+
+
+def _down_cases():
+    rng = np.random.default_rng(8072024)
+    inners = [1, 3, 4, 17, 32, 100, 127, 128, 129, 511, 512, 516, 520, 1000, 1024, 2056]
+    cases = []
+    while len(cases) < 140:
+        inner, G, outer = int(rng.choice(inners)), int(rng.choice([1, 2, 5, 12, 40])), int(rng.choice([1, 2, 3, 9]))
+        fan = int(rng.choice([1, 2, 3, 7, 19, 31]))
+        if outer * G * fan * inner > 2_000_000:
+            continue
+        kind = str(rng.choice(["contiguous", "interleaved", "uneven"]))
+        method = str(rng.choice(["sum", "average"]))
+        type_name, default = [("float32", 0.0), ("float32", float("nan")), ("float64", 0.0), ("int32", 0.0), ("uint32", float("nan"))][int(rng.integers(0, 5))]
+        cases.append((outer, G, fan, inner, kind, method, type_name, default, int(rng.integers(0, 2 ** 31))))
+    return cases
+
+
+@pytest.mark.parametrize("outer,G,fan,inner,kind,method,type_name,default,seed", _down_cases())
+def test_drilldown_regime_boundaries(outer, G, fan, inner, kind, method, type_name, default, seed):
+    """One refined dimension across the drillDown forms (row form, line-aligned windows, scale +
+    broadcast, one lane per child) and their extent boundaries."""
+    rng = np.random.default_rng(seed)
+    if kind == "contiguous":
+        child = np.repeat(np.arange(G), fan)
+    elif kind == "interleaved":
+        child = np.arange(G * fan) % G
+    else:
+        child = np.repeat(np.arange(G), rng.integers(1, fan + 1, size=G))
+    child = child.astype(np.uint32)
+    K = len(child)
+    old_len, new_len = [outer, G, inner], [outer, K, inner]
+    n_old = outer * G * inner
+    vals = rng.integers(0 if type_name == "uint32" else -60, 120, size=n_old).astype(np.float64)
+    if type_name.startswith("float"):
+        vals = vals * 0.25
+    dense = np.where(rng.random(n_old) < 0.3, default, vals)
+    maps = [np.arange(outer, dtype=np.uint32), child, np.arange(inner, dtype=np.uint32)]
+    plan = pkg.Plan.drilldown(type_name, default, method, old_len, new_len, maps)
+    o = OracleStore(n_old, type_name, default)
+    typed = to_typed(dense, type_name).astype(np.float64)
+    if type_name in ("int32", "uint32") and default != default:
+        typed = np.where(np.isnan(dense), np.nan, typed)
+    o.set_data(typed)
+    ev, es = expected_typed(o.drill_down(old_len, new_len, maps, method))
+    g = pkg.HipStore(n_old, type_name, default)
+    g.set_data_f64(dense)
+    out = g.drill_down(old_len, new_len, maps, method)
+    assert np.array_equal(out.get_status(), es), plan.kernel_name
+    assert same_typed(out.get_data(), ev), plan.kernel_name
+
+
+def _dice_cases():
+    rng = np.random.default_rng(772024)
+    cases = []
+    while len(cases) < 120:
+        lens = [int(rng.choice([1, 2, 3, 7, 10, 33])), int(rng.choice([1, 4, 9, 30])), int(rng.choice([1, 3, 4, 16, 100, 128, 129, 1000]))]
+        if int(np.prod(lens)) > 1_500_000:
+            continue
+        type_name, default = [("float32", 0.0), ("float64", float("nan")), ("int32", 0.0), ("uint32", float("nan"))][int(rng.integers(0, 4))]
+        cases.append((lens, type_name, default, int(rng.integers(0, 2 ** 31))))
+    return cases
+
+
+@pytest.mark.parametrize("lens,type_name,default,seed", _dice_cases())
+def test_dice_selections_randomized(lens, type_name, default, seed):
+    """dice (in-memory.js:213-263) with random selections on every dimension: subsets, reorderings,
+    unknown items (-1) and duplicates (only the last occurrence receives the cells)."""
+    rng = np.random.default_rng(seed)
+    sel = []
+    for l in lens:
+        mode = int(rng.integers(0, 4))
+        if mode == 0:
+            s_ = np.arange(l)
+        elif mode == 1:
+            s_ = np.sort(rng.choice(l, size=int(rng.integers(0, l + 1)), replace=False))
+        elif mode == 2:
+            s_ = rng.permutation(l)[: int(rng.integers(1, l + 1))]
+        else:
+            s_ = rng.integers(-1, l, size=int(rng.integers(1, l + 3)))
+        sel.append(s_.astype(np.int32))
+    new_len = [len(x) for x in sel]
+    n = int(np.prod(lens))
+    vals = rng.integers(1, 500, size=n).astype(np.float64)
+    dense = np.where(rng.random(n) < 0.3, default, vals)
+    o = OracleStore(n, type_name, default)
+    typed = to_typed(dense, type_name).astype(np.float64)
+    if type_name in ("int32", "uint32") and default != default:
+        typed = np.where(np.isnan(dense), np.nan, typed)
+    o.set_data(typed)
+    ev, es = expected_typed(o.dice(lens, new_len, sel))
+    g = pkg.HipStore(n, type_name, default)
+    g.set_data_f64(dense)
+    out = g.dice(lens, new_len, sel)
+    assert out.size == int(np.prod(new_len))
+    assert np.array_equal(out.get_status(), es)
+    assert same_typed(out.get_data(), ev)
+
+
+@pytest.mark.parametrize("seed", range(60))
+def test_reorder_random_permutations(seed):
+    rng = np.random.default_rng(4000 + seed)
+    nd = int(rng.integers(2, 6))
+    lens = [int(rng.choice([1, 2, 3, 4, 7, 8, 10, 16, 25, 64, 100])) for _ in range(nd)]
+    while int(np.prod(lens)) > 2_000_000:
+        lens[int(rng.integers(0, nd))] = 2
+    perm = [int(x) for x in rng.permutation(nd)]
+    type_name, default = [("float32", 0.0), ("int32", 0.0), ("uint32", float("nan")), ("float64", float("nan"))][seed % 4]
+    n = int(np.prod(lens))
+    vals = rng.integers(1, 1000, size=n).astype(np.float64)
+    unset = rng.random(n) < 0.3
+    g = pkg.HipStore(n, type_name, default)
+    g.set_data_f64(np.where(unset, default, vals))
+    out = g.reorder(lens, perm)
+    moved = lambda a: np.ascontiguousarray(a.reshape(lens).transpose(perm)).ravel()  # noqa: E731
+    assert np.array_equal(out.get_status(), moved(g.get_status()))
+    assert same_typed(out.get_data(), moved(g.get_data()))
 
 
 REORDER_CASES = [
