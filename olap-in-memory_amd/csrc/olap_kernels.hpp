@@ -1157,9 +1157,11 @@ __global__ __launch_bounds__(kBlock) void load_scatter_kernel(const T *__restric
     v = x;
     set = !Cell<T>::is_default(v, def_nan);
   } else {
+    // his.getValue() hands out HIS default (:119), which my setValue keeps unless it is MY default
+    // (:122-133): 0 under my NaN default is a set cell; NaN under my 0 default is one for float cells
     v = Cell<T>::default_value(his_nan);
     constexpr bool is_float = (Cell<T>::dtype == OLAP_FLOAT32 || Cell<T>::dtype == OLAP_FLOAT64);
-    set = is_float && his_nan && !def_nan;  // NaN is storable under a zero default
+    set = his_nan ? (is_float && !def_nan) : def_nan;
   }
   mine[dst] = set ? v : Cell<T>::default_value(def_nan);
   if (mine_st) mine_st[dst] = set ? OLAP_STATUS_SET : 0;
