@@ -397,7 +397,7 @@ extern "C" int olap_drillup_plan(olap_plan **out, int dtype, int default_kind, i
         for (uint32_t g = 0; g < a.G && fits; ++g) {
           const uint64_t c = (uint64_t)(gstart[g + 1] - gstart[g]) * a.inner;
           if (c > budget - vcells) fits = false;
-          if (cells + c > budget - vcells || groups == 1024) {
+          if (cells + c > budget - vcells || groups == kGroupTileMaxGroups) {
             cut.push_back(g);
             cells = 0;
             groups = 0;

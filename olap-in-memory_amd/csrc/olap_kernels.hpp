@@ -319,6 +319,8 @@ __global__ __launch_bounds__(kBlock) void drillup_tile_kernel(const T *__restric
   }
 }
 
+constexpr uint32_t kGroupTileMaxGroups = 1024;  // groups per tile of the group-tile regime (LDS holds their bounds)
+
 // Group-tile regime: contiguous groups (calendars) whose rows K*inner do not fit LDS — e.g. day ->
 // month on [100, 3652, 30].  The members of consecutive groups are consecutive memory, so a tile is a
 // run of whole GROUPS of one outer row (the plan cuts the group list into tiles of <= kTileBytes of
@@ -334,10 +336,9 @@ __global__ __launch_bounds__(kBlock) void drillup_gtile_kernel(const T *__restri
   constexpr int V = 16 / sizeof(T);
   constexpr uint32_t kCells = kTileBytes / sizeof(T);
   constexpr int NL = kCells / V / kBlock;
-  constexpr uint32_t kMaxGroups = 1024;  // groups per tile (plan-side limit)
   T *tile = reinterpret_cast<T *>(lds_raw);
   int32_t *stile = reinterpret_cast<int32_t *>(lds_raw + kTileBytes);
-  uint32_t *l_gstart = reinterpret_cast<uint32_t *>(lds_raw + kTileBytes + (HAS_STATUS ? kCells * 4 : 0));  // kMaxGroups + 1
+  uint32_t *l_gstart = reinterpret_cast<uint32_t *>(lds_raw + kTileBytes + (HAS_STATUS ? kCells * 4 : 0));  // kGroupTileMaxGroups + 1 entries
 
   const uint32_t bid = a.xcd_order ? xcd_contiguous(blockIdx.x, gridDim.x) : blockIdx.x;
   const uint32_t t = bid % a.n_gtile;
@@ -2069,7 +2070,7 @@ static hipError_t drillup_axis_launch(const T *in, const int32_t *st_in, T *out,
     }
   }
   if (!rows && a.gtile && a.n_gtile > 0 && a.aligned16 && a.outer * a.n_gtile < 0x7FFFFFFFull) {
-    const size_t lds = kTileBytes + (HS ? kTileBytes / sizeof(T) * 4 : 0) + (1024 + 1) * 4;
+    const size_t lds = kTileBytes + (HS ? kTileBytes / sizeof(T) * 4 : 0) + (kGroupTileMaxGroups + 1) * 4;
     const unsigned blocks = (unsigned)(a.outer * a.n_gtile);
     const uint64_t n_cells = a.outer * a.K * a.inner;
 #define OLAP_GTILE(F) hipLaunchKernelGGL((drillup_gtile_kernel<T, METHOD, HS, F>), blocks, kBlock, lds, stream, in, st_in, out, st_out, a, n_cells)

@@ -67,6 +67,42 @@ __global__ __launch_bounds__(256) void colsum_f32_kernel(const float4 *__restric
   out[i] = a;
 }
 
+// K rows, one row in flight, C column slots (256 slots = 4 KiB apart) per lane: a workgroup sweeps
+// C*4 KiB of contiguous memory per row, float64 accumulation, non-temporal loads
+template <int C, bool XCD>
+__global__ __launch_bounds__(256) void colrows_kernel(const float *__restrict__ in, float *__restrict__ out, uint64_t inner, int K) {
+  const uint32_t bid = XCD ? xcd_contiguous(blockIdx.x, gridDim.x) : blockIdx.x;
+  const uint64_t inner4 = inner / 4;
+  const uint64_t base = (uint64_t)bid * 256 * C + threadIdx.x;
+  double acc[C][4];
+#pragma unroll
+  for (int c = 0; c < C; ++c)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[c][e] = 0.0;
+  for (int k = 0; k < K; ++k) {
+    Vec<float, 4> v[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      const uint64_t i = base + (uint64_t)c * 256;
+      if (i < inner4) v[c] = load_stream<float, 4>(in + (uint64_t)k * inner + i * 4);
+    }
+#pragma unroll
+    for (int c = 0; c < C; ++c)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[c][e] += (double)v[c].v[e];
+  }
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    const uint64_t i = base + (uint64_t)c * 256;
+    if (i < inner4) {
+      Vec<float, 4> o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o.v[e] = (float)acc[c][e];
+      store_stream<float, 4>(out + i * 4, o);
+    }
+  }
+}
+
 struct Timer {
   hipEvent_t a, b;
   Timer() {
@@ -157,6 +193,13 @@ int main(int argc, char **argv) {
     vs.push_back({"rows VEC=8 U=4 nt values only", [&, g8] { hipLaunchKernelGGL((drillup_rows_kernel<float, OLAP_SUM, false, 8, 4, true, true, true>), g8, 256, 0, 0, in, nullptr, out, (int32_t *)nullptr, a8); }, N * 4.0 + inner * 4.0, {}});
     vs.push_back({"rows VEC=8 U=2 nt values only", [&, g8] { hipLaunchKernelGGL((drillup_rows_kernel<float, OLAP_SUM, false, 8, 2, true, true, true>), g8, 256, 0, 0, in, nullptr, out, (int32_t *)nullptr, a8); }, N * 4.0 + inner * 4.0, {}});
   }
+#define COLS(C, X, NAME) vs.push_back({NAME, [&] { hipLaunchKernelGGL((colrows_kernel<C, X>), (unsigned)((inner / 4 + 256 * C - 1) / (256 * C)), 256, 0, 0, in, out, inner, (int)K); }, N * 4.0 + inner * 4.0, {}})
+  COLS(1, false, "colrows C=1");
+  COLS(2, false, "colrows C=2");
+  COLS(4, false, "colrows C=4");
+  COLS(8, false, "colrows C=8");
+  COLS(2, true, "colrows C=2 xcd");
+  COLS(4, true, "colrows C=4 xcd");
   ROWS(4, true, true, st_out, "rows U=4 nt + status out");
   ROWS(1, true, true, st_out, "rows U=1 nt + status out");
   ROWS(1, false, true, (int32_t *)nullptr, "rows U=1 exact");
