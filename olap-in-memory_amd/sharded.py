@@ -67,6 +67,12 @@ class HipEngine:
     def make_drillup(self, dtype, default, method, old_len, new_len, maps):
         return _HipDrillUp(self, Plan.drillup(dtype, default, method, old_len, new_len, maps))
 
+    def make_dice(self, dtype, default, old_len, new_len, sel):
+        return _HipDrillUp(self, Plan.dice(dtype, default, old_len, new_len, sel))
+
+    def make_drilldown(self, dtype, default, method, old_len, new_len, maps):
+        return _HipDrillUp(self, Plan.drilldown(dtype, default, method, old_len, new_len, maps))
+
     def fill_seeded(self, values, status, n, first_cell, dtype, seed, frac):
         capi.check(capi.lib().olap_fill_seeded(values.data_ptr(), status.data_ptr(), int(n), int(first_cell),
                                                capi.DTYPES[dtype], int(seed), float(frac), self.stream()))
@@ -81,14 +87,17 @@ class HipEngine:
 class ShardedStore:
     """One measure of a cube whose dimension 0 is split across the ranks of a process group."""
 
-    def __init__(self, lens, dtype="float32", default=0.0, rank=0, world=1, engine=None, group=None):
+    def __init__(self, lens, dtype="float32", default=0.0, rank=0, world=1, engine=None, group=None, bounds=None):
         if engine is None:
             raise ValueError("an engine is required (HipEngine on a GPU box)")
         self.lens = [int(x) for x in lens]
         self.dtype, self.default = dtype, default
         self.rank, self.world, self.group = int(rank), int(world), group
         self.engine = engine
-        self.bounds = partition_rows(self.lens[0], self.world)
+        # `bounds`: an explicit (possibly uneven) row partition, e.g. what a dice of dimension 0 leaves
+        self.bounds = partition_rows(self.lens[0], self.world) if bounds is None else [int(b) for b in bounds]
+        if len(self.bounds) != self.world + 1 or self.bounds[0] != 0 or self.bounds[-1] != self.lens[0]:
+            raise ValueError("bounds must list world+1 ascending row offsets from 0 to the extent of dimension 0")
         self.row_lo, self.row_hi = self.bounds[self.rank], self.bounds[self.rank + 1]
         self.inner0 = int(np.prod(self.lens[1:])) if len(self.lens) > 1 else 1
         self.local_cells = (self.row_hi - self.row_lo) * self.inner0
@@ -120,6 +129,54 @@ class ShardedStore:
         op.run(self.values, None, out.values, out.status)
         out._keepalive = op
         return out
+
+    def _local(self, op, new_tail, bounds=None, new_rows=None):
+        """Runs a per-shard plan (no communication) into a new store with the same partition."""
+        rows = self.lens[0] if new_rows is None else new_rows
+        out = ShardedStore([rows] + list(new_tail), self.dtype, self.default, self.rank, self.world, self.engine, self.group,
+                           self.bounds if bounds is None else bounds)
+        op.run(self.values, None, out.values, out.status)
+        out._keepalive = op
+        return out
+
+    def dice_other_axes(self, selections):
+        """dice on non-sharded dimensions (in-memory.js:213-263): selections[d] lists the OLD item index
+        of every new item of dimension d (-1: unknown item), None keeps a dimension; selections[0]
+        must be None.  Per shard, no communication, partition kept."""
+        if selections[0] is not None:
+            raise ValueError("dimension 0 is the sharded axis: use dice_dim0")
+        old_len = self.local_lens
+        sel = [np.arange(l, dtype=np.int32) if s is None else np.asarray(s, dtype=np.int32) for l, s in zip(old_len, selections)]
+        new_len = [len(x) for x in sel]
+        return self._local(self.engine.make_dice(self.dtype, self.default, old_len, new_len, sel), new_len[1:])
+
+    def drilldown_other_axis(self, axis, child_to_parent, method="sum"):
+        """drillDown of a non-sharded dimension (in-memory.js:336-430): child_to_parent[new item] = old
+        item.  Per shard, no communication, partition kept."""
+        if axis < 1:
+            raise ValueError("refining the sharded axis changes the partition: not provided")
+        old_len = self.local_lens
+        child = np.asarray(child_to_parent, dtype=np.uint32)
+        new_len = list(old_len)
+        new_len[axis] = len(child)
+        maps = [np.arange(l, dtype=np.uint32) for l in old_len]
+        maps[axis] = child
+        return self._local(self.engine.make_drilldown(self.dtype, self.default, method, old_len, new_len, maps), new_len[1:])
+
+    def dice_dim0(self, rows):
+        """dice of the sharded dimension by an ASCENDING list of global rows: every rank keeps those of
+        its own rows that were selected — no data moves, the partition becomes uneven.  (A selection
+        that reorders rows across ranks would need an all-to-all; the reference's dice keeps item
+        order unless asked otherwise, src/cube.js:821-857.)"""
+        rows = np.asarray(rows, dtype=np.int64)
+        if rows.size and (np.any(np.diff(rows) <= 0) or rows[0] < 0 or rows[-1] >= self.lens[0]):
+            raise ValueError("dice_dim0 takes strictly ascending row indices inside dimension 0")
+        bounds = [int(np.searchsorted(rows, b)) for b in self.bounds]
+        mine = rows[bounds[self.rank]:bounds[self.rank + 1]] - self.row_lo
+        old_len = self.local_lens
+        sel = [mine.astype(np.int32)] + [np.arange(l, dtype=np.int32) for l in old_len[1:]]
+        new_len = [len(mine)] + old_len[1:]
+        return self._local(self.engine.make_dice(self.dtype, self.default, old_len, new_len, sel), self.lens[1:], bounds, len(rows))
 
     def plan_drillup_dim0(self, row_map, n_groups, method="sum", always_collective=False):
         """Prepares drillUp of the sharded axis: row_map[global row] -> group (< n_groups)."""

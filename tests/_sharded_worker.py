@@ -47,8 +47,31 @@ class _OracleDrillUp:
             out_status.copy_(torch.from_numpy(ts))
 
 
+class _OracleOp:
+    """dice / drillDown of the oracle behind the engine's plan interface."""
+
+    def __init__(self, kind, dtype, default, *args):
+        self.kind, self.dtype, self.default, self.args = kind, dtype, default, args
+
+    def run(self, values, status, out_values, out_status):
+        v = values.numpy().astype(np.float64)
+        o = OracleStore(v.size, self.dtype, self.default)
+        o.set_data(v)
+        res = o.dice(*self.args) if self.kind == "dice" else o.drill_down(*self.args)
+        tv, ts = res.typed()
+        out_values.copy_(torch.from_numpy(tv.astype(np.float32)))
+        if out_status is not None:
+            out_status.copy_(torch.from_numpy(ts))
+
+
 class OracleEngine:
     name = "oracle-standin"
+
+    def make_dice(self, dtype, default, old_len, new_len, sel):
+        return _OracleOp("dice", dtype, default, list(old_len), list(new_len), [np.asarray(x) for x in sel])
+
+    def make_drilldown(self, dtype, default, method, old_len, new_len, maps):
+        return _OracleOp("drilldown", dtype, default, list(old_len), list(new_len), [np.asarray(m) for m in maps], method)
 
     def empty(self, n, dtype):
         td = {"float32": torch.float32, "int32": torch.int32}[dtype]
@@ -100,6 +123,19 @@ def main():
             torch.cuda.synchronize()
         results["axis2_%s" % frac] = {"range": [o.row_lo * o.inner0, o.row_hi * o.inner0],
                                       "values": o.values.cpu().numpy().astype(np.float64).tolist()}
+        # per-shard dice / drillDown (no communication) and a row selection on the sharded axis itself
+        def dump(key, st):
+            if getattr(st.values, "is_cuda", False):
+                torch.cuda.synchronize()
+            results["%s_%s" % (key, frac)] = {"range": [st.row_lo * st.inner0, st.row_hi * st.inner0],
+                                              "values": st.values.cpu().numpy().astype(np.float64).tolist()}
+
+        dump("dice12", s.dice_other_axes([None, [4, 0, -1, 2], [9, 8, 1]]))
+        dump("down2", s.drilldown_other_axis(2, np.repeat(np.arange(10), 3), "sum"))
+        picked = s.dice_dim0([1, 2, 4, 6])
+        assert picked.bounds == [0, 2, 4] and picked.lens[0] == 4, picked.bounds
+        dump("rows", picked)
+        dump("rows_then_sum", picked.drillup_other_axis(1, np.zeros(6, np.uint32), 1, "sum"))
     with open("%s.%d" % (out_path, rank), "w") as f:
         json.dump(results, f)
     dist.barrier()

@@ -63,6 +63,25 @@ def check(results):
             got[r["range"][0]:r["range"][1]] = r["values"]
         assert np.array_equal(got.astype(np.float32), e2)
 
+        def gathered(key, n):
+            out = np.full(n, np.nan)
+            for res in results:
+                r = res["%s_%s" % (key, frac)]
+                out[r["range"][0]:r["range"][1]] = r["values"]
+            return out.astype(np.float32)
+
+        ident = lambda l: np.arange(l, dtype=np.int32)  # noqa: E731
+        e3, _ = o.dice(lens, [7, 4, 3], [ident(7), np.array([4, 0, -1, 2], np.int32), np.array([9, 8, 1], np.int32)]).typed()
+        assert np.array_equal(gathered("dice12", 84), e3)
+        e4, _ = o.drill_down(lens, [7, 6, 30], [np.arange(7, dtype=np.uint32), np.arange(6, dtype=np.uint32),
+                                                  np.repeat(np.arange(10), 3).astype(np.uint32)], "sum").typed()
+        assert np.array_equal(gathered("down2", 1260), e4)
+        picked = o.dice(lens, [4, 6, 10], [np.array([1, 2, 4, 6], np.int32), ident(6), ident(10)])
+        e5, _ = picked.typed()
+        assert np.array_equal(gathered("rows", 240), e5)
+        e6, _ = picked.drill_up([4, 6, 10], [4, 1, 10], [np.arange(4, dtype=np.uint32), np.zeros(6, np.uint32), np.arange(10, dtype=np.uint32)], "sum").typed()
+        assert np.array_equal(gathered("rows_then_sum", 40), e6)
+
 
 def test_partition_rows():
     from conftest import load_package
