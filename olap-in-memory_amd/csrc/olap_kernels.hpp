@@ -2032,7 +2032,8 @@ static hipError_t drillup_axis_launch(const T *in, const int32_t *st_in, T *out,
   // the waves sweep the K rows together.  Narrow lanes or short rows (e.g. inner = 274) need the
   // depth back, and so does the heavier exact state machine.
   constexpr int U = 4;
-  const bool shallow = (kAdditive || IsPick<METHOD>::value) && VEC * sizeof(T) >= 16 && a.n_vec >= 1024;
+  bool shallow = (kAdditive || IsPick<METHOD>::value) && VEC * sizeof(T) >= 16 && a.n_vec >= 1024;
+  if (const char *e = getenv("OLAP_ROWS_DEPTH")) shallow = atoi(e) == 1;  // A/B: 1 or 4 rows in flight
   if (!rows) {
     // LDS tile regime for small `inner` (short row pieces make the flat regime's accesses waste much
     // of every cache line): whole rows of K*inner cells staged per workgroup, kTileBytes of cells
