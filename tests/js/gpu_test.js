@@ -215,6 +215,79 @@ describe('pending dice (fused dice -> drillUp)', () => {
   });
 });
 
+describe('pending selections against eager execution (seeded random chains)', () => {
+  // the same chain of slice / dice / drillUp / removeDimension run lazily (selections stay pending
+  // and fuse) and eagerly (cells read back after every step, which materialises each store)
+  let state = 20240807;
+  const rand = (n) => {
+    state = (Math.imul(state, 1664525) + 1013904223) | 0;
+    return (state >>> 8) % n;
+  };
+  const build = () => {
+    const sizes = [5, 4, 3, 6];
+    const dims = sizes.map((n, d) => {
+      const dim = new GenericDimension(`d${d}`, 'item', Array.from({ length: n }, (_x, i) => `d${d}i${i}`));
+      dim.addAttribute('item', 'parity', (item) => (Number(item.slice(-1)) % 2 ? 'odd' : 'even'));
+      return dim;
+    });
+    const cube = new Cube(dims);
+    cube.createStoredMeasure('sum_m', {}, 'float32', 0);
+    cube.createStoredMeasure('last_m', Object.fromEntries(dims.map((d) => [d.id, 'last'])), 'int32', NaN_);
+    const n = sizes.reduce((a, b) => a * b, 1);
+    cube.setData('sum_m', Array.from({ length: n }, (_x, i) => ((i * 7) % 11 === 0 ? 0 : (i % 13) + 0.5)));
+    cube.setData('last_m', Array.from({ length: n }, (_x, i) => ((i * 5) % 7 === 0 ? NaN_ : i % 17)));
+    return cube;
+  };
+  const step = (cube, eager) => {
+    if (cube.dimensions.length === 0) return cube;
+    const dim = cube.dimensions[rand(cube.dimensions.length)];
+    const items = dim.getItems();
+    let next;
+    switch (rand(5)) {
+      case 0:
+        next = cube.slice(dim.id, dim.rootAttribute, items[rand(items.length)]);
+        break;
+      case 1: {
+        const keep = items.filter(() => rand(3) > 0);
+        next = cube.dice(dim.id, dim.rootAttribute, keep.length ? keep : [items[0]], rand(2) === 1);
+        break;
+      }
+      case 2:
+        next = dim.attributes.includes('parity') && dim.rootAttribute !== 'parity' ? cube.drillUp(dim.id, 'parity') : cube.drillUp(dim.id, 'all');
+        break;
+      case 3:
+        next = cube.removeDimension(dim.id);
+        break;
+      default:
+        next = dim.attributes.includes('parity') ? cube.dice(dim.id, 'parity', [rand(2) ? 'odd' : 'even']) : cube;
+    }
+    if (eager) for (const id of next.storedMeasureIds) next.getData(id);
+    return next;
+  };
+  it('120 chains of up to 5 operations agree cell for cell', () => {
+    for (let chain = 0; chain < 120; ++chain) {
+      const seed = state;
+      const length = 1 + rand(5);
+      const run = (eager) => {
+        state = seed;
+        rand(5);
+        let cube = build();
+        for (let i = 0; i < length; ++i) cube = step(cube, eager);
+        return cube;
+      };
+      const lazy = run(false);
+      const after = state;
+      const eager = run(true);
+      state = after;
+      assert.deepEqual(lazy.dimensionIds, eager.dimensionIds, `chain ${chain}`);
+      for (const id of ['sum_m', 'last_m']) {
+        assert.deepEqual(lazy.getNestedArray(id), eager.getNestedArray(id), `chain ${chain} ${id}`);
+        assert.deepEqual(Array.from(lazy.getStatusMap(id).keys()), Array.from(eager.getStatusMap(id).keys()), `chain ${chain} ${id} keys`);
+      }
+    }
+  });
+});
+
 describe('dimensions', () => {
   it('removeDimension with every aggregator', () => {
     let cube = new Cube([new GenericDimension('location', 'city', ['paris', 'toledo', 'tokyo']), new GenericDimension('period', 'season', ['summer', 'winter'])]);
