@@ -312,6 +312,28 @@ def main():
             torch.cuda.synchronize()
             us = a.elapsed_time(b) / 200 * 1e3
             res["axis%d" % axis] = {"us_per_launch": round(us, 3), "cells_per_s": 1e6 / (us * 1e-6)}
+            # the same 200 launches captured once into a hipGraph and replayed: what is left is the
+            # kernel itself plus the graph's per-node dispatch, without one host launch per query
+            try:
+                side = torch.cuda.Stream()
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.stream(side):
+                    o.plan.run(small.values.data_ptr(), None, ov.data_ptr(), os_.data_ptr(), side.cuda_stream)
+                    side.synchronize()
+                    with torch.cuda.graph(graph, stream=side):
+                        for _ in range(200):
+                            o.plan.run(small.values.data_ptr(), None, ov.data_ptr(), os_.data_ptr(), torch.cuda.current_stream().cuda_stream)
+                graph.replay()
+                torch.cuda.synchronize()
+                a.record()
+                for _ in range(5):
+                    graph.replay()
+                b.record()
+                torch.cuda.synchronize()
+                gus = a.elapsed_time(b) / 1000 * 1e3
+                res["axis%d" % axis].update({"graph_us_per_launch": round(gus, 3), "graph_cells_per_s": 1e6 / (gus * 1e-6)})
+            except Exception as err:  # a capture problem must not cost the headline line
+                res["axis%d" % axis]["graph_error"] = str(err)[:200]
         extra["cache_resident_1e6"] = res
         extra["config3_chain"] = bench_config3(pkg, engine, store, torch)
         extra["config5_time_rollup"] = bench_config5(pkg, engine, torch)
