@@ -61,3 +61,7 @@ run("[1000,1000,100] axis1 -> 100 contiguous groups", [1000, 1000, 100], 1, np.a
 run("[900,3652,30] day in the middle -> month", [900, 3652, 30], 1, month)
 run("[274,3652,100] day in the middle -> month", [274, 3652, 100], 1, month)
 run("[274,3652,100] day in the middle -> month, first", [274, 3652, 100], 1, month, "first")
+# odd trailing extents: no 16 B alignment between rows
+run("[10,3001,3333] axis0 -> all (odd inner)", [10, 3001, 3333], 0, np.zeros(10))
+run("[3001,10,3333] axis1 -> all (odd inner)", [3001, 10, 3333], 1, np.zeros(10))
+run("[3001,3333,10] axis1 -> 11 groups (inner 10)", [3001, 3333, 10], 1, np.arange(3333) // 303)
