@@ -103,6 +103,39 @@ __global__ __launch_bounds__(256) void colrows_kernel(const float *__restrict__ 
   }
 }
 
+// cache-policy variants of the same loop: POLICY 0 plain, 1 nt, 2 sc1 nt, 3 sc0 sc1 nt, 4 sc1, 5 sc0 sc1
+template <int POLICY>
+__device__ __forceinline__ float4 load_policy(const float4 *p) {
+  float4 v;
+  if constexpr (POLICY == 0) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+  else if constexpr (POLICY == 1) asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(v) : "v"(p) : "memory");
+  else if constexpr (POLICY == 2) asm volatile("global_load_dwordx4 %0, %1, off sc1 nt" : "=v"(v) : "v"(p) : "memory");
+  else if constexpr (POLICY == 3) asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1 nt" : "=v"(v) : "v"(p) : "memory");
+  else if constexpr (POLICY == 4) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
+  else asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(v) : "v"(p) : "memory");
+  return v;
+}
+
+template <int POLICY>
+__global__ __launch_bounds__(256) void colpolicy_kernel(const float *__restrict__ in, float *__restrict__ out, uint64_t inner, int K) {
+  const uint64_t inner4 = inner / 4;
+  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= inner4) return;
+  double acc[4] = {0.0, 0.0, 0.0, 0.0};
+  for (int k = 0; k < K; ++k) {
+    float4 v = load_policy<POLICY>(reinterpret_cast<const float4 *>(in + (uint64_t)k * inner) + i);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    acc[0] += (double)v.x;
+    acc[1] += (double)v.y;
+    acc[2] += (double)v.z;
+    acc[3] += (double)v.w;
+  }
+  Vec<float, 4> o;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) o.v[e] = (float)acc[e];
+  store_stream<float, 4>(out + i * 4, o);
+}
+
 struct Timer {
   hipEvent_t a, b;
   Timer() {
@@ -200,6 +233,13 @@ int main(int argc, char **argv) {
   COLS(8, false, "colrows C=8");
   COLS(2, true, "colrows C=2 xcd");
   COLS(4, true, "colrows C=4 xcd");
+#define POL(P, NAME) vs.push_back({NAME, [&] { hipLaunchKernelGGL((colpolicy_kernel<P>), (unsigned)((inner / 4 + 255) / 256), 256, 0, 0, in, out, inner, (int)K); }, N * 4.0 + inner * 4.0, {}})
+  POL(0, "policy plain");
+  POL(1, "policy nt");
+  POL(2, "policy sc1 nt");
+  POL(3, "policy sc0 sc1 nt");
+  POL(4, "policy sc1");
+  POL(5, "policy sc0 sc1");
   ROWS(4, true, true, st_out, "rows U=4 nt + status out");
   ROWS(1, true, true, st_out, "rows U=1 nt + status out");
   ROWS(1, false, true, (int32_t *)nullptr, "rows U=1 exact");
