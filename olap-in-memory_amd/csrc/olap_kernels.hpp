@@ -73,10 +73,7 @@ struct Lane {
     }
   }
 
-  template <bool NT>
-  __device__ __forceinline__ void finish_and_store(bool def_nan, T *out, int32_t *st_out, uint64_t oidx) {
-    Vec<T, VEC> ov;
-    Vec<int32_t, VEC> os;
+  __device__ __forceinline__ void finish(bool def_nan, Vec<T, VEC> &ov, Vec<int32_t, VEC> &os) {
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
       if constexpr (kPick) {
@@ -94,6 +91,13 @@ struct Lane {
         if constexpr (METHOD == OLAP_PARTIAL_AVERAGE) os.v[e] = (int32_t)agg[e].count;  // count, not a mask
       }
     }
+  }
+
+  template <bool NT>
+  __device__ __forceinline__ void finish_and_store(bool def_nan, T *out, int32_t *st_out, uint64_t oidx) {
+    Vec<T, VEC> ov;
+    Vec<int32_t, VEC> os;
+    finish(def_nan, ov, os);
     if constexpr (NT) {
       store_stream<T, VEC>(out + oidx, ov);
       if (st_out) store_stream<int32_t, VEC>(st_out + oidx, os);

@@ -487,11 +487,12 @@ def _boundary_cases():
     """Seeded sample of one-axis drillUps whose extents sit on the boundaries between the kernel
     regimes (vector width, 128 vector slots, the 16 KiB tile, 256-member groups, 131 072 outputs)."""
     rng = np.random.default_rng(20240807)
-    inners = [1, 2, 3, 4, 5, 15, 16, 17, 31, 32, 33, 63, 64, 100, 127, 128, 129, 255, 256, 508, 511, 512, 513, 516, 1000, 1024, 4096, 5000]
+    inners = [1, 2, 3, 4, 5, 15, 16, 17, 31, 32, 33, 63, 64, 100, 127, 128, 129, 255, 256, 257, 508, 511, 512, 513, 515, 516, 1000, 1001, 1023,
+              1024, 1026, 4096, 4099, 5000]
     ks = [1, 2, 3, 10, 30, 255, 256, 257, 1000, 4097]
     outers = [1, 2, 3, 7, 64, 100]
     cases = []
-    while len(cases) < 700:
+    while len(cases) < 900:
         inner, K, outer = int(rng.choice(inners)), int(rng.choice(ks)), int(rng.choice(outers))
         if outer * K * inner > 3_000_000:
             continue
