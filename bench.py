@@ -350,9 +350,9 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32 cells, f64 accumulate",
+            "dtype": "f64",  # the arithmetic type: float64 accumulators over Float32 cells (config.cell_type)
             "data": "synthetic (seeded mulberry32, values in [0.5,1.5), generated on device)",
-            "config": {"workload": workload, "shape": lens, "cells_per_gpu": local_cells,
+            "config": {"workload": workload, "shape": lens, "cells_per_gpu": local_cells, "cell_type": "float32",
                        "kernel": op.local.plan.kernel_name, "collective": ("reduce_scatter" if op.scatter else "all_reduce") if world > 1 else "none",
                        "steps_pipelined": bool(world > 1 and not args.serial_steps)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
