@@ -126,7 +126,7 @@ __global__ __launch_bounds__(kBlock) void drillup_rows_kernel(const T *__restric
   const uint32_t chunk = bid - (uint32_t)og * bpr;
   const uint64_t g = og % a.G;
   const uint64_t o = og / a.G;
-  const uint64_t iv = (uint64_t)chunk * kBlock + threadIdx.x;
+  const uint64_t iv = (uint64_t)chunk * blockDim.x + threadIdx.x;  // workgroups of 256, 128 or 64 lanes (launcher)
   if (iv >= a.n_vec) return;
   const uint64_t i0 = iv * VEC;
   const bool def_nan = a.def_nan != 0;
@@ -169,18 +169,21 @@ __global__ __launch_bounds__(kBlock) void drillup_rows_kernel(const T *__restric
 }
 
 // Flat regime (inner small): one lane per VEC output cells, (outer, group) decoded per lane.
-template <typename T, int METHOD, bool HAS_STATUS, int VEC, bool FAST>
+// IDX: the lane index is decoded in 32-bit arithmetic when the launch has < 2^32 lanes (a 64-bit
+// division is a long software sequence on CDNA).
+template <typename T, int METHOD, bool HAS_STATUS, int VEC, bool FAST, typename IDX>
 __global__ __launch_bounds__(kBlock) void drillup_flat_kernel(const T *__restrict__ in,
                                                               const int32_t *__restrict__ st_in,
                                                               T *__restrict__ out,
                                                               int32_t *__restrict__ st_out,
                                                               const DrillUpAxis a) {
-  const uint64_t t = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (t >= a.total) return;
-  const uint64_t iv = t % a.n_vec;
-  const uint64_t og = t / a.n_vec;
-  const uint64_t g = og % a.G;
-  const uint64_t o = og / a.G;
+  const IDX t = (IDX)blockIdx.x * kBlock + threadIdx.x;
+  if ((uint64_t)t >= a.total) return;
+  const IDX nv = (IDX)a.n_vec, ng = (IDX)a.G;
+  const uint64_t iv = t % nv;
+  const IDX og = t / nv;
+  const uint64_t g = og % ng;
+  const uint64_t o = og / ng;
   const uint64_t i0 = iv * VEC;
   const bool def_nan = a.def_nan != 0;
 
@@ -204,6 +207,8 @@ __global__ __launch_bounds__(kBlock) void drillup_flat_kernel(const T *__restric
     Vec<int32_t, VEC> s[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
+      // (cached loads: with short row pieces neighbouring outputs share lines — streaming loads
+      // took [3001,3333,10] from 89 to 159 us)
       v[u] = load_vec<T, VEC>(base + k[u] * a.inner);
       if constexpr (HAS_STATUS) s[u] = load_vec<int32_t, VEC>(sbase + k[u] * a.inner);
     }
@@ -2028,7 +2033,20 @@ static hipError_t drillup_axis_launch(const T *in, const int32_t *st_in, T *out,
   constexpr bool kAdditive = (METHOD == OLAP_SUM || METHOD == OLAP_AVERAGE || METHOD == OLAP_PARTIAL_AVERAGE);
   const bool fast = kAdditive && !HS && !a.def_nan;
   const bool contig = a.order == nullptr;
-  const uint64_t row_blocks = a.outer * a.G * a.blocks_per_row;
+  // a row takes a whole number of workgroups: 271 slots fill 271 of 512 lanes at 256 lanes per
+  // workgroup, 271 of 320 at 64 — the row regime picks the largest workgroup that fills >= 85 %
+  unsigned row_lanes = kBlock;
+  {
+    static const int forced = getenv("OLAP_ROWS_LANES") ? atoi(getenv("OLAP_ROWS_LANES")) : 0;
+    double best = 0.0;
+    for (unsigned cand : {256u, 128u, 64u}) {
+      const double fill = (double)a.n_vec / (double)(((a.n_vec + cand - 1) / cand) * cand);
+      if (fill >= 0.85) { row_lanes = cand; best = 1.0; break; }
+      if (fill > best) { best = fill; row_lanes = cand; }
+    }
+    if (forced == 64 || forced == 128 || forced == 256) row_lanes = (unsigned)forced;
+  }
+  const uint64_t row_blocks = a.outer * a.G * ((a.n_vec + row_lanes - 1) / row_lanes);
   const bool rows = a.n_vec >= 128 && row_blocks < 0x7FFFFFFFull;
   // Rows in flight per lane.  With full 16 B lanes and rows that fill whole workgroups ONE is
   // fastest for the plain streaming forms (tools/microbench.hip, profiles/microbench_r01.txt: 67 us
@@ -2086,9 +2104,15 @@ static hipError_t drillup_axis_launch(const T *in, const int32_t *st_in, T *out,
 #undef OLAP_GTILE
     return hipGetLastError();
   }
-#define OLAP_ROWS(C, F) hipLaunchKernelGGL((drillup_rows_kernel<T, METHOD, HS, VEC, U, C, F>), (unsigned)row_blocks, kBlock, 0, stream, in, st_in, out, st_out, a)
-#define OLAP_ROWS1(C, F) hipLaunchKernelGGL((drillup_rows_kernel<T, METHOD, HS, VEC, 1, C, F>), (unsigned)row_blocks, kBlock, 0, stream, in, st_in, out, st_out, a)
-#define OLAP_FLAT(F) hipLaunchKernelGGL((drillup_flat_kernel<T, METHOD, HS, VEC, F>), grid_for(a.total), kBlock, 0, stream, in, st_in, out, st_out, a)
+#define OLAP_ROWS(C, F) hipLaunchKernelGGL((drillup_rows_kernel<T, METHOD, HS, VEC, U, C, F>), (unsigned)row_blocks, row_lanes, 0, stream, in, st_in, out, st_out, ar)
+#define OLAP_ROWS1(C, F) hipLaunchKernelGGL((drillup_rows_kernel<T, METHOD, HS, VEC, 1, C, F>), (unsigned)row_blocks, row_lanes, 0, stream, in, st_in, out, st_out, ar)
+#define OLAP_FLAT(F)                                                                                                                              \
+  do {                                                                                                                                             \
+    if (a.total < 0xFFFFFF00ull) hipLaunchKernelGGL((drillup_flat_kernel<T, METHOD, HS, VEC, F, uint32_t>), grid_for(a.total), kBlock, 0, stream, in, st_in, out, st_out, a); \
+    else hipLaunchKernelGGL((drillup_flat_kernel<T, METHOD, HS, VEC, F, uint64_t>), grid_for(a.total), kBlock, 0, stream, in, st_in, out, st_out, a);                        \
+  } while (0)
+  DrillUpAxis ar = a;  // the row regime's own workgroup width
+  ar.blocks_per_row = (a.n_vec + row_lanes - 1) / row_lanes;
   if (rows) {
     if constexpr (kAdditive && !HS) {
       if (fast) {

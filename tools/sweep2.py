@@ -65,3 +65,8 @@ run("[274,3652,100] day in the middle -> month, first", [274, 3652, 100], 1, mon
 run("[10,3001,3333] axis0 -> all (odd inner)", [10, 3001, 3333], 0, np.zeros(10))
 run("[3001,10,3333] axis1 -> all (odd inner)", [3001, 10, 3333], 1, np.zeros(10))
 run("[3001,3333,10] axis1 -> 11 groups (inner 10)", [3001, 3333, 10], 1, np.arange(3333) // 303)
+# rows whose slots fill the last workgroup of a row only partly
+run("[400,100,1200] axis1 -> 10 interleaved (300 slots/row)", [400, 100, 1200], 1, np.arange(100) % 10)
+run("[700,100,700] axis1 -> 10 interleaved (175 slots/row)", [700, 100, 700], 1, np.arange(100) % 10)
+run("[3653,101,271] axis1 -> 10 interleaved (271 4-byte slots)", [3653, 101, 271], 1, np.arange(101) % 10)
+run("[1800,100,540] axis1 -> 10 interleaved (135 slots/row)", [1800, 100, 540], 1, np.arange(100) % 10)
