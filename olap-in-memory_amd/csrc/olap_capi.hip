@@ -1275,8 +1275,8 @@ extern "C" int olap_drilldown_plan(olap_plan **out, int dtype, int default_kind,
     p->dev_err = (unsigned long long *)ev;
     a.err = p->dev_err;
   }
-  const bool dd_lines = p->dd_rows && !(method == OLAP_SUM && p->dd.use_rounding) && (size_t)p->vec * olap_dtype_size(dtype) == 16 &&
-                        (p->axis.inner * olap_dtype_size(dtype)) % 128 != 0;
+  const bool dd_lines = p->dd_rows && !(method == OLAP_SUM && p->dd.use_rounding) && (p->axis.inner * olap_dtype_size(dtype)) % 128 != 0 &&
+                        ((size_t)p->vec * olap_dtype_size(dtype) == 16 || p->axis.inner * olap_dtype_size(dtype) >= 2048);
   p->kernel_name = p->dd_rows ? (dd_lines ? "drilldown_rows_lines_kernel" : "drilldown_rows_kernel") : (p->dd_two_pass ? "drilldown_scale_kernel+gather_kernel" : "drilldown_kernel");
   *out = p;
   return OLAP_OK;
@@ -1349,8 +1349,10 @@ static int run_typed(olap_plan *p, const void *in_v, const int32_t *in_s, void *
         const bool divide = p->method == OLAP_SUM;
         const bool spread = divide && p->dd.use_rounding;
         // rows off the 128-byte grid: store line-aligned windows from LDS (drilldown_rows_lines_kernel)
-        if (!spread && vec * sizeof(T) == 16 && (a.inner * sizeof(T)) % 128 != 0 && !getenv("OLAP_DD_NO_LINES"))
-          e = Launch<T>::drilldown_rows_lines(hs, in, in_s, out, out_s, a, divide, p->dd_longest, stream);
+        const bool whole_groups = vec * sizeof(T) == 16;  // rows are whole 16-byte groups
+        if (!spread && a.aligned16 && (a.inner * sizeof(T)) % 128 != 0 && (whole_groups || a.inner * sizeof(T) >= 2048) &&
+            !getenv("OLAP_DD_NO_LINES"))
+          e = Launch<T>::drilldown_rows_lines(hs, !whole_groups, in, in_s, out, out_s, a, divide, p->dd_longest, stream);
         else
           e = Launch<T>::drilldown_rows(hs, vec, in, in_s, out, out_s, a, divide, p->dd.use_rounding, p->dd_longest, stream);
         break;

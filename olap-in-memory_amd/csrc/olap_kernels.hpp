@@ -1565,7 +1565,11 @@ __global__ __launch_bounds__(kBlock) void drilldown_rows_kernel(const T *__restr
 // child values of the parent window are computed once into LDS and every child row is stored from a
 // window shifted by that row's own misalignment, so each wave stores whole lines; only the two ends
 // of a row are partial.
-template <typename T, bool HAS_STATUS, int VEC>
+// ANY: rows are not even whole 16-byte groups (inner % VEC != 0, the usual case for cubes with odd
+// extents): the parent window is staged cell by cell, a child row's window starts at any cell
+// offset (4 LDS reads per group instead of one) and the groups that straddle a row's ends are
+// stored cell by cell — everything in between still leaves as aligned 16-byte stores.
+template <typename T, bool HAS_STATUS, int VEC, bool ANY>
 __global__ __launch_bounds__(kBlock) void drilldown_rows_lines_kernel(const T *__restrict__ in,
                                                                       const int32_t *__restrict__ st_in,
                                                                       T *__restrict__ out,
@@ -1594,7 +1598,24 @@ __global__ __launch_bounds__(kBlock) void drilldown_rows_lines_kernel(const T *_
   const int64_t w0 = (int64_t)chunk * CH - (int64_t)LINE;
   const T *prow = in + (o * a.G + g) * a.inner;
   const int32_t *psrow = HAS_STATUS ? st_in + (o * a.G + g) * a.inner : nullptr;
-  for (uint32_t slot = threadIdx.x; slot < SLOTS; slot += kBlock) {
+  if constexpr (ANY) {
+    for (uint32_t c = threadIdx.x; c < CH + LINE; c += kBlock) {
+      const int64_t i = w0 + (int64_t)c;
+      T ov = T(0);
+      int32_t os = 0;
+      if (i >= 0 && i < (int64_t)a.inner) {
+        const T pv = prow[i];
+        const double old_value = Cell<T>::to_f64(pv);
+        const bool has = cell_is_set<T>(pv, HAS_STATUS ? psrow[i] : OLAP_STATUS_SET, HAS_STATUS, def_nan) &&
+                         old_value == old_value && old_value != 0.0;  // in-memory.js:386-387
+        const double r = divide ? old_value / n : old_value;           // :419, :422
+        emit_cell<T>(r, has && !is_default_f64(r, def_nan), def_nan, ov, os);
+      }
+      lv[c] = ov;
+      ls[c] = os;
+    }
+  }
+  for (uint32_t slot = threadIdx.x; !ANY && slot < SLOTS; slot += kBlock) {
     const int64_t i = w0 + (int64_t)slot * VEC;
     Vec<T, VEC> ov;
     Vec<int32_t, VEC> os;
@@ -1624,12 +1645,36 @@ __global__ __launch_bounds__(kBlock) void drilldown_rows_lines_kernel(const T *_
   for (uint32_t j = jbeg; j < jend; ++j) {
     const uint64_t k = a.order ? (uint64_t)a.order[j] : (uint64_t)j;
     T *row = out + (o * a.K + k) * a.inner;
-    const uint32_t shift = (uint32_t)(((uintptr_t)row / sizeof(T)) % LINE);  // cells past the line start; a multiple of VEC
+    const uint32_t shift = (uint32_t)(((uintptr_t)row / sizeof(T)) % LINE);  // cells past the line start (a multiple of VEC unless ANY)
     const int64_t i = (int64_t)chunk * CH + (int64_t)threadIdx.x * VEC - (int64_t)shift;
-    if (i < 0 || i >= (int64_t)a.inner) continue;
     const uint32_t at = threadIdx.x * VEC + LINE - shift;  // = i - w0
-    store_stream<T, VEC>(row + i, *reinterpret_cast<const Vec<T, VEC> *>(&lv[at]));
-    if (st_out) store_stream<int32_t, VEC>(st_out + (o * a.K + k) * a.inner + i, *reinterpret_cast<const Vec<int32_t, VEC> *>(&ls[at]));
+    if constexpr (!ANY) {
+      if (i < 0 || i >= (int64_t)a.inner) continue;
+      store_stream<T, VEC>(row + i, *reinterpret_cast<const Vec<T, VEC> *>(&lv[at]));
+      if (st_out) store_stream<int32_t, VEC>(st_out + (o * a.K + k) * a.inner + i, *reinterpret_cast<const Vec<int32_t, VEC> *>(&ls[at]));
+    } else {
+      if (i + (int64_t)VEC <= 0 || i >= (int64_t)a.inner) continue;
+      Vec<T, VEC> ov;
+      Vec<int32_t, VEC> os;
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        ov.v[e] = lv[at + e];
+        os.v[e] = ls[at + e];
+      }
+      int32_t *srow = st_out ? st_out + (o * a.K + k) * a.inner : nullptr;
+      if (i >= 0 && i + (int64_t)VEC <= (int64_t)a.inner) {  // (row + i) is 16 B aligned by construction
+        store_stream<T, VEC>(row + i, ov);
+        if (srow) store_stream<int32_t, VEC>(srow + i, os);
+      } else {  // the group straddles an end of the row
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          if (i + e >= 0 && i + e < (int64_t)a.inner) {
+            row[i + e] = ov.v[e];
+            if (srow) srow[i + e] = os.v[e];
+          }
+        }
+      }
+    }
   }
 }
 
@@ -1988,7 +2033,7 @@ struct Launch {
                               const DrillDown &a, hipStream_t stream);
   static hipError_t drilldown_rows(bool has_status, int vec, const T *in, const int32_t *st_in, T *out, int32_t *st_out,
                                    const DrillUpAxis &a, int divide, int use_rounding, uint32_t longest_group, hipStream_t stream);
-  static hipError_t drilldown_rows_lines(bool has_status, const T *in, const int32_t *st_in, T *out, int32_t *st_out,
+  static hipError_t drilldown_rows_lines(bool has_status, bool any_shift, const T *in, const int32_t *st_in, T *out, int32_t *st_out,
                                          const DrillUpAxis &a, int divide, uint32_t longest_group, hipStream_t stream);
   static hipError_t drilldown_scale(bool has_status, const T *in, const int32_t *st_in, T *q, const DrillDownScale &a,
                                     hipStream_t stream);
@@ -2399,7 +2444,7 @@ hipError_t Launch<T>::drilldown_rows(bool has_status, int vec, const T *in, cons
 }
 
 template <typename T>
-hipError_t Launch<T>::drilldown_rows_lines(bool has_status, const T *in, const int32_t *st_in, T *out, int32_t *st_out,
+hipError_t Launch<T>::drilldown_rows_lines(bool has_status, bool any_shift, const T *in, const int32_t *st_in, T *out, int32_t *st_out,
                                            const DrillUpAxis &a, int divide, uint32_t longest_group, hipStream_t stream) {
   constexpr int V = 16 / (int)sizeof(T);
   constexpr uint32_t LINE = 128 / sizeof(T);
@@ -2408,10 +2453,10 @@ hipError_t Launch<T>::drilldown_rows_lines(bool has_status, const T *in, const i
   const uint64_t blocks = a.outer * a.G * bpr * segments;
   if (blocks == 0) return hipSuccess;
   if (blocks >= 0x7FFFFFFFull) return hipErrorInvalidValue;
-  if (has_status)
-    hipLaunchKernelGGL((drilldown_rows_lines_kernel<T, true, V>), (unsigned)blocks, kBlock, 0, stream, in, st_in, out, st_out, a, divide, segments, (uint32_t)bpr);
-  else
-    hipLaunchKernelGGL((drilldown_rows_lines_kernel<T, false, V>), (unsigned)blocks, kBlock, 0, stream, in, st_in, out, st_out, a, divide, segments, (uint32_t)bpr);
+#define OLAP_DDL(HS, ANY) hipLaunchKernelGGL((drilldown_rows_lines_kernel<T, HS, V, ANY>), (unsigned)blocks, kBlock, 0, stream, in, st_in, out, st_out, a, divide, segments, (uint32_t)bpr)
+  if (has_status) { if (any_shift) OLAP_DDL(true, true); else OLAP_DDL(true, false); }
+  else { if (any_shift) OLAP_DDL(false, true); else OLAP_DDL(false, false); }
+#undef OLAP_DDL
   return hipGetLastError();
 }
 

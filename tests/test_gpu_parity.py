@@ -547,9 +547,9 @@ def test_drillup_regime_boundaries(outer, K, inner, kind, method, type_name, def
 
 def _down_cases():
     rng = np.random.default_rng(8072024)
-    inners = [1, 3, 4, 17, 32, 100, 127, 128, 129, 511, 512, 516, 520, 1000, 1024, 2056]
+    inners = [1, 3, 4, 17, 32, 100, 127, 128, 129, 511, 512, 513, 515, 516, 520, 1000, 1001, 1023, 1024, 1026, 2049, 2056]
     cases = []
-    while len(cases) < 140:
+    while len(cases) < 260:
         inner, G, outer = int(rng.choice(inners)), int(rng.choice([1, 2, 5, 12, 40])), int(rng.choice([1, 2, 3, 9]))
         fan = int(rng.choice([1, 2, 3, 7, 19, 31]))
         if outer * G * fan * inner > 2_000_000:
