@@ -25,6 +25,8 @@ cd "$R"
 timeout -k 10 300 python tools/sweep.py > "$O/sweep.txt" 2>&1 && tail -3 "$O/sweep.txt"
 timeout -k 10 300 python tools/sweep2.py > "$O/sweep_awkward.txt" 2>&1 && tail -3 "$O/sweep_awkward.txt"
 timeout -k 10 200 python tools/dd_bench.py > "$O/dd_bench.txt" 2>&1 && tail -5 "$O/dd_bench.txt"
+timeout -k 10 200 python tools/odd.py 2>&1 | grep -v amdgpu.ids > "$O/odd.txt" && cat "$O/odd.txt"
+timeout -k 10 200 python tools/big.py 2>&1 | grep -v amdgpu.ids > "$O/big.txt" && cat "$O/big.txt"
 timeout -k 10 200 node tools/js_bench.js > "$O/js_bench.txt" 2>&1 && tail -5 "$O/js_bench.txt"
 timeout -k 10 200 node tools/js_reference_benchmark.js > "$O/js_reference_benchmark.txt" 2>&1 && tail -3 "$O/js_reference_benchmark.txt"
 timeout -k 10 200 node tools/js_chain.js > "$O/js_chain.txt" 2>&1 && tail -3 "$O/js_chain.txt"
