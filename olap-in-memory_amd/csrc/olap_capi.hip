@@ -429,6 +429,7 @@ extern "C" int olap_drillup_plan(olap_plan **out, int dtype, int default_kind, i
       uint32_t longest = 0;
       for (size_t gi = 0; gi + 1 < gstart.size(); ++gi) longest = std::max(longest, gstart[gi + 1] - gstart[gi]);
       const uint64_t cells = a.outer * a.G * a.inner;
+      // (a wavefront per 271-cell row was tried for more outputs than this: 260 us against the tile's 103)
       if (cells > 0 && cells < 131072 && longest >= 256) {
         DrillUpReduce &rd = p->reduce;
         uint64_t S;
@@ -453,6 +454,12 @@ extern "C" int olap_drillup_plan(olap_plan **out, int dtype, int default_kind, i
               (uint64_t)rows4 * a.inner <= (uint64_t)rd.unit * 4) {
             rd.vec4 = 1;
             rd.rows = rows4;
+            rd.seg_len = (uint32_t)seg_len;
+          } else if (contiguous && a.G == 1 && olap_dtype_size(dtype) == 4 && a.inner == 1) {
+            // rows at any cell offset: aligned 16-byte groups with masked ends (every lane of the unit busy)
+            rd.vec4 = 1;
+            rd.edge = 1;
+            rd.rows = rd.unit * 4;
             rd.seg_len = (uint32_t)seg_len;
           }
         } else {

@@ -494,6 +494,7 @@ struct DrillUpReduce {
   uint32_t rows;      // member rows a unit reads per step: power of two, rows * inner <= unit
   uint32_t unit;      // lanes cooperating on one (outer, group, segment): 64 (a wavefront) or 256
   uint32_t vec4;      // 1: the 16 B form (drillup_reduce4_kernel) applies; `rows` is then sized for unit*4 cells
+  uint32_t edge;      // 16 B form with inner == 1 and rows at ANY cell offset (K % 4 != 0): aligned groups, masked ends
   Partial *part;      // [outer*G*inner * S]
 };
 
@@ -651,7 +652,55 @@ __global__ __launch_bounds__(kBlock) void drillup_reduce4_kernel(const T *__rest
   Partial p[4];
 #pragma unroll
   for (int e = 0; e < 4; ++e) p[e] = partial_identity<METHOD>();
-  if (active) {
+  if (active && rd.edge) {
+    // inner == 1, the row starts anywhere inside a 16-byte group: sweep the ALIGNED groups that cover
+    // [gbeg, gend) of the buffer and let cells outside the row contribute nothing
+    constexpr int U = 4;
+    const int64_t gbeg = (int64_t)(o * a.K) + (int64_t)cell_beg, gend = (int64_t)(o * a.K) + (int64_t)cell_end;
+    const int64_t n_cells = (int64_t)(a.outer * a.K);
+    for (int64_t gi = (gbeg & ~(int64_t)3) + (int64_t)lane * 4; gi < gend; gi += (int64_t)step_cells * U) {
+      Vec<T, 4> x[U];
+      Vec<int32_t, 4> sx[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int64_t g4 = gi + (int64_t)u * step_cells;
+        if (g4 < gend && g4 + 4 <= n_cells) {
+          x[u] = load_stream<T, 4>(in + g4);
+          if constexpr (HAS_STATUS) sx[u] = load_stream<int32_t, 4>(st_in + g4);
+        } else if (g4 < gend) {  // the last group of the buffer, cell by cell
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const bool ok = g4 + e < n_cells;
+            x[u].v[e] = ok ? in[g4 + e] : T(0);
+            if constexpr (HAS_STATUS) sx[u].v[e] = ok ? st_in[g4 + e] : 0;
+          }
+        } else {  // past the segment: nothing to read (the masks below drop these cells)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            x[u].v[e] = T(0);
+            if constexpr (HAS_STATUS) sx[u].v[e] = 0;
+          }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int64_t g4 = gi + (int64_t)u * step_cells;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const bool valid = g4 + e >= gbeg && g4 + e < gend;
+          if constexpr (FAST) {
+            const double v = valid ? Cell<T>::to_f64(x[u].v[e]) : 0.0;
+            p[e].acc += v;
+            p[e].meta += (v != 0.0) ? 1u : 0u;
+          } else {
+            const int32_t st = HAS_STATUS ? sx[u].v[e] : OLAP_STATUS_SET;
+            if (valid && cell_is_set<T>(x[u].v[e], st, HAS_STATUS, def_nan))
+              partial_add<METHOD>(p[e], Cell<T>::to_f64(x[u].v[e]), (uint32_t)(g4 + e - (int64_t)(o * a.K)), def_nan);
+          }
+        }
+      }
+    }
+  } else if (active) {
     constexpr int U = 4;
     constexpr int V = 4;
     for (uint64_t c = cell_beg + lane * 4; c < cell_end; c += (uint64_t)step_cells * U) {

@@ -396,7 +396,9 @@ def test_reduce_regime_shapes(lens, axis, method):
 
 @pytest.mark.parametrize("lens,axis", [([5000, 300], 1), ([4200, 260, 4], 1), ([1000, 264, 8], 1), ([3, 40000, 2], 1), ([100000], 0),
                                        ([2000000], 0), ([400000, 10], 0), ([2, 40000, 64], 1), ([70000, 128], 0), ([3, 1000, 12], 1),
-                                       ([7, 4097, 100], 1), ([2, 9000, 68], 1), ([1, 50000, 24], 1)])
+                                       ([7, 4097, 100], 1), ([2, 9000, 68], 1), ([1, 50000, 24], 1),
+                                       # inner = 1 with rows at odd offsets (K % 4 != 0): aligned groups, masked ends
+                                       ([5000, 301], 1), ([3, 40001], 1), ([100001], 0), ([130000, 257], 1)])
 @pytest.mark.parametrize("method", ["sum", "average", "first", "last", "highest", "lowest", "product"])
 @pytest.mark.parametrize("type_name,default", [("float32", 0.0), ("float32", float("nan")), ("uint32", float("nan"))])
 def test_reduce_regime_to_all(lens, axis, method, type_name, default):
