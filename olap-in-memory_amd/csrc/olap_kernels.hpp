@@ -295,6 +295,56 @@ __global__ __launch_bounds__(kBlock) void drillup_tile_kernel(const T *__restric
   const uint32_t n_out = rows * tl.out_row;
   T *dst = out + row0 * tl.out_row;
   int32_t *sdst = st_out ? st_out + row0 * tl.out_row : nullptr;
+  if constexpr (ALL && FAST) {  // (FAST: sum / average over a 0 default without a mask)
+    // one long row per output (rolling up a last dimension of 256..4096 items): a tile holds a dozen
+    // rows, so a lane per row would leave the workgroup idle — 16 lanes share a row, each sums a
+    // contiguous sixteenth, and the partial sums are added up by a 16-lane shuffle.  Float64 and
+    // re-associated, like the reduce regime and under the same condition (groups of >= 256 members).
+    if (tl.inner == 1 && a.K >= 256) {
+      constexpr uint32_t L = 16;
+      for (uint32_t slot = threadIdx.x; slot < rows * L; slot += kBlock) {
+        const uint32_t r = slot / L, part = slot % L;
+        const uint32_t kb = (uint32_t)((uint64_t)a.K * part / L), ke = (uint32_t)((uint64_t)a.K * (part + 1) / L);
+        const T *cells = tile + r * tl.row_elems;
+        double acc = 0.0;
+        uint32_t cnt = 0;  // contributions (cells that are set, i.e. non-zero): `average` divides by it
+        uint32_t k = kb;
+        for (; k + 4 <= ke; k += 4) {
+          const T x0 = cells[k], x1 = cells[k + 1], x2 = cells[k + 2], x3 = cells[k + 3];
+          acc += Cell<T>::to_f64(x0);
+          acc += Cell<T>::to_f64(x1);
+          acc += Cell<T>::to_f64(x2);
+          acc += Cell<T>::to_f64(x3);
+          if constexpr (METHOD != OLAP_SUM)
+            cnt += (Cell<T>::is_default(x0, false) ? 0u : 1u) + (Cell<T>::is_default(x1, false) ? 0u : 1u) +
+                   (Cell<T>::is_default(x2, false) ? 0u : 1u) + (Cell<T>::is_default(x3, false) ? 0u : 1u);
+        }
+        for (; k < ke; ++k) {
+          acc += Cell<T>::to_f64(cells[k]);
+          if constexpr (METHOD != OLAP_SUM) cnt += Cell<T>::is_default(cells[k], false) ? 0u : 1u;
+        }
+#pragma unroll
+        for (uint32_t d = L / 2; d > 0; d >>= 1) {
+          acc += __shfl_down(acc, d, L);
+          if constexpr (METHOD != OLAP_SUM) cnt += __shfl_down(cnt, d, L);
+        }
+        if (part == 0) {
+          Agg<METHOD> agg;
+          agg.acc = acc;
+          agg.count = cnt;
+          agg.has = acc != 0.0 && (METHOD == OLAP_SUM || cnt != 0);
+          agg.finish(def_nan);
+          T ov;
+          int32_t os;
+          emit_cell<T>(agg.acc, agg.has, def_nan, ov, os);
+          if constexpr (METHOD == OLAP_PARTIAL_AVERAGE) os = (int32_t)agg.count;
+          dst[r] = ov;
+          if (sdst) sdst[r] = os;
+        }
+      }
+      return;
+    }
+  }
   for (uint32_t idx = threadIdx.x; idx < n_out; idx += kBlock) {
     const uint32_t r = idx / tl.out_row;
     const uint32_t rem = idx - r * tl.out_row;

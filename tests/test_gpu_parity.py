@@ -787,6 +787,32 @@ def test_drilldown_with_distributions_randomized(seed):
     assert same_typed(out.get_data(), ev)
 
 
+@pytest.mark.parametrize("method", ["sum", "average"])
+@pytest.mark.parametrize("type_name", ["float32", "int32"])
+@pytest.mark.parametrize("K", [257, 1000])
+def test_tile_regime_long_last_dimension(K, type_name, method):
+    """Rolling up a long last dimension with more than 131 072 rows: the tile kernel's 16-lanes-per-row
+    path (float64, re-associated like the reduce regime; the inputs are half-integers, so exact here)."""
+    rng = np.random.default_rng(41)
+    lens = [131500, K]
+    n = lens[0] * K
+    vals = rng.integers(-8, 9, size=n).astype(np.float64) * (0.5 if type_name == "float32" else 1.0)
+    dense = np.where(rng.random(n) < 0.3, 0.0, vals)
+    maps = [np.arange(lens[0], dtype=np.uint32), np.zeros(K, np.uint32)]
+    plan = pkg.Plan.drillup(type_name, 0.0, method, lens, [lens[0], 1], maps)
+    assert plan.kernel_name == "drillup_tile_kernel", plan.kernel_name
+    g = pkg.HipStore(n, type_name, 0.0)
+    g.set_data_f64(dense)
+    out = g.drill_up(lens, [lens[0], 1], maps, method)
+    typed = to_typed(dense, type_name).astype(np.float64).reshape(lens)
+    total = typed.sum(axis=1)
+    count = (typed != 0).sum(axis=1)
+    expect = total if method == "sum" else np.where(count > 0, total / np.maximum(count, 1), 0.0)
+    ev = to_typed(expect, type_name)
+    assert same_typed(out.get_data(), ev)
+    assert np.array_equal(out.get_status() == 2, ev != 0)
+
+
 REORDER_CASES = [
     ([10] * 6, [5, 4, 3, 2, 1, 0], "reorder_brick4_kernel"),          # runs of 100 cells on both sides
     ([12, 7, 20], [2, 1, 0], "reorder_brick4_kernel"),                # one brick = the whole cube
