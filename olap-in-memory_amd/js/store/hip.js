@@ -299,3 +299,4 @@ class HipStore {
 
 module.exports = HipStore;
 module.exports.toPlainArray = toPlainArray;
+module.exports._internals = { visibleDims, effectiveSelection }; // host-side logic, unit-tested without a device

@@ -239,6 +239,23 @@ describe('formula parser (no device)', () => {
   });
 });
 
+describe('pending-selection bookkeeping (host side of the lazy dice)', () => {
+  const { visibleDims, effectiveSelection } = HipStore._internals;
+  it('of two new items naming one old item only the last receives the cells', () => {
+    assert.deepEqual(Array.from(effectiveSelection([2, 0, 2, -1, 1, 0])), [-1, -1, 2, -1, 1, 0]);
+    assert.deepEqual(Array.from(effectiveSelection([])), []);
+  });
+  it('lines up the dimensions a cube still has with those of the pending selection', () => {
+    const pending = (midLen) => ({ midLen: Uint32Array.from(midLen) });
+    assert.deepEqual(visibleDims(pending([3, 1, 5]), [3, 5]), [0, 2]); // the sliced-away dimension is skipped
+    assert.deepEqual(visibleDims(pending([3, 1, 5]), [3, 1, 5]), [0, 1, 2]); // nothing dropped
+    assert.deepEqual(visibleDims(pending([1, 1, 4]), [1, 4]), [0, 2]); // two single-item dimensions: either is fine
+    assert.deepEqual(visibleDims(pending([1, 1]), []), []); // everything sliced away
+    assert.equal(visibleDims(pending([3, 2, 5]), [3, 5]), null); // a dropped dimension must have one item
+    assert.equal(visibleDims(pending([3, 1, 5]), [3, 5, 2]), null); // more dimensions than the selection has
+  });
+});
+
 describe('errors raised before any device work', () => {
   it('store constructor', () => {
     assert.throws(() => new HipStore(4, 'float32', 1), /Invalid default value, only NaN and 0 are supported/);
