@@ -1561,12 +1561,16 @@ extern "C" int olap_total(const void *values, const int32_t *status, uint64_t n,
     double total;
     unsigned long long count;
   } host = {0.0, 0};
-  Acc *dev = nullptr;
-  HIP_TRY(dev_alloc((void **)&dev, sizeof(Acc)));
-  hipError_t e = hipMemcpyAsync(dev, &host, sizeof(host), hipMemcpyHostToDevice, (hipStream_t)stream);
-  if (e == hipSuccess) {
-    DISPATCH_DTYPE(dtype, e = Launch<T>::total((const T *)values, status, n, default_kind == OLAP_DEFAULT_NAN, &dev->total, &dev->count, (hipStream_t)stream));
+  if (n == 0) {
+    if (total) *total = 0.0;
+    if (n_set) *n_set = 0;
+    return OLAP_OK;
   }
+  // [0]: the result pair, [1..]: one partial slot per workgroup (deterministic two-stage reduction)
+  Acc *dev = nullptr;
+  HIP_TRY(dev_alloc((void **)&dev, sizeof(Acc) * (1 + (size_t)kTotalBlocks)));
+  hipError_t e = hipSuccess;
+  DISPATCH_DTYPE(dtype, e = Launch<T>::total((const T *)values, status, n, default_kind == OLAP_DEFAULT_NAN, dev + 1, &dev->total, &dev->count, (hipStream_t)stream));
   if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
   if (e == hipSuccess) e = hipMemcpy(&host, dev, sizeof(host), hipMemcpyDeviceToHost);
   dev_free(dev);

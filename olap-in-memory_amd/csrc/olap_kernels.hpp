@@ -378,6 +378,7 @@ __global__ __launch_bounds__(kBlock) void drillup_tile_kernel(const T *__restric
   }
 }
 
+constexpr uint32_t kTotalBlocks = 4096;  // workgroups (and partial slots) of the store total
 constexpr uint32_t kGroupTileMaxGroups = 1024;  // groups per tile of the group-tile regime (LDS holds their bounds)
 
 // Group-tile regime: contiguous groups (calendars) whose rows K*inner do not fit LDS — e.g. day ->
@@ -1891,18 +1892,64 @@ __global__ __launch_bounds__(kBlock) void average_finish_kernel(T *values, const
   }
 }
 
-// float64 total + count of set cells: wave shuffle -> LDS -> one atomic pair per workgroup
-template <typename T>
+// float64 total + count of set cells (in-memory.js:22-28), in two deterministic stages: every
+// workgroup reduces a grid-strided share of the cells (16 B streaming loads, 4 in flight, wave
+// shuffle, LDS) into its own slot of `partial`; total_finish_kernel adds the slots up in a fixed order.
+struct TotalPartial {
+  double sum;
+  unsigned long long count;
+};
+
+template <typename T, bool VECTOR>
 __global__ __launch_bounds__(kBlock) void total_kernel(const T *values, const int32_t *status, uint64_t n, int def_nan_i,
-                                                       double *total, unsigned long long *count) {
+                                                       TotalPartial *partial) {
+  constexpr int V = 16 / sizeof(T);
   const bool def_nan = def_nan_i != 0;
+  const bool hs = status != nullptr;
   double acc = 0.0;
   unsigned long long cnt = 0;
-  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kBlock) {
-    const T v = values[i];
-    if (cell_is_set<T>(v, status ? status[i] : OLAP_STATUS_SET, status != nullptr, def_nan)) {
-      acc += Cell<T>::to_f64(v);
-      ++cnt;
+  if constexpr (VECTOR) {
+    const uint64_t n_groups = n / V;
+    constexpr int U = 4;
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    for (uint64_t q = (uint64_t)blockIdx.x * kBlock + threadIdx.x; q < n_groups; q += stride * U) {
+      Vec<T, V> x[U];
+      Vec<int32_t, V> sx[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const uint64_t qq = q + (uint64_t)u * stride;
+        if (qq < n_groups) {
+          x[u] = load_stream<T, V>(values + qq * V);
+          if (hs) sx[u] = load_stream<int32_t, V>(status + qq * V);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (q + (uint64_t)u * stride < n_groups) {
+#pragma unroll
+          for (int e = 0; e < V; ++e) {
+            if (cell_is_set<T>(x[u].v[e], hs ? sx[u].v[e] : OLAP_STATUS_SET, hs, def_nan)) {
+              acc += Cell<T>::to_f64(x[u].v[e]);
+              ++cnt;
+            }
+          }
+        }
+      }
+    }
+    if (blockIdx.x == 0 && threadIdx.x < n - n_groups * V) {  // the last n % V cells
+      const uint64_t i = n_groups * V + threadIdx.x;
+      if (cell_is_set<T>(values[i], hs ? status[i] : OLAP_STATUS_SET, hs, def_nan)) {
+        acc += Cell<T>::to_f64(values[i]);
+        ++cnt;
+      }
+    }
+  } else {
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kBlock) {
+      const T v = values[i];
+      if (cell_is_set<T>(v, hs ? status[i] : OLAP_STATUS_SET, hs, def_nan)) {
+        acc += Cell<T>::to_f64(v);
+        ++cnt;
+      }
     }
   }
 #pragma unroll
@@ -1919,14 +1966,45 @@ __global__ __launch_bounds__(kBlock) void total_kernel(const T *values, const in
   }
   __syncthreads();
   if (threadIdx.x == 0) {
+    TotalPartial p{0.0, 0};
+    for (int w = 0; w < kBlock / 64; ++w) {
+      p.sum += s_acc[w];
+      p.count += s_cnt[w];
+    }
+    partial[blockIdx.x] = p;
+  }
+}
+
+template <int UNUSED>  // (a template only so that every translation unit may carry it)
+__global__ __launch_bounds__(kBlock) void total_finish_kernel(const TotalPartial *partial, uint32_t n_partial, double *total,
+                                                              unsigned long long *count) {
+  double acc = 0.0;
+  unsigned long long cnt = 0;
+  for (uint32_t i = threadIdx.x; i < n_partial; i += kBlock) {
+    acc += partial[i].sum;
+    cnt += partial[i].count;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    acc += __shfl_down(acc, off, 64);
+    cnt += __shfl_down(cnt, off, 64);
+  }
+  __shared__ double s_acc[kBlock / 64];
+  __shared__ unsigned long long s_cnt[kBlock / 64];
+  if ((threadIdx.x & 63) == 0) {
+    s_acc[threadIdx.x >> 6] = acc;
+    s_cnt[threadIdx.x >> 6] = cnt;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
     double a = 0.0;
     unsigned long long c = 0;
     for (int w = 0; w < kBlock / 64; ++w) {
       a += s_acc[w];
       c += s_cnt[w];
     }
-    atomicAdd(total, a);
-    atomicAdd(count, c);
+    *total = a;
+    *count = c;
   }
 }
 
@@ -2145,7 +2223,7 @@ struct Launch {
                                 hipStream_t stream);
   static hipError_t average_finish(T *values, const int32_t *counts, int32_t *status, uint64_t n, int def_nan,
                                    hipStream_t stream);
-  static hipError_t total(const T *values, const int32_t *status, uint64_t n, int def_nan, double *total,
+  static hipError_t total(const T *values, const int32_t *status, uint64_t n, int def_nan, void *workspace, double *total,
                           unsigned long long *count, hipStream_t stream);
   static hipError_t compact_count(const T *values, const int32_t *status, uint64_t n, uint64_t chunk, unsigned n_chunks,
                                   int def_nan, unsigned long long *counts, hipStream_t stream);
@@ -2609,10 +2687,16 @@ hipError_t Launch<T>::average_finish(T *values, const int32_t *counts, int32_t *
 }
 
 template <typename T>
-hipError_t Launch<T>::total(const T *values, const int32_t *status, uint64_t n, int def_nan, double *total,
+hipError_t Launch<T>::total(const T *values, const int32_t *status, uint64_t n, int def_nan, void *workspace, double *total,
                             unsigned long long *count, hipStream_t stream) {
-  if (n == 0) return hipSuccess;
-  hipLaunchKernelGGL((total_kernel<T>), grid_stride_for(n), kBlock, 0, stream, values, status, n, def_nan, total, count);
+  // workspace: kTotalBlocks TotalPartial slots
+  constexpr uint64_t per_block = (uint64_t)kBlock * (16 / sizeof(T)) * 4;  // cells one sweep of a workgroup covers
+  const unsigned blocks = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(kTotalBlocks, (n + per_block - 1) / per_block));
+  const bool vector = (((uintptr_t)values | (uintptr_t)status) & 15u) == 0;
+  TotalPartial *partial = (TotalPartial *)workspace;
+  if (vector) hipLaunchKernelGGL((total_kernel<T, true>), blocks, kBlock, 0, stream, values, status, n, def_nan, partial);
+  else hipLaunchKernelGGL((total_kernel<T, false>), blocks, kBlock, 0, stream, values, status, n, def_nan, partial);
+  hipLaunchKernelGGL((total_finish_kernel<0>), 1, kBlock, 0, stream, partial, blocks, total, count);
   return hipGetLastError();
 }
 

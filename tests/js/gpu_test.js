@@ -288,6 +288,37 @@ describe('pending selections against eager execution (seeded random chains)', ()
   });
 });
 
+describe('collapse', () => {
+  const chain = (cube) => cube.dimensionIds.reduce((c, id) => c.slice(id, 'all', 'all'), cube);
+  it('additive rules: one total per measure equals the chain of slices', () => {
+    const cube = testCube();
+    cube.createStoredMeasure('signal', {}, 'float32', NaN_);
+    cube.setNestedArray('signal', [[0.5, NaN_], [NaN_, 2.25], [4, NaN_]]);
+    cube.createStoredMeasure('empty_nan', {}, 'int32', NaN_);
+    cube.createStoredMeasure('empty_zero', {}, 'float32', 0);
+    cube.createComputedMeasure('ratio', 'routers / antennas');
+    const fast = cube.collapse();
+    const slow = chain(cube);
+    assert.deepEqual(fast.dimensionIds, []);
+    for (const id of cube.storedMeasureIds) {
+      assert.deepEqual(fast.getData(id), slow.getData(id), id);
+      assert.deepEqual(Array.from(fast.getStatusMap(id).keys()), Array.from(slow.getStatusMap(id).keys()), `${id} keys`);
+    }
+    assert.deepEqual(fast.getData('antennas'), [63]);
+    assert.deepEqual(fast.getData('signal'), [6.75]);
+    assert.deepEqual(fast.storedMeasuresRules, slow.storedMeasuresRules);
+    assert.deepEqual(fast.getData('ratio'), slow.getData('ratio'));
+    assert.deepEqual(fast.getData('ratio'), [66 / 63]);
+  });
+  it('any other rule keeps the chain (an average of averages is not the overall average)', () => {
+    const cube = new Cube([new GenericDimension('a', 'item', ['x', 'y']), new GenericDimension('b', 'item', ['p', 'q', 'r'])]);
+    cube.createStoredMeasure('avg_m', { a: 'average', b: 'sum' }, 'float32', 0);
+    cube.setNestedArray('avg_m', [[1, 2, 3], [4, 0, 6]]);
+    assert.deepEqual(cube.collapse().getData('avg_m'), chain(cube).getData('avg_m'));
+    assert.deepEqual(cube.collapse().getData('avg_m'), [(1 + 4) / 2 + 2 / 1 + (3 + 6) / 2]);
+  });
+});
+
 describe('dimensions', () => {
   it('removeDimension with every aggregator', () => {
     let cube = new Cube([new GenericDimension('location', 'city', ['paris', 'toledo', 'tokyo']), new GenericDimension('period', 'season', ['summer', 'winter'])]);
