@@ -19,7 +19,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 
 def run_workers(engine, tmp_path, world=2):
     out = str(tmp_path / "res")
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", WORLD_SIZE=str(world))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29533 + world), WORLD_SIZE=str(world))
     procs = []
     for r in range(world):
         e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
@@ -92,8 +92,10 @@ def test_partition_rows():
     assert partition_rows(3, 4) == [0, 1, 2, 3, 3]
 
 
-def test_sharded_drillup_gloo_cpu(tmp_path):
-    check(run_workers("oracle", tmp_path))
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_drillup_gloo_cpu(tmp_path, world):
+    """7 rows over 2 ranks (4 + 3) and over 3 ranks (3 + 2 + 2): ragged partitions."""
+    check(run_workers("oracle", tmp_path, world))
 
 
 @pytest.mark.gpu
