@@ -231,6 +231,8 @@ struct olap_plan {
   GatherReduce gr{};
   DrillUpReduce reduce{};                  // S > 0: reduce regime of the one-axis drillUp
   bool dd_two_pass = false;                // float cells, no distributions: scale + broadcast
+  bool dice_lines = false;                 // dice of one dimension, rows not whole 16-byte groups: row copies through
+                                           // drilldown_rows_lines_kernel (uses `axis`, `dd_longest`)
   bool dd_rows = false;                    // one refined axis, wide rows: drilldown_rows_kernel (uses `axis`)
   uint32_t dd_longest = 0;                 // children of the largest parent
   void *dev_tab2 = nullptr;                // second table set (two-pass drillDown)
@@ -613,6 +615,7 @@ extern "C" int olap_dice_plan(olap_plan **out, int dtype, int default_kind, int 
   p->in_cells = product(old_len, ndim);
   p->out_cells = product(new_len, ndim);
   std::vector<RemapDim> dims(ndim);
+  std::vector<char> untouched(ndim > 0 ? ndim : 1, 1);
   uint64_t stride = 1;
   for (int d = ndim - 1; d >= 0; --d) {
     RemapDim &rd = dims[d];
@@ -621,6 +624,7 @@ extern "C" int olap_dice_plan(olap_plan **out, int dtype, int default_kind, int 
     bool ident = old_len[d] == new_len[d];
     for (uint32_t j = 0; ident && j < new_len[d]; ++j) ident = sel[d][j] == (int32_t)j;
     rd.arithmetic = ident;
+    untouched[d] = ident;
     if (!ident) {
       // Map(oldIdx -> newIdx) built left to right (in-memory.js:219-224): of two new items naming
       // the same old item only the LAST receives the cells
@@ -638,6 +642,55 @@ extern "C" int olap_dice_plan(olap_plan **out, int dtype, int default_kind, int 
     return rc;
   }
   p->kernel_name = "gather(dice)";
+  // One diced dimension, every new item names a distinct old item, rows that are not whole 16-byte
+  // groups (cubes with odd extents): the gather would move 4 bytes per lane; instead every selected
+  // source row is copied to its destination row through the line-aligned windows of
+  // drilldown_rows_lines_kernel (a "drillDown" in which each parent has at most one child and
+  // nothing is divided).
+  {
+    int axis = -1, touched = 0;
+    for (int d = 0; d < ndim; ++d)
+      if (!untouched[d]) {
+        axis = d;
+        ++touched;
+      }
+    const uint64_t vf = 16 / olap_dtype_size(dtype);
+    if (touched == 1 && p->out_cells > 0 && !getenv("OLAP_DICE_NO_LINES")) {
+      uint64_t outer = 1, inner = 1;
+      for (int d = 0; d < axis; ++d) outer *= old_len[d];
+      for (int d = axis + 1; d < ndim; ++d) inner *= old_len[d];
+      const uint32_t G = old_len[axis], K = new_len[axis];
+      bool plain = inner % vf != 0 && inner * olap_dtype_size(dtype) >= 2048 && K > 0;
+      std::vector<uint32_t> count(G + 1, 0);
+      for (uint32_t j = 0; plain && j < K; ++j) {
+        if (sel[axis][j] < 0 || count[sel[axis][j] + 1] != 0) plain = false;  // unknown item, or an old item named twice
+        else count[sel[axis][j] + 1] = 1;
+      }
+      const uint64_t bpr = (inner + 128 / olap_dtype_size(dtype) + (uint64_t)kBlock * vf - 1) / ((uint64_t)kBlock * vf);
+      if (plain && outer * G * bpr < 0x7FFFFFFFull) {
+        std::vector<uint32_t> tab(G + 1 + K);
+        for (uint32_t g = 0; g < G; ++g) tab[g + 1] = tab[g] + count[g + 1];
+        for (uint32_t j = 0; j < K; ++j) tab[G + 1 + tab[sel[axis][j]]] = j;  // one child at most per source row
+        void *dev = nullptr;
+        if ((rc = upload(&dev, tab.data(), tab.size() * sizeof(uint32_t)))) {
+          olap_plan_destroy(p);
+          return rc;
+        }
+        p->owned.push_back(dev);
+        DrillUpAxis &ax = p->axis;
+        ax.outer = outer;
+        ax.K = K;
+        ax.inner = inner;
+        ax.G = G;
+        ax.gstart = (const uint32_t *)dev;
+        ax.order = (const uint32_t *)dev + G + 1;
+        ax.def_nan = p->def_nan;
+        p->dd_longest = 1;
+        p->dice_lines = true;
+        p->kernel_name = "drilldown_rows_lines_kernel(dice)";
+      }
+    }
+  }
   *out = p;
   return OLAP_OK;
 }
@@ -1320,6 +1373,12 @@ static int run_typed(olap_plan *p, const void *in_v, const int32_t *in_s, void *
       e = Launch<T>::drillup_generic(p->method, hs, in, in_s, out, out_s, p->gen, stream);
       break;
     case PLAN_GATHER: {
+      if (p->dice_lines && aligned16(in) && aligned16(out) && (!in_s || aligned16(in_s)) && (!out_s || aligned16(out_s))) {
+        DrillUpAxis a = p->axis;
+        a.aligned16 = 1;
+        e = Launch<T>::drilldown_rows_lines(hs, true, in, in_s, out, out_s, a, 2, p->dd_longest, stream);
+        break;
+      }
       Remap r = p->remap;
       int vec = p->vec;
       if (vec > 1 && !(aligned16(in) && aligned16(out) && (!in_s || aligned16(in_s)) && (!out_s || aligned16(out_s)))) {

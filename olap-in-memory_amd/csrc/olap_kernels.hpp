@@ -1705,11 +1705,17 @@ __global__ __launch_bounds__(kBlock) void drilldown_rows_lines_kernel(const T *_
       int32_t os = 0;
       if (i >= 0 && i < (int64_t)a.inner) {
         const T pv = prow[i];
-        const double old_value = Cell<T>::to_f64(pv);
-        const bool has = cell_is_set<T>(pv, HAS_STATUS ? psrow[i] : OLAP_STATUS_SET, HAS_STATUS, def_nan) &&
-                         old_value == old_value && old_value != 0.0;  // in-memory.js:386-387
-        const double r = divide ? old_value / n : old_value;           // :419, :422
-        emit_cell<T>(r, has && !is_default_f64(r, def_nan), def_nan, ov, os);
+        if (divide == 2) {  // dice: the selected source row is copied as it is (set cells keep their value)
+          const bool set = cell_is_set<T>(pv, HAS_STATUS ? psrow[i] : OLAP_STATUS_SET, HAS_STATUS, def_nan);
+          ov = set ? pv : Cell<T>::default_value(def_nan);
+          os = set ? OLAP_STATUS_SET : 0;
+        } else {
+          const double old_value = Cell<T>::to_f64(pv);
+          const bool has = cell_is_set<T>(pv, HAS_STATUS ? psrow[i] : OLAP_STATUS_SET, HAS_STATUS, def_nan) &&
+                           old_value == old_value && old_value != 0.0;  // in-memory.js:386-387
+          const double r = divide ? old_value / n : old_value;           // :419, :422
+          emit_cell<T>(r, has && !is_default_f64(r, def_nan), def_nan, ov, os);
+        }
       }
       lv[c] = ov;
       ls[c] = os;

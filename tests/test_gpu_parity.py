@@ -813,6 +813,39 @@ def test_tile_regime_long_last_dimension(K, type_name, method):
     assert np.array_equal(out.get_status() == 2, ev != 0)
 
 
+@pytest.mark.parametrize("lens,axis", [([7, 9, 513], 1), ([3, 30, 1001], 1), ([5, 4, 2049], 1), ([12, 3, 171], 0), ([2, 40, 515], 1)])
+@pytest.mark.parametrize("type_name,default", [("float32", 0.0), ("float32", float("nan")), ("uint32", float("nan")), ("float64", 0.0), ("int32", 0.0)])
+def test_dice_row_copies_odd_extents(lens, axis, type_name, default):
+    """dice of one dimension of a cube with odd extents, every new item naming a distinct old item
+    (subset, reordered): row copies through line-aligned windows instead of the 4-byte gather."""
+    rng = np.random.default_rng(53)
+    n = int(np.prod(lens))
+    vals = rng.integers(1, 500, size=n).astype(np.float64)
+    dense = np.where(rng.random(n) < 0.3, default, vals)
+    keep = rng.permutation(lens[axis])[: max(1, lens[axis] * 2 // 3)]
+    if lens[0] % 2:
+        keep = np.sort(keep)
+    sel = [np.arange(l, dtype=np.int32) for l in lens]
+    sel[axis] = keep.astype(np.int32)
+    new_len = [len(x) for x in sel]
+    plan = pkg.Plan.dice(type_name, default, lens, new_len, sel)
+    inner = int(np.prod(lens[axis + 1:]))
+    isz = np.dtype(type_name).itemsize
+    expect_lines = inner % (16 // isz) != 0 and inner * isz >= 2048
+    assert plan.kernel_name == ("drilldown_rows_lines_kernel(dice)" if expect_lines else "gather(dice)"), plan.kernel_name
+    o = OracleStore(n, type_name, default)
+    typed = to_typed(dense, type_name).astype(np.float64)
+    if type_name in ("int32", "uint32") and default != default:
+        typed = np.where(np.isnan(dense), np.nan, typed)
+    o.set_data(typed)
+    ev, es = expected_typed(o.dice(lens, new_len, sel))
+    g = pkg.HipStore(n, type_name, default)
+    g.set_data_f64(dense)
+    out = g.dice(lens, new_len, sel)
+    assert np.array_equal(out.get_status(), es)
+    assert same_typed(out.get_data(), ev)
+
+
 REORDER_CASES = [
     ([10] * 6, [5, 4, 3, 2, 1, 0], "reorder_brick4_kernel"),          # runs of 100 cells on both sides
     ([12, 7, 20], [2, 1, 0], "reorder_brick4_kernel"),                # one brick = the whole cube

@@ -50,5 +50,7 @@ run("drillUp location -> 10 interleaved groups", P.drillup("float32", 0.0, "sum"
 run("drillUp product -> all", P.drillup("float32", 0.0, "sum", shape, [3653, 101, 1], [ident(3653), ident(101), np.zeros(271, np.uint32)]), n, 3653 * 101)
 sel = [np.arange(3653, dtype=np.int32), np.arange(0, 101, 3, dtype=np.int32), np.arange(271, dtype=np.int32)]
 run("dice 34 of 101 locations (bytes = 2 x selected)", P.dice("float32", 0.0, shape, [3653, 34, 271], sel), n, 3653 * 34 * 271)
+sel0 = [np.arange(0, 3653, 3, dtype=np.int32), np.arange(101, dtype=np.int32), np.arange(271, dtype=np.int32)]
+run("dice every third day (bytes = 2 x selected)", P.dice("float32", 0.0, shape, [len(sel0[0]), 101, 271], sel0), n, len(sel0[0]) * 101 * 271)
 run("drillDown month -> day", P.drilldown("float32", 0.0, "sum", [G, 101, 271], shape, [month, ident(101), ident(271)]), G * 101 * 271, n)
 run("reorder (product, location, day)", P.reorder("float32", 0.0, shape, [2, 1, 0]), n, n)
