@@ -231,6 +231,8 @@ struct olap_plan {
   GatherReduce gr{};
   DrillUpReduce reduce{};                  // S > 0: reduce regime of the one-axis drillUp
   bool dd_two_pass = false;                // float cells, no distributions: scale + broadcast
+  bool dice_pieces = false;                // dice of one dimension, short rows not whole 16-byte groups: dice_pieces_kernel
+  DicePieces pieces{};
   bool dice_lines = false;                 // dice of one dimension, rows not whole 16-byte groups: row copies through
                                            // drilldown_rows_lines_kernel (uses `axis`, `dd_longest`)
   bool dd_rows = false;                    // one refined axis, wide rows: drilldown_rows_kernel (uses `axis`)
@@ -660,7 +662,32 @@ extern "C" int olap_dice_plan(olap_plan **out, int dtype, int default_kind, int 
       for (int d = 0; d < axis; ++d) outer *= old_len[d];
       for (int d = axis + 1; d < ndim; ++d) inner *= old_len[d];
       const uint32_t G = old_len[axis], K = new_len[axis];
-      bool plain = inner % vf != 0 && inner * olap_dtype_size(dtype) >= 2048 && K > 0;
+      // short rows: one wavefront per (outer, new item) piece, any selection (dice_pieces_kernel)
+      if (inner % vf != 0 && inner * olap_dtype_size(dtype) >= 256 && inner * olap_dtype_size(dtype) <= kPieceBytes && K > 0 &&
+          outer * K < 0x1FFFFFFFFull && !getenv("OLAP_DICE_NO_PIECES")) {
+        std::vector<int32_t> eff(K, -1);
+        std::vector<int64_t> last(G ? G : 1, -1);
+        for (uint32_t j = 0; j < K; ++j)
+          if (sel[axis][j] >= 0) last[sel[axis][j]] = j;
+        for (uint32_t j = 0; j < K; ++j)
+          if (sel[axis][j] >= 0 && last[sel[axis][j]] == (int64_t)j) eff[j] = sel[axis][j];
+        void *dev = nullptr;
+        if ((rc = upload(&dev, eff.data(), eff.size() * sizeof(int32_t)))) {
+          olap_plan_destroy(p);
+          return rc;
+        }
+        p->owned.push_back(dev);
+        p->pieces.outer = outer;
+        p->pieces.k_old = G;
+        p->pieces.k_new = K;
+        p->pieces.inner = inner;
+        p->pieces.n_in_cells = p->in_cells;
+        p->pieces.sel = (const int32_t *)dev;
+        p->pieces.def_nan = p->def_nan;
+        p->dice_pieces = true;
+        p->kernel_name = "dice_pieces_kernel";
+      }
+      bool plain = !p->dice_pieces && inner % vf != 0 && inner * olap_dtype_size(dtype) >= 2048 && K > 0;
       std::vector<uint32_t> count(G + 1, 0);
       for (uint32_t j = 0; plain && j < K; ++j) {
         if (sel[axis][j] < 0 || count[sel[axis][j] + 1] != 0) plain = false;  // unknown item, or an old item named twice
@@ -1373,6 +1400,10 @@ static int run_typed(olap_plan *p, const void *in_v, const int32_t *in_s, void *
       e = Launch<T>::drillup_generic(p->method, hs, in, in_s, out, out_s, p->gen, stream);
       break;
     case PLAN_GATHER: {
+      if (p->dice_pieces && aligned16(in) && aligned16(out) && (!in_s || aligned16(in_s)) && (!out_s || aligned16(out_s))) {
+        e = Launch<T>::dice_pieces(hs, in, in_s, out, out_s, p->pieces, stream);
+        break;
+      }
       if (p->dice_lines && aligned16(in) && aligned16(out) && (!in_s || aligned16(in_s)) && (!out_s || aligned16(out_s))) {
         DrillUpAxis a = p->axis;
         a.aligned16 = 1;

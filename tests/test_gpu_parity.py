@@ -813,9 +813,11 @@ def test_tile_regime_long_last_dimension(K, type_name, method):
     assert np.array_equal(out.get_status() == 2, ev != 0)
 
 
-@pytest.mark.parametrize("lens,axis", [([7, 9, 513], 1), ([3, 30, 1001], 1), ([5, 4, 2049], 1), ([12, 3, 171], 0), ([2, 40, 515], 1)])
+@pytest.mark.parametrize("lens,axis", [([7, 9, 513], 1), ([3, 30, 1001], 1), ([5, 4, 2049], 1), ([12, 3, 171], 0), ([2, 40, 515], 1),
+                                       ([300, 7, 65], 1), ([3, 5, 7, 33], 1), ([1, 6, 1023], 1)])
 @pytest.mark.parametrize("type_name,default", [("float32", 0.0), ("float32", float("nan")), ("uint32", float("nan")), ("float64", 0.0), ("int32", 0.0)])
-def test_dice_row_copies_odd_extents(lens, axis, type_name, default):
+@pytest.mark.parametrize("messy", [False, True])
+def test_dice_row_copies_odd_extents(lens, axis, type_name, default, messy):
     """dice of one dimension of a cube with odd extents, every new item naming a distinct old item
     (subset, reordered): row copies through line-aligned windows instead of the 4-byte gather."""
     rng = np.random.default_rng(53)
@@ -825,14 +827,22 @@ def test_dice_row_copies_odd_extents(lens, axis, type_name, default):
     keep = rng.permutation(lens[axis])[: max(1, lens[axis] * 2 // 3)]
     if lens[0] % 2:
         keep = np.sort(keep)
+    if messy:  # an unknown item and an old item named twice (only its last mention receives the cells)
+        keep = np.concatenate([keep[:1], [-1], keep, keep[:1]])
     sel = [np.arange(l, dtype=np.int32) for l in lens]
     sel[axis] = keep.astype(np.int32)
     new_len = [len(x) for x in sel]
     plan = pkg.Plan.dice(type_name, default, lens, new_len, sel)
     inner = int(np.prod(lens[axis + 1:]))
     isz = np.dtype(type_name).itemsize
-    expect_lines = inner % (16 // isz) != 0 and inner * isz >= 2048
-    assert plan.kernel_name == ("drilldown_rows_lines_kernel(dice)" if expect_lines else "gather(dice)"), plan.kernel_name
+    odd = inner % (16 // isz) != 0
+    if odd and 256 <= inner * isz <= 4096:
+        expected = "dice_pieces_kernel"            # one wavefront per row piece
+    elif odd and inner * isz >= 2048 and not messy:
+        expected = "drilldown_rows_lines_kernel(dice)"  # row copies through line-aligned windows
+    else:
+        expected = "gather(dice)"
+    assert plan.kernel_name == expected, plan.kernel_name
     o = OracleStore(n, type_name, default)
     typed = to_typed(dense, type_name).astype(np.float64)
     if type_name in ("int32", "uint32") and default != default:

@@ -26,7 +26,8 @@ G = int(month.max()) + 1
 ident = lambda l: np.arange(l, dtype=np.uint32)  # noqa: E731
 
 
-def run(name, plan, n_in, n_out):
+def run(name, plan, n_in, n_out, n_read=None):
+    """n_read: cells actually read when the operation touches only part of its input (dice)."""
     vals = eng.empty(n_in, "float32")
     pkg.capi.check(L.olap_fill_seeded(vals.data_ptr(), None, n_in, 0, 2, 99, 1.0, eng.stream()))
     out = eng.empty(n_out, "float32")
@@ -40,7 +41,7 @@ def run(name, plan, n_in, n_out):
     b.record()
     torch.cuda.synchronize()
     ms = a.elapsed_time(b) / 20
-    gbs = (n_in + n_out) * 4 / (ms * 1e-3) / 1e9
+    gbs = ((n_in if n_read is None else n_read) + n_out) * 4 / (ms * 1e-3) / 1e9
     print("%-46s %9.1f us %9.1f GB/s  %.3f  %s" % (name, ms * 1e3, gbs, gbs / 8000, plan.kernel_name), flush=True)
 
 
@@ -49,8 +50,8 @@ run("drillUp day -> month", P.drillup("float32", 0.0, "sum", shape, [G, 101, 271
 run("drillUp location -> 10 interleaved groups", P.drillup("float32", 0.0, "sum", shape, [3653, 10, 271], [ident(3653), (np.arange(101) % 10).astype(np.uint32), ident(271)]), n, 3653 * 10 * 271)
 run("drillUp product -> all", P.drillup("float32", 0.0, "sum", shape, [3653, 101, 1], [ident(3653), ident(101), np.zeros(271, np.uint32)]), n, 3653 * 101)
 sel = [np.arange(3653, dtype=np.int32), np.arange(0, 101, 3, dtype=np.int32), np.arange(271, dtype=np.int32)]
-run("dice 34 of 101 locations (bytes = 2 x selected)", P.dice("float32", 0.0, shape, [3653, 34, 271], sel), n, 3653 * 34 * 271)
+run("dice 34 of 101 locations (bytes = 2 x selected)", P.dice("float32", 0.0, shape, [3653, 34, 271], sel), n, 3653 * 34 * 271, 3653 * 34 * 271)
 sel0 = [np.arange(0, 3653, 3, dtype=np.int32), np.arange(101, dtype=np.int32), np.arange(271, dtype=np.int32)]
-run("dice every third day (bytes = 2 x selected)", P.dice("float32", 0.0, shape, [len(sel0[0]), 101, 271], sel0), n, len(sel0[0]) * 101 * 271)
+run("dice every third day (bytes = 2 x selected)", P.dice("float32", 0.0, shape, [len(sel0[0]), 101, 271], sel0), n, len(sel0[0]) * 101 * 271, len(sel0[0]) * 101 * 271)
 run("drillDown month -> day", P.drilldown("float32", 0.0, "sum", [G, 101, 271], shape, [month, ident(101), ident(271)]), G * 101 * 271, n)
 run("reorder (product, location, day)", P.reorder("float32", 0.0, shape, [2, 1, 0]), n, n)
