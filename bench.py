@@ -1,27 +1,37 @@
 #!/usr/bin/env python3
 """bench.py — cells aggregated / s on drillUp(sum), MI355X.
 
-  python bench.py [--gpus N --steps K --warmup W]          (N > 1: launched by torch.distributed.run)
+  python bench.py [--gpus N --steps K --warmup W]
+
+With N > 1 and no WORLD_SIZE in the environment the script starts its N ranks itself (a child
+`python -m torch.distributed.run`, before anything here touches the GPU) and relays rank 0's line;
+under torch.distributed.run it is one of the ranks.
 
 A step is one drillUp(sum) of the outermost dimension over a device-resident Float32 measure
 (in-memory.js:265-334 through libolapgpu's C ABI):
 
-  N = 1   BASELINE.json's 10^8-cell cube, shape [10]*8, dim0 -> 'all'   (the configuration the
-          >= 70 % HBM-read target is quoted on; configs[1]'s 10^6-cell cube fits the Infinity Cache
-          and is reported beside it as `cache_resident_1e6`)
-  N > 1   the 10^9-cell family sharded on dim0, 40 rows per GPU: [40*N,5,5,5,5,5,5,10,20]
-          (1.25e8 cells per GPU, = configs[3]'s shard-friendly shape at N = 8); each rank reduces
-          its rows, one RCCL reduce-scatter over xGMI combines the partials.  Weak scaling.
+  N = 1   BASELINE.json's 10^8-cell cube, shape [10]*8, dim0 -> 'all' (the configuration the >= 70 %
+          HBM-read target is quoted on).  Reported beside it: configs[1]'s 10^6-cell cube
+          (`cache_resident_1e6`), configs[2]'s chain, configs[4]'s calendar roll-up, and configs[3]'s
+          WHOLE 10^9-cell cube on this one GPU in both shapes (`config4_single_gpu`) — the N = 1 point
+          of the 10^9 scaling series.
+  N > 1   configs[3]: the 10^9-cell cube sharded on dim0 (olap_sharded_store / olap_shard_drillup):
+          each rank reduces its rows, ONE RCCL reduce-scatter over xGMI combines the partials.
+          STRONG scaling: the same 10^9 cells at every N.  Headline shape [320,5,5,5,5,5,5,10,20]
+          (40 rows per GPU at N = 8, 12.5 MB partials); the literal [10]*9 (400 MB partials, xGMI-bound
+          by construction) is reported beside it as `literal_shape`.
 
-One JSON line on rank 0.  `value` = input cells of all ranks per second, buffers resident in HBM.
-`roofline` = algorithmic bytes (4 B read per input cell + 4 B value and 4 B status written per
-output cell) / the kernel's mean duration from HIP events on the launch stream.  `cpu_baseline` =
-the CPU oracle (oracle/olap_oracle.c, a single-thread C port of the reference loop) timed on this
-host on a bounded sample; a reported baseline, not a target.
+One JSON line on rank 0.  `value` = input cells of the whole job per second, buffers resident in HBM.
+`roofline` = algorithmic bytes (4 B read per input cell + 4 B written per output cell) / the kernel's
+mean duration from HIP events on the launch stream, against the 8 TB/s peak and against the box's
+plain-read ceiling measured in the same run.  `cpu_baseline*` = CPU forms of the same loop timed on
+this host on bounded samples; reported baselines, not targets.
 """
 import argparse
 import json
 import os
+import shutil
+import subprocess
 import sys
 import time
 
@@ -32,10 +42,12 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec
+FRIENDLY_SHAPE = [320, 5, 5, 5, 5, 5, 5, 10, 20]  # 10^9 cells; 320 rows divide by 2, 4 and 8
+LITERAL_SHAPE = [10] * 9
 
 
-def cpu_baseline(seconds_budget=12.0):
-    """Single-thread C port of the reference's drillUp loop on [10, 2*10^6] (2*10^7 cells)."""
+def cpu_baseline(seconds_budget=8.0):
+    """Single-thread C port of the reference's Map-semantics drillUp loop on [10, 2*10^6] (2*10^7 cells)."""
     from oracle.oracle import OracleStore
 
     lens = [10, 2_000_000]
@@ -53,6 +65,49 @@ def cpu_baseline(seconds_budget=12.0):
     return {"value": n * reps / spent, "unit": "cells/s", "cores": 1, "kind": "port",
             "sample": "drillUp(sum) dim0 of a [10, 2000000] float32 cube (2e7 cells), %d repetitions, "
                       "oracle/olap_oracle.c (Map-semantics C port of in-memory.js:265-334)" % reps}
+
+
+def cpu_baseline_flat(seconds_budget=6.0):
+    """The flat-TypedArray form (README.md:12-14) as plain C loops on the headline shape [10, 10^7]:
+    one thread, and OpenMP over every host core (oracle/flat_baseline.c)."""
+    from oracle.oracle import flat_baseline
+
+    L, max_threads = flat_baseline()
+    K, inner = 10, 10_000_000
+    rng = np.random.default_rng(20240807)
+    a = (0.5 + rng.random(K * inner, dtype=np.float32)).astype(np.float32)
+    o = np.zeros(inner, np.float32)
+    out = {}
+    for label, threads in (("single_thread", 1), ("all_cores", max_threads)):
+        L.flat_drillup_sum(a.ctypes.data, o.ctypes.data, K, inner, threads)  # warm-up: page faults, thread start
+        reps, spent = 0, 0.0
+        while reps < 3 or (spent < seconds_budget / 2 and reps < 50):
+            spent += L.flat_drillup_sum(a.ctypes.data, o.ctypes.data, K, inner, threads)
+            reps += 1
+        out[label] = {"value": K * inner * reps / spent, "unit": "cells/s", "cores": threads, "repetitions": reps}
+    out["kind"] = "port"
+    out["host_cores"] = os.cpu_count()
+    out["sample"] = ("drillUp(sum) dim0 of a dense [10, 10000000] float32 buffer (1e8 cells), float64 accumulators, "
+                     "oracle/flat_baseline.c (plain loops; OpenMP over column blocks for all_cores)")
+    return out
+
+
+def cpu_baseline_js():
+    """The same flat loop in JavaScript over a Float32Array, one thread under node."""
+    node = shutil.which("node")
+    if not node:
+        return {"skipped": "node is not installed on this host"}
+    try:
+        r = subprocess.run([node, os.path.join(ROOT, "oracle", "flat_baseline.js"), "10", "10000000", "8"], stdout=subprocess.PIPE,
+                           stderr=subprocess.PIPE, text=True, timeout=240)
+        if r.returncode != 0:
+            return {"skipped": "node failed: " + r.stderr[-300:]}
+        d = json.loads(r.stdout.strip().splitlines()[-1])
+    except Exception as err:  # a baseline problem must not cost the headline line
+        return {"skipped": str(err)[:300]}
+    return {"value": d["cells_per_s"], "unit": "cells/s", "cores": 1, "host_cores": d["host_cores"], "kind": "port", "node": d["node"],
+            "sample": "drillUp(sum) dim0 of a dense Float32Array [10, 10000000] (1e8 cells), %d repetitions, mean; "
+                      "oracle/flat_baseline.js (timing shape of test/cube-benchmark.js:5-18)" % d["repetitions"]}
 
 
 def read_traffic():
@@ -106,7 +161,7 @@ def bench_config3(pkg, engine, store, torch):
     t1, t2 = engine.empty(10 ** 7, "float32"), engine.empty(10 ** 7, "float32")
     t3, t4 = engine.empty(3 * 10 ** 6, "float32"), engine.empty(3 * 10 ** 5, "float32")
     st = engine.stream()
-    src = store.values.data_ptr()
+    src = store.data_ptr()
 
     # the whole chain as ONE selection over the source cube (what the Node host issues: the slice's
     # single-member roll-up moves no cells, so its dice stays pending and composes with the next one)
@@ -178,16 +233,68 @@ def bench_config5(pkg, engine, torch):
             "drillUp_location_country_us": us2, "kernel": measures[0][1].kernel_name}
 
 
+def bench_1e9_single_gpu(pkg, engine, torch, iters=10):
+    """BASELINE configs[3]'s whole 10^9-cell cube on ONE GPU (4 GB resident), both shapes: the N = 1 point of
+    the strong-scaling series that `bench.py --gpus N` continues."""
+    n = 10 ** 9
+    vals = engine.empty(n, "float32")
+    pkg.capi.check(pkg.lib().olap_fill_seeded(vals.data_ptr(), None, n, 0, 2, 20240807, 1.0, engine.stream()))
+    res = {}
+    for label, shape in (("friendly_shape", FRIENDLY_SHAPE), ("literal_shape", LITERAL_SHAPE)):
+        n_out = n // shape[0]
+        out = engine.empty(n_out, "float32")
+        maps = [np.zeros(shape[0], np.uint32)] + [np.arange(l, dtype=np.uint32) for l in shape[1:]]
+        plan = pkg.Plan.drillup("float32", 0.0, "sum", shape, [1] + shape[1:], maps)
+        us = _time(torch, lambda: plan.run(vals.data_ptr(), None, out.data_ptr(), None, engine.stream()), iters=iters, warm=2)
+        gbs = (n + n_out) * 4 / (us * 1e-6) / 1e9
+        res[label] = {"shape": shape, "us_per_step": us, "cells_per_s": n / (us * 1e-6), "achieved_GBps": gbs, "frac": gbs / HBM_PEAK_GBS,
+                      "kernel": plan.kernel_name}
+        del out
+    del vals
+    torch.cuda.empty_cache()
+    return res
+
+
+def read_ceiling(pkg, engine, torch, buf, n_bytes):
+    """the achievable read ceiling of THIS box — a plain grid-stride 16-byte streaming read of the
+    same 400 MB buffer, measured in the same run (olap_diag_read_ceiling)."""
+    scratch = engine.empty(2048, "float32")
+    L = pkg.lib()
+    us = _time(torch, lambda: pkg.capi.check(L.olap_diag_read_ceiling(buf.data_ptr(), n_bytes, scratch.data_ptr(), engine.stream())), iters=50, warm=5)
+    return n_bytes / (us * 1e-6) / 1e9
+
+
+def launch_ranks(args):
+    """N > 1 without a launcher: start the ranks as a child process tree BEFORE this process touches the GPU
+    (never an exec of a process that has initialised HIP) and relay what they print."""
+    import socket
+
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, text=True)
+    sys.stdout.write(r.stdout)
+    sys.stdout.flush()
+    raise SystemExit(r.returncode)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="N = 1: only the headline workload")
     ap.add_argument("--serial-steps", action="store_true", help="N > 1: no overlap between consecutive steps")
     ap.add_argument("--rehearse", action="store_true",
-                    help="developer aid: N ranks share cuda:0 and talk over gloo (exercises the N>1 code path on a 1-GPU box; numbers are meaningless)")
+                    help="developer aid: the N ranks share cuda:0 and gloo carries the payloads (exercises the N > 1 code path on "
+                         "a 1-GPU box with a 10x smaller cube; the numbers are meaningless)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        launch_ranks(args)
 
     import torch
     import torch.distributed as dist
@@ -195,148 +302,206 @@ def main():
     from __graft_entry__ import load_package
 
     pkg = load_package()
-    from olap_in_memory_amd.sharded import HipEngine, ShardedStore
+    from olap_in_memory_amd import capi
+    from olap_in_memory_amd.sharded import Comm, HipEngine, ShardedStore, exchange_over_process_group
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d" % (args.gpus, args.gpus))
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: libolapgpu has no CPU fallback")
     if args.rehearse:
         local_rank = 0
     torch.cuda.set_device(local_rank)
-    pkg.capi.check(pkg.lib().olap_set_device(local_rank))
+    capi.check(pkg.lib().olap_set_device(local_rank))
     if world > 1:
         if args.rehearse:
             dist.init_process_group(backend="gloo")
         else:
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     engine = HipEngine(torch.device("cuda", local_rank))
-
-    if world == 1:
-        lens = [10] * 8
-        workload = "drillUp(sum) dimension0->all, 8-dim 10^8-cell Float32 cube [10]*8, all cells set"
-    else:
-        lens = [40 * world, 5, 5, 5, 5, 5, 5, 10, 20]
-        workload = ("drillUp(sum) of the sharded dimension0->all, 9-dim cube [%d,5,5,5,5,5,5,10,20] "
-                    "(1.25e8 cells per GPU, %.3g cells), RCCL reduce-scatter of the partials" % (lens[0], float(np.prod(lens))))
-    store = ShardedStore(lens, "float32", 0.0, rank, world, engine).fill_seeded(20240807, 1.0)
-    op = store.plan_drillup_dim0(np.zeros(lens[0], np.uint32), 1, "sum")
-    torch.cuda.synchronize()
+    stream = engine.stream()
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    # At N > 1 the K steps are independent queries over the resident shards; they are issued as a
-    # pipeline (the reduce-scatter of step i overlaps the local reduction of step i+1, two buffer
-    # pairs).  --serial-steps times them strictly one after the other instead.
-    step = op.step if (world == 1 or args.serial_steps) else op.step_pipelined
+    def max_over_ranks(seconds):
+        if world == 1:
+            return seconds
+        t = torch.tensor([seconds], dtype=torch.float64, device="cpu" if args.rehearse else "cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    extra = {}
+    if world == 1:
+        lens = [10] * 8
+        workload = "drillUp(sum) dimension0->all, 8-dim 10^8-cell Float32 cube [10]*8, all cells set"
+        n = int(np.prod(lens))
+        n_out = n // lens[0]
+        values = engine.empty(n, "float32")
+        capi.check(pkg.lib().olap_fill_seeded(values.data_ptr(), None, n, 0, 2, 20240807, 1.0, stream))
+        partial = engine.empty(n_out, "float32")
+        maps = [np.zeros(lens[0], np.uint32)] + [np.arange(l, dtype=np.uint32) for l in lens[1:]]
+        plan = pkg.Plan.drillup("float32", 0.0, "sum", lens, [1] + lens[1:], maps)
+        kernel_name = plan.kernel_name
+        local_cells = n
+
+        def step():
+            plan.run(values.data_ptr(), None, partial.data_ptr(), None, stream)
+
+        def kernel_only():
+            step()
+
+        def finish():
+            pass
+        collective, pipelined, transport = "none", False, "none"
+    else:
+        lens = list(FRIENDLY_SHAPE)
+        if args.rehearse:
+            lens[-1] = 2  # 10^8 cells: gloo moves the payloads through host memory
+        comm = Comm.detached(world, rank, 0) if args.rehearse else Comm.from_process_group(dist, local_rank)
+        transport = comm.transport
+        store = ShardedStore(comm, lens, "float32", 0.0).fill_seeded(20240807, 1.0)
+        pipelined = not (args.serial_steps or args.rehearse)
+        op = store.plan_drillup_dim0(np.zeros(lens[0], np.uint32), 1, "sum", placement=capi.PLACE_SCATTER, depth=2 if pipelined else 1)
+        vals, stat = store.step_inputs()
+        n_out = op.out_cells
+        local_cells = op.local_cells(0)
+        kernel_name = op.kernel_name(0)
+        workload = ("drillUp(sum) of the sharded dimension0->all, 9-dim 10^9-cell Float32 cube %s on %d GPUs (%.4g cells per GPU), "
+                    "one RCCL reduce-scatter of the partials per step" % (lens, world, local_cells))
+        collective = "reduce_scatter"
+
+        if args.rehearse:
+            def step():
+                op.local(0, vals[0], None, stream)
+                exchange_over_process_group(op, dist)
+                op.finish(0, stream)
+        else:
+            def step():
+                op.step(vals, stat, [stream])
+
+        def kernel_only():
+            op.local(0, vals[0], None, stream)
+
+        def finish():
+            op.wait([stream])
+    torch.cuda.synchronize()
+
+    # ---- the timed region: W warm-up steps, then exactly K steps between barriers, max over ranks
     for _ in range(args.warmup):
         step()
-    op.flush()
+    finish()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    op.flush()
+    finish()
     barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if args.rehearse else "cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = max_over_ranks(time.perf_counter() - t0)
 
     # kernel-only duration on the launch stream (HIP events), separately from the step loop
     k0, k1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
     k0.record()
     for _ in range(args.steps):
-        op.local.run(store.values, None, op.partial, None)
+        kernel_only()
     k1.record()
     torch.cuda.synchronize()
     kernel_ms = k0.elapsed_time(k1) / args.steps
 
-    local_cells = store.local_cells
     total_cells = float(np.prod(lens))
-    n_out = op.n_out
-    # bytes = N_in*4 (read) + N_out*4 (write); the Int32 mask is neither read nor
-    # written here because for Float32 cells over a 0 default it is a function of the values
+    # bytes = N_in*4 (read) + N_out*4 (write); the Int32 mask is neither read nor written here
+    # because for Float32 cells over a 0 default it is a function of the values
     alg_bytes = local_cells * 4 + n_out * 4
     achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
 
-    # the same launch with the Int32 status mask read and written (10 % of the cells unset)
-    with_mask = None
-    if world == 1:
-        sparse = ShardedStore(lens, "float32", 0.0, rank, world, engine).fill_seeded(20240807, 0.9)
-        ost = engine.empty(n_out, "int32")
-        for _ in range(5):
-            op.local.run(sparse.values, sparse.status, op.partial, ost)
-        m0, m1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        m0.record()
-        for _ in range(args.steps):
-            op.local.run(sparse.values, sparse.status, op.partial, ost)
-        m1.record()
-        torch.cuda.synchronize()
-        mask_ms = m0.elapsed_time(m1) / args.steps
-        mask_bytes = (local_cells + n_out) * 8
-        with_mask = {"kernel_ms": mask_ms, "algorithmic_bytes": mask_bytes, "achieved_GBps": mask_bytes / (mask_ms * 1e-3) / 1e9,
-                     "frac": mask_bytes / (mask_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "cells_per_s": local_cells / (mask_ms * 1e-3),
-                     "note": "values + Int32 status read and written, 90 % of the cells set"}
-        del sparse
+    if world > 1 and not args.rehearse:
+        # the literal [10]^9 shape of configs[3] beside the headline: rows split 2,2,1,1,... at N = 8 and every
+        # rank ships a 400 MB partial, so the collective dominates; fewer steps, same protocol
+        del op, store
+        torch.cuda.empty_cache()
+        lit = ShardedStore(comm, LITERAL_SHAPE, "float32", 0.0).fill_seeded(20240807, 1.0)
+        lop = lit.plan_drillup_dim0(np.zeros(10, np.uint32), 1, "sum", placement=capi.PLACE_SCATTER, depth=2 if pipelined else 1)
+        lv, ls = lit.step_inputs()
+        k_lit = max(2, min(args.steps, 20))
+        for _ in range(2):
+            lop.step(lv, ls, [stream])
+        lop.wait([stream])
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(k_lit):
+            lop.step(lv, ls, [stream])
+        lop.wait([stream])
+        barrier()
+        lit_elapsed = max_over_ranks(time.perf_counter() - t1)
+        extra["literal_shape"] = {"shape": LITERAL_SHAPE, "steps": k_lit, "ms_per_step": lit_elapsed / k_lit * 1e3,
+                                  "cells_per_s": 1e9 * k_lit / lit_elapsed, "rows_per_rank": [b - a for a, b in zip(lit.bounds, lit.bounds[1:])],
+                                  "partial_bytes_per_rank": int(lop.out_cells) * 4}
+        del lop, lit
 
-    extra = {}
+    with_mask = None
+    ceiling = None
     if world == 1:
-        # configs[1]: 10^6 cells, drillUp on axes 0 / 3 / 5 (resident in the 256 MiB Infinity Cache)
-        small = ShardedStore([10] * 6, "float32", 0.0, 0, 1, engine).fill_seeded(20240807, 1.0)
-        res = {}
-        for axis in (0, 3, 5):
-            lens6 = [10] * 6
-            new6 = list(lens6)
-            new6[axis] = 1
-            maps = [np.zeros(10, np.uint32) if i == axis else np.arange(10, dtype=np.uint32) for i in range(6)]
-            o = engine.make_drillup("float32", 0.0, "sum", lens6, new6, maps)
-            ov, os_ = engine.empty(10 ** 5, "float32"), engine.empty(10 ** 5, "int32")
-            for _ in range(20):
-                o.run(small.values, None, ov, os_)
-            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a.record()
-            for _ in range(200):
-                o.run(small.values, None, ov, os_)
-            b.record()
-            torch.cuda.synchronize()
-            us = a.elapsed_time(b) / 200 * 1e3
-            res["axis%d" % axis] = {"us_per_launch": round(us, 3), "cells_per_s": 1e6 / (us * 1e-6)}
-            # the same 200 launches captured once into a hipGraph and replayed: what is left is the
-            # kernel itself plus the graph's per-node dispatch, without one host launch per query
-            try:
-                side = torch.cuda.Stream()
-                graph = torch.cuda.CUDAGraph()
-                with torch.cuda.stream(side):
-                    o.plan.run(small.values.data_ptr(), None, ov.data_ptr(), os_.data_ptr(), side.cuda_stream)
-                    side.synchronize()
-                    with torch.cuda.graph(graph, stream=side):
-                        for _ in range(200):
-                            o.plan.run(small.values.data_ptr(), None, ov.data_ptr(), os_.data_ptr(), torch.cuda.current_stream().cuda_stream)
-                graph.replay()
-                torch.cuda.synchronize()
-                a.record()
-                for _ in range(5):
+        ceiling = read_ceiling(pkg, engine, torch, values, n * 4)
+        if not args.no_extras:
+            # the same launch with the Int32 status mask read and written (10 % of the cells unset)
+            sv, ss = engine.empty(n, "float32"), engine.empty(n, "int32")
+            capi.check(pkg.lib().olap_fill_seeded(sv.data_ptr(), ss.data_ptr(), n, 0, 2, 20240807, 0.9, stream))
+            ost = engine.empty(n_out, "int32")
+            mask_us = _time(torch, lambda: plan.run(sv.data_ptr(), ss.data_ptr(), partial.data_ptr(), ost.data_ptr(), stream), iters=args.steps, warm=5)
+            mask_bytes = (n + n_out) * 8
+            with_mask = {"kernel_ms": mask_us * 1e-3, "algorithmic_bytes": mask_bytes, "achieved_GBps": mask_bytes / (mask_us * 1e-6) / 1e9,
+                         "frac": mask_bytes / (mask_us * 1e-6) / 1e9 / HBM_PEAK_GBS, "cells_per_s": n / (mask_us * 1e-6),
+                         "note": "values + Int32 status read and written, 90 % of the cells set"}
+            del sv, ss, ost
+
+            # configs[1]: 10^6 cells, drillUp on axes 0 / 3 / 5 (resident in the 256 MiB Infinity Cache)
+            small = engine.empty(10 ** 6, "float32")
+            capi.check(pkg.lib().olap_fill_seeded(small.data_ptr(), None, 10 ** 6, 0, 2, 20240807, 1.0, stream))
+            res = {}
+            for axis in (0, 3, 5):
+                lens6 = [10] * 6
+                new6 = list(lens6)
+                new6[axis] = 1
+                maps6 = [np.zeros(10, np.uint32) if i == axis else np.arange(10, dtype=np.uint32) for i in range(6)]
+                o = pkg.Plan.drillup("float32", 0.0, "sum", lens6, new6, maps6)
+                ov, os_ = engine.empty(10 ** 5, "float32"), engine.empty(10 ** 5, "int32")
+                us = _time(torch, lambda: o.run(small.data_ptr(), None, ov.data_ptr(), os_.data_ptr(), stream), iters=200, warm=20)
+                res["axis%d" % axis] = {"us_per_launch": round(us, 3), "cells_per_s": 1e6 / (us * 1e-6)}
+                # the same 200 launches captured once into a hipGraph and replayed: what is left is the
+                # kernel itself plus the graph's per-node dispatch, without one host launch per query
+                try:
+                    side = torch.cuda.Stream()
+                    graph = torch.cuda.CUDAGraph()
+                    with torch.cuda.stream(side):
+                        o.run(small.data_ptr(), None, ov.data_ptr(), os_.data_ptr(), side.cuda_stream)
+                        side.synchronize()
+                        with torch.cuda.graph(graph, stream=side):
+                            for _ in range(200):
+                                o.run(small.data_ptr(), None, ov.data_ptr(), os_.data_ptr(), torch.cuda.current_stream().cuda_stream)
                     graph.replay()
-                b.record()
-                torch.cuda.synchronize()
-                gus = a.elapsed_time(b) / 1000 * 1e3
-                res["axis%d" % axis].update({"graph_us_per_launch": round(gus, 3), "graph_cells_per_s": 1e6 / (gus * 1e-6)})
-            except Exception as err:  # a capture problem must not cost the headline line
-                res["axis%d" % axis]["graph_error"] = str(err)[:200]
-        extra["cache_resident_1e6"] = res
-        extra["config3_chain"] = bench_config3(pkg, engine, store, torch)
-        extra["config5_time_rollup"] = bench_config5(pkg, engine, torch)
+                    torch.cuda.synchronize()
+                    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    a.record()
+                    for _ in range(5):
+                        graph.replay()
+                    b.record()
+                    torch.cuda.synchronize()
+                    gus = a.elapsed_time(b) / 1000 * 1e3
+                    res["axis%d" % axis].update({"graph_us_per_launch": round(gus, 3), "graph_cells_per_s": 1e6 / (gus * 1e-6)})
+                except Exception as err:  # a capture problem must not cost the headline line
+                    res["axis%d" % axis]["graph_error"] = str(err)[:200]
+            extra["cache_resident_1e6"] = res
+            extra["config3_chain"] = bench_config3(pkg, engine, values, torch)
+            extra["config5_time_rollup"] = bench_config5(pkg, engine, torch)
+            del values, partial
+            torch.cuda.empty_cache()
+            extra["config4_single_gpu"] = bench_1e9_single_gpu(pkg, engine, torch)
 
     if rank == 0:
         line = {
@@ -348,23 +513,28 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            # N = 1 is the 10^8-cell headline; every N > 1 runs the SAME 10^9 cells (config4_single_gpu is their N = 1 point)
+            "scaling": "weak" if world == 1 else "strong",
             "vs_baseline": None,
             "dtype": "f64",  # the arithmetic type: float64 accumulators over Float32 cells (config.cell_type)
             "data": "synthetic (seeded mulberry32, values in [0.5,1.5), generated on device)",
             "config": {"workload": workload, "shape": lens, "cells_per_gpu": local_cells, "cell_type": "float32",
-                       "kernel": op.local.plan.kernel_name, "collective": ("reduce_scatter" if op.scatter else "all_reduce") if world > 1 else "none",
-                       "steps_pipelined": bool(world > 1 and not args.serial_steps)},
+                       "kernel": kernel_name, "collective": collective, "transport": transport, "steps_pipelined": bool(pipelined)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": read_traffic() if world == 1 else None,
                          "kernel_ms": kernel_ms, "algorithmic_bytes": alg_bytes,
                          "hbm_read_frac": local_cells * 4 / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
         }
+        if ceiling:
+            line["roofline"].update({"read_ceiling": ceiling, "frac_of_read_ceiling": achieved / ceiling,
+                                     "read_ceiling_note": "plain 16-byte streaming read of the same 400 MB buffer, same run"})
         if with_mask:
             line["with_status_mask"] = with_mask
         line.update(extra)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
+            line["cpu_baseline_flat"] = cpu_baseline_flat()
+            line["cpu_baseline_js"] = cpu_baseline_js()
         print(json.dumps(line))
     if world > 1:
         dist.barrier()

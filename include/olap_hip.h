@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define OLAP_ABI_VERSION 1
+#define OLAP_ABI_VERSION 2
 #define OLAP_MAX_DIMS 32
 #define OLAP_STATUS_SET 0x2 /* README.md:714-716: the only status bit the reference code implements */
 
@@ -92,7 +92,10 @@ int olap_device_synchronize(void);
  * Plans: an op's small host-side tables (per-dimension index maps) are validated, folded into
  * a launch plan and uploaded once; olap_plan_run() is then pure kernel launches on `stream`
  * (a hipStream_t, NULL = the null stream) and may be captured into a hipGraph.  A plan may be
- * run any number of times on buffers of the planned sizes; it is not thread-safe.
+ * run any number of times on buffers of the planned sizes.  It belongs to the device that was
+ * current when it was built (its tables and scratch live there; running it with another device
+ * current fails with OLAP_ERR_INVALID_ARGUMENT), it is not thread-safe, and because the reduce
+ * regimes keep their scratch in the plan it must not run on two streams at once.
  * ---------------------------------------------------------------------------------------- */
 typedef struct olap_plan olap_plan;
 
@@ -194,6 +197,14 @@ int olap_eval_formula(const int32_t *code, int n_code, const double *consts, int
                       const void *const *in_values, const int32_t *const *in_status, const int *in_dtypes,
                       const int *in_defaults, const double *scalars, int n_scalars, double *out_f64,
                       uint64_t n, void *stream);
+/* Plain copies between host memory and device buffers of the raw-pointer API, for hosts without a
+ * HIP binding of their own (blocking). */
+int olap_memcpy_to_host(void *host, const void *device, uint64_t bytes);
+int olap_memcpy_to_device(void *device, const void *host, uint64_t bytes);
+/* Diagnostic: a plain grid-stride 16-byte streaming read of `bytes` bytes that keeps one float sum
+ * per workgroup (the achievable read ceiling of the box, measured in the same run as
+ * the kernels it is compared with).  `scratch` needs 4 * 2048 bytes.  Asynchronous on `stream`. */
+int olap_diag_read_ceiling(const void *device, uint64_t bytes, void *scratch, void *stream);
 /* `total` getter (in-memory.js:22-28): float64 sum of the set cells, and their count.
  * Synchronises `stream`. */
 int olap_total(const void *values, const int32_t *status, uint64_t n, int dtype, int default_kind,
@@ -269,6 +280,154 @@ int olap_store_reorder(const olap_store *store, olap_store **out, int ndim,
                        const uint32_t *old_len, const int32_t *perm);
 int olap_store_load(olap_store *store, const olap_store *other, int ndim, const uint32_t *my_len,
                     const uint32_t *his_len, const int32_t *const *his_to_mine);
+
+/* ------------------------------------------------------------------------------------------
+ * Multi-GPU: a cube partitioned along its OUTERMOST dimension.  Row-major layout
+ * (src/cube.js:709-728) makes a dimension-0 partition a set of contiguous slabs: rank r owns rows
+ * [bounds[r], bounds[r+1]).  Every store operation that leaves dimension 0 alone runs per shard with
+ * no communication.  drillUp ON dimension 0 (in-memory.js:265-334 with a non-identity map on the
+ * sharded axis — the per-measure store call of src/cube.js:1012-1020) reduces each rank's own rows
+ * into a partial [G, inner0] cube with the ordinary kernels and a row sub-map, then ONE RCCL
+ * collective over xGMI combines the partials (olap_shard_recipe below says which).
+ *
+ * A communicator names the ranks and where they run:
+ *   olap_comm_init_all     one process drives n devices (the Node.js host); ranks 0..n-1 are all local
+ *   olap_comm_init_rank    one process per GPU (bench.py under torch.distributed.run); the 128-byte
+ *                          unique id of rank 0 (olap_comm_unique_id) reaches the others out of band
+ *   olap_comm_init_detached no transport: olap_shard_drillup_exchange() fails, the caller moves the
+ *                          payloads itself (rehearsals over gloo; tests)
+ * Ranks that share one device (init_all with a repeated device, e.g. {0,0}) exchange by reading
+ * each other's buffers directly — RCCL refuses two ranks on one device — so a one-GPU machine can
+ * run the sharded store end to end.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct olap_comm olap_comm;
+#define OLAP_UNIQUE_ID_BYTES 128
+int olap_comm_unique_id(char id[OLAP_UNIQUE_ID_BYTES]);
+int olap_comm_init_rank(olap_comm **comm, const char id[OLAP_UNIQUE_ID_BYTES], int world, int rank, int device);
+int olap_comm_init_all(olap_comm **comm, const int *devices, int n);
+int olap_comm_init_detached(olap_comm **comm, int world, int rank, int device);
+void olap_comm_destroy(olap_comm *comm);
+int olap_comm_world(const olap_comm *comm);
+int olap_comm_local_count(const olap_comm *comm);            /* ranks driven by this process */
+int olap_comm_local_rank(const olap_comm *comm, int local);  /* global rank of local rank `local` */
+int olap_comm_local_device(const olap_comm *comm, int local);
+/* "rccl" | "direct" (same-device ranks) | "detached" */
+const char *olap_comm_transport(const olap_comm *comm);
+
+/* Host-only partition arithmetic (no device needed).
+ * olap_shard_bounds: contiguous balanced split of n_rows over `world` ranks, the first
+ *   n_rows % world ranks get one more row; bounds has world + 1 entries.
+ * olap_shard_dice_bounds: the partition left by a dice of dimension 0 with the strictly ascending
+ *   row list `rows` (every rank keeps its own selected rows, no data moves): new_bounds[r] = number
+ *   of selected rows below bounds[r].  Fails (OLAP_ERR_INVALID_ARGUMENT) when `rows` is not
+ *   strictly ascending inside [0, bounds[world]). */
+int olap_shard_bounds(uint32_t n_rows, int world, uint32_t *bounds);
+int olap_shard_dice_bounds(const uint32_t *bounds, int world, const int32_t *rows, uint32_t n_rows_selected,
+                           uint32_t *new_bounds);
+
+/* What one sharded drillUp of dimension 0 ships and how the partials are combined. */
+typedef enum { OLAP_XCHG_SUM = 0, OLAP_XCHG_MAX = 1, OLAP_XCHG_GATHER = 2 } olap_xchg_op;
+typedef enum {
+  OLAP_FINISH_NONE = 0,     /* sum over a 0 default: the reduced values ARE the result (set <=> != 0) */
+  OLAP_FINISH_RESTORE = 1,  /* sum over a NaN default: cells no rank contributed to get the default back */
+  OLAP_FINISH_AVERAGE = 2,  /* (sum, contribution count) -> in-memory.js:323-331, count modulo 65536 */
+  OLAP_FINISH_COMBINE = 3   /* highest/lowest/first/last/product: the same drillUp over the rank axis */
+} olap_shard_finish;
+typedef enum {
+  OLAP_PLACE_SCATTER = 0,   /* additive methods: rank r keeps flat cells [r*per, (r+1)*per), per = ceil(n_out/world) */
+  OLAP_PLACE_ALL = 1,       /* every rank holds the whole result */
+  OLAP_PLACE_ROOT = 2       /* rank 0 holds the whole result */
+} olap_shard_placement;
+typedef struct {
+  int local_method;     /* olap_method run by each rank over its own rows */
+  int zero_unset;       /* float cells over a NaN default: unset partial cells are shipped as 0, never as NaN */
+  int n_payloads;       /* 1 or 2 */
+  int payload_dtype[2]; /* [0]: the cell type; [1]: OLAP_INT32 (mask, or contribution counts for average) */
+  int payload_op[2];    /* olap_xchg_op; masks are combined with MAX (an OR of 0 / 0x2), never added */
+  int finish;           /* olap_shard_finish */
+} olap_shard_recipe;
+/* host-only; `method` is one of the seven reference methods */
+int olap_shard_recipe_get(int dtype, int default_kind, int method, olap_shard_recipe *recipe);
+
+/* Reusable sharded drillUp of dimension 0.  lens[ndim] are the GLOBAL old lengths, bounds[world+1]
+ * the row partition, maps[d] as in olap_drillup_plan with maps[0] over the global rows (every rank
+ * takes its own slice), new_len the global new lengths.  The object owns, per local rank, the
+ * partial / exchange / result buffers (two sets when depth == 2) and one stream for the exchange.
+ *
+ * olap_shard_drillup_step(): for every local rank i — local reduction of in_values[i] on
+ * streams[i], then the exchange and the finishing kernels on the exchange stream, ordered by
+ * events only (no host wait).  With depth 2 consecutive steps are independent queries and the
+ * exchange of step k overlaps the local reduction of step k+1.  olap_shard_drillup_wait() makes
+ * streams[i] wait for everything issued so far.  The three phases can also be called one by one
+ * (rehearsals that move the payloads themselves call _local, their own collective on the buffers
+ * olap_shard_drillup_payload() names, then _finish).  Not thread-safe. */
+typedef struct olap_shard_drillup olap_shard_drillup;
+int olap_shard_drillup_create(olap_shard_drillup **op, olap_comm *comm, int dtype, int default_kind, int method,
+                              int ndim, const uint32_t *lens, const uint32_t *new_len, const uint32_t *bounds,
+                              const uint32_t *const *maps, int placement, int depth);
+void olap_shard_drillup_destroy(olap_shard_drillup *op);
+uint64_t olap_shard_drillup_out_cells(const olap_shard_drillup *op);     /* cells of the global result */
+uint64_t olap_shard_drillup_local_cells(const olap_shard_drillup *op, int local);
+const char *olap_shard_drillup_kernel_name(const olap_shard_drillup *op, int local);
+int olap_shard_drillup_step(olap_shard_drillup *op, const void *const *in_values, const int32_t *const *in_status,
+                            void *const *streams);
+int olap_shard_drillup_wait(olap_shard_drillup *op, void *const *streams);
+int olap_shard_drillup_local(olap_shard_drillup *op, int local, const void *in_values, const int32_t *in_status, void *stream);
+int olap_shard_drillup_exchange(olap_shard_drillup *op, void *const *streams);
+int olap_shard_drillup_finish(olap_shard_drillup *op, int local, void *stream);
+/* payload p of local rank `local` in the buffer set of the LAST step: what is sent, where the combined
+ * data must land (recv holds count cells for SUM / MAX under PLACE_ALL / ROOT, per cells under SCATTER,
+ * world * count cells for GATHER), their element type and the combining operation */
+int olap_shard_drillup_payload(const olap_shard_drillup *op, int local, int p, void **send, void **recv,
+                               uint64_t *count, int *dtype, int *xchg_op);
+/* result of the LAST step on local rank `local` (device pointers; *status may come back NULL when the
+ * mask is a function of the values): flat range [*first, *first + *count) of the global output */
+int olap_shard_drillup_result(const olap_shard_drillup *op, int local, void **values, int32_t **status,
+                              uint64_t *first, uint64_t *count);
+
+/* Sharded store handle: one measure whose dimension 0 is split over the ranks of `comm`; each local
+ * rank's slab is an ordinary olap_store on its device.  In a one-process communicator the host-facing
+ * accessors see the whole measure; with one process per GPU they see this process' rows only
+ * (host arrays are still full-size: only the local slabs are read or written). */
+typedef struct olap_sharded_store olap_sharded_store;
+int olap_sharded_store_create(olap_sharded_store **store, olap_comm *comm, int ndim, const uint32_t *lens,
+                              int dtype, int default_kind, const uint32_t *bounds /* NULL: balanced */);
+void olap_sharded_store_destroy(olap_sharded_store *store);
+uint64_t olap_sharded_store_size(const olap_sharded_store *store);
+int olap_sharded_store_ndim(const olap_sharded_store *store);
+const uint32_t *olap_sharded_store_lens(const olap_sharded_store *store);
+const uint32_t *olap_sharded_store_bounds(const olap_sharded_store *store);  /* world + 1 entries */
+olap_comm *olap_sharded_store_comm(const olap_sharded_store *store);
+olap_store *olap_sharded_store_shard(const olap_sharded_store *store, int local);  /* borrowed */
+int olap_sharded_store_fill_seeded(olap_sharded_store *store, uint32_t seed, double frac);
+int olap_sharded_store_set_data_f64(olap_sharded_store *store, const double *host_values, uint64_t n);
+int olap_sharded_store_get_data_f64(const olap_sharded_store *store, double *host_values);
+int olap_sharded_store_get_status(const olap_sharded_store *store, int32_t *host_status);
+int olap_sharded_store_get_value(const olap_sharded_store *store, uint64_t index, double *value, int *is_set);
+int olap_sharded_store_set_value(olap_sharded_store *store, uint64_t index, double value, int is_null);
+int olap_sharded_store_fill(olap_sharded_store *store, double value);
+int olap_sharded_store_total(const olap_sharded_store *store, double *total);  /* local ranks only */
+int olap_sharded_store_clone(const olap_sharded_store *store, olap_sharded_store **out);
+/* whole measure on the device of local rank 0 as an ordinary store, and back (one-process
+ * communicators: device-to-device copies; one process per GPU: RCCL broadcasts of the slabs) */
+int olap_sharded_store_gather(const olap_sharded_store *store, olap_store **out);
+int olap_sharded_store_scatter(olap_sharded_store **store, olap_comm *comm, const olap_store *whole, int ndim,
+                               const uint32_t *lens);
+/* The bulk operations.  Dimension 0 untouched (identity map / selection / perm[0] == 0): per shard,
+ * no communication, *out_sharded keeps the partition.  drillUp that changes dimension 0: partial +
+ * ONE collective, the (K0 / G0 times smaller) result arrives as an ordinary store in *out_whole on
+ * the device of local rank 0 (every process gets it when there is one process per GPU).  dice of
+ * dimension 0 by a strictly ascending list of existing rows: per shard, the partition becomes
+ * uneven.  Anything else that touches dimension 0 (reordering it, refining it, selections that
+ * repeat, permute or invent rows): OLAP_ERR_INVALID_ARGUMENT with a message starting "sharded:" —
+ * gather first.  Exactly one of *out_sharded / *out_whole is set on success. */
+int olap_sharded_store_drillup(const olap_sharded_store *store, olap_sharded_store **out_sharded, olap_store **out_whole,
+                               const uint32_t *new_len, const uint32_t *const *maps, int method);
+int olap_sharded_store_dice(const olap_sharded_store *store, olap_sharded_store **out, const uint32_t *new_len,
+                            const int32_t *const *sel);
+int olap_sharded_store_drilldown(const olap_sharded_store *store, olap_sharded_store **out, const uint32_t *new_len,
+                                 const uint32_t *const *maps, int method, const double *distributions, uint64_t n_dist);
+int olap_sharded_store_reorder(const olap_sharded_store *store, olap_sharded_store **out, const int32_t *perm);
 
 #ifdef __cplusplus
 }

@@ -21,8 +21,8 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 
 KERNEL_UNITS = ["olap_kernels_f32.hip", "olap_kernels_f64.hip", "olap_kernels_i32.hip", "olap_kernels_u32.hip",
-                "olap_capi.hip"]
-HEADERS = ["olap_device.hpp", "olap_kernels.hpp", os.path.join(ROOT, "include", "olap_hip.h")]
+                "olap_capi.hip", "olap_sharded.hip"]
+HEADERS = ["olap_device.hpp", "olap_kernels.hpp", "olap_internal.hpp", os.path.join(ROOT, "include", "olap_hip.h")]
 
 
 def _newer(target, sources):
@@ -68,7 +68,7 @@ def build_lib(force=False, verbose=False):
                     print(out)
     target = lib_path()
     if force or jobs or _newer(target, objs):
-        _run([HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", target] + objs)
+        _run([HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", target] + objs + ["-ldl"])
     return target
 
 

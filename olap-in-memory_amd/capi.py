@@ -98,7 +98,71 @@ SIGNATURES = {
     "olap_store_dice_drillup": (_i32, [_vp, _pvp, _i32, _pu32, _pu32, _pu32, _ppi32, _ppu32, _i32]),
     "olap_store_reorder": (_i32, [_vp, _pvp, _i32, _pu32, _pi32]),
     "olap_store_load": (_i32, [_vp, _vp, _i32, _pu32, _pu32, _ppi32]),
+    "olap_memcpy_to_host": (_i32, [_vp, _vp, _u64]),
+    "olap_memcpy_to_device": (_i32, [_vp, _vp, _u64]),
+    "olap_diag_read_ceiling": (_i32, [_vp, _u64, _vp, _vp]),
+    # multi-GPU (include/olap_hip.h, "Multi-GPU")
+    "olap_comm_unique_id": (_i32, [C.c_char_p]),
+    "olap_comm_init_rank": (_i32, [_pvp, C.c_char_p, _i32, _i32, _i32]),
+    "olap_comm_init_all": (_i32, [_pvp, C.POINTER(C.c_int), _i32]),
+    "olap_comm_init_detached": (_i32, [_pvp, _i32, _i32, _i32]),
+    "olap_comm_destroy": (None, [_vp]),
+    "olap_comm_world": (_i32, [_vp]),
+    "olap_comm_local_count": (_i32, [_vp]),
+    "olap_comm_local_rank": (_i32, [_vp, _i32]),
+    "olap_comm_local_device": (_i32, [_vp, _i32]),
+    "olap_comm_transport": (C.c_char_p, [_vp]),
+    "olap_shard_bounds": (_i32, [C.c_uint32, _i32, _pu32]),
+    "olap_shard_dice_bounds": (_i32, [_pu32, _i32, _pi32, C.c_uint32, _pu32]),
+    "olap_shard_recipe_get": (_i32, [_i32, _i32, _i32, _vp]),
+    "olap_shard_drillup_create": (_i32, [_pvp, _vp, _i32, _i32, _i32, _i32, _pu32, _pu32, _pu32, _ppu32, _i32, _i32]),
+    "olap_shard_drillup_destroy": (None, [_vp]),
+    "olap_shard_drillup_out_cells": (_u64, [_vp]),
+    "olap_shard_drillup_local_cells": (_u64, [_vp, _i32]),
+    "olap_shard_drillup_kernel_name": (C.c_char_p, [_vp, _i32]),
+    "olap_shard_drillup_step": (_i32, [_vp, _pvp, _pvp, _pvp]),
+    "olap_shard_drillup_wait": (_i32, [_vp, _pvp]),
+    "olap_shard_drillup_local": (_i32, [_vp, _i32, _vp, _vp, _vp]),
+    "olap_shard_drillup_exchange": (_i32, [_vp, _pvp]),
+    "olap_shard_drillup_finish": (_i32, [_vp, _i32, _vp]),
+    "olap_shard_drillup_payload": (_i32, [_vp, _i32, _i32, _pvp, _pvp, _pu64, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "olap_shard_drillup_result": (_i32, [_vp, _i32, _pvp, _pvp, _pu64, _pu64]),
+    "olap_sharded_store_create": (_i32, [_pvp, _vp, _i32, _pu32, _i32, _i32, _pu32]),
+    "olap_sharded_store_destroy": (None, [_vp]),
+    "olap_sharded_store_size": (_u64, [_vp]),
+    "olap_sharded_store_ndim": (_i32, [_vp]),
+    "olap_sharded_store_lens": (_pu32, [_vp]),
+    "olap_sharded_store_bounds": (_pu32, [_vp]),
+    "olap_sharded_store_comm": (_vp, [_vp]),
+    "olap_sharded_store_shard": (_vp, [_vp, _i32]),
+    "olap_sharded_store_fill_seeded": (_i32, [_vp, C.c_uint32, _dbl]),
+    "olap_sharded_store_set_data_f64": (_i32, [_vp, _pdbl, _u64]),
+    "olap_sharded_store_get_data_f64": (_i32, [_vp, _pdbl]),
+    "olap_sharded_store_get_status": (_i32, [_vp, _pi32]),
+    "olap_sharded_store_get_value": (_i32, [_vp, _u64, _pdbl, C.POINTER(C.c_int)]),
+    "olap_sharded_store_set_value": (_i32, [_vp, _u64, _dbl, _i32]),
+    "olap_sharded_store_fill": (_i32, [_vp, _dbl]),
+    "olap_sharded_store_total": (_i32, [_vp, _pdbl]),
+    "olap_sharded_store_clone": (_i32, [_vp, _pvp]),
+    "olap_sharded_store_gather": (_i32, [_vp, _pvp]),
+    "olap_sharded_store_scatter": (_i32, [_pvp, _vp, _vp, _i32, _pu32]),
+    "olap_sharded_store_drillup": (_i32, [_vp, _pvp, _pvp, _pu32, _ppu32, _i32]),
+    "olap_sharded_store_dice": (_i32, [_vp, _pvp, _pu32, _ppi32]),
+    "olap_sharded_store_drilldown": (_i32, [_vp, _pvp, _pu32, _ppu32, _i32, _pdbl, _u64]),
+    "olap_sharded_store_reorder": (_i32, [_vp, _pvp, _pi32]),
 }
+
+
+class ShardRecipe(C.Structure):
+    """olap_shard_recipe"""
+    _fields_ = [("local_method", C.c_int), ("zero_unset", C.c_int), ("n_payloads", C.c_int),
+                ("payload_dtype", C.c_int * 2), ("payload_op", C.c_int * 2), ("finish", C.c_int)]
+
+
+XCHG_SUM, XCHG_MAX, XCHG_GATHER = 0, 1, 2
+FINISH_NONE, FINISH_RESTORE, FINISH_AVERAGE, FINISH_COMBINE = 0, 1, 2, 3
+PLACE_SCATTER, PLACE_ALL, PLACE_ROOT = 0, 1, 2
+UNIQUE_ID_BYTES = 128
 
 _lib = None
 

@@ -17,6 +17,7 @@
 #include <string>
 #include <vector>
 
+#include "olap_internal.hpp"
 #include "olap_kernels.hpp"
 
 using namespace olap;
@@ -24,7 +25,7 @@ using namespace olap;
 // ------------------------------------------------------------------ errors
 static thread_local std::string g_last_error;
 
-static int fail(int code, const char *fmt, ...) {
+int fail(int code, const char *fmt, ...) {
   char buf[512];
   va_list ap;
   va_start(ap, fmt);
@@ -34,16 +35,10 @@ static int fail(int code, const char *fmt, ...) {
   return code;
 }
 
-static int hip_fail(hipError_t e, const char *what) {
+int hip_fail(hipError_t e, const char *what) {
   if (e == hipErrorOutOfMemory) return fail(OLAP_ERR_OUT_OF_MEMORY, "%s: %s", what, hipGetErrorString(e));
   return fail(OLAP_ERR_HIP, "%s: %s", what, hipGetErrorString(e));
 }
-
-#define HIP_TRY(expr)                                  \
-  do {                                                 \
-    hipError_t e__ = (expr);                           \
-    if (e__ != hipSuccess) return hip_fail(e__, #expr); \
-  } while (0)
 
 // ------------------------------------------------------------------ device memory pool
 // hipMalloc / hipFree cost milliseconds for buffers of tens of MB (and hipFree synchronises the
@@ -137,8 +132,8 @@ DevicePool &pool() {
 }
 }  // namespace
 
-static hipError_t dev_alloc(void **out, size_t bytes) { return pool().alloc(out, bytes); }
-static void dev_free(void *p) { pool().release(p); }
+hipError_t dev_alloc(void **out, size_t bytes) { return pool().alloc(out, bytes); }
+void dev_free(void *p) { pool().release(p); }
 
 extern "C" const char *olap_last_error(void) { return g_last_error.c_str(); }
 extern "C" int olap_abi_version(void) { return OLAP_ABI_VERSION; }
@@ -169,11 +164,11 @@ extern "C" size_t olap_dtype_size(int dtype) {
   }
 }
 
-static int check_dtype(int dtype) {
+int check_dtype(int dtype) {
   if (dtype < OLAP_INT32 || dtype > OLAP_FLOAT64) return fail(OLAP_ERR_INVALID_TYPE, "Invalid type");
   return OLAP_OK;
 }
-static int check_default(int kind) {
+int check_default(int kind) {
   if (kind != OLAP_DEFAULT_ZERO && kind != OLAP_DEFAULT_NAN)
     return fail(OLAP_ERR_INVALID_DEFAULT, "Invalid default value, only NaN and 0 are supported");
   return OLAP_OK;
@@ -189,7 +184,7 @@ extern "C" int olap_device_count(void) {
   return n;
 }
 
-static int require_device() {
+int require_device() {
   static thread_local int ok = -1;
   if (ok == 1) return OLAP_OK;
   if (olap_device_count() <= 0)
@@ -246,6 +241,10 @@ struct olap_plan {
   std::string kernel_name;
   hipStream_t last_stream = nullptr;
   bool ran = false;
+  int device = 0;                          // the device the tables and scratch live on (current at creation)
+  olap_plan() { (void)hipGetDevice(&device); }
+  int cache_refs = 0;                      // handle-layer LRU: users between find() and release() (guarded by the cache lock)
+  bool cache_evicted = false;              // evicted while in use: the last release() destroys it
 };
 
 static uint64_t product(const uint32_t *v, int n) {
@@ -1482,6 +1481,11 @@ extern "C" int olap_plan_run(olap_plan *p, const void *in_values, const int32_t 
   if (!p) return fail(OLAP_ERR_INVALID_ARGUMENT, "plan is NULL");
   if ((p->in_cells && !in_values) || (p->out_cells && !out_values))
     return fail(OLAP_ERR_INVALID_ARGUMENT, "values pointers must not be NULL");
+  {
+    int cur = -1;
+    if (hipGetDevice(&cur) == hipSuccess && cur != p->device)
+      return fail(OLAP_ERR_INVALID_ARGUMENT, "plan was built on device %d but the current device is %d", p->device, cur);
+  }
   hipStream_t s = (hipStream_t)stream;
   p->last_stream = s;
   p->ran = true;
@@ -1572,6 +1576,65 @@ extern "C" int olap_average_finish(void *values, const int32_t *counts, int32_t 
   hipError_t e = hipSuccess;
   DISPATCH_DTYPE(dtype, e = Launch<T>::average_finish((T *)values, counts, out_status, n, default_kind == OLAP_DEFAULT_NAN, (hipStream_t)stream));
   if (e != hipSuccess) return hip_fail(e, "average_finish");
+  return OLAP_OK;
+}
+
+// the copy runs on the null stream of the device that owns the buffer, so it is ordered behind the
+// work enqueued there
+static void enter_device_of(const void *device_ptr) {
+  hipPointerAttribute_t attr;
+  if (hipPointerGetAttributes(&attr, device_ptr) == hipSuccess) (void)hipSetDevice(attr.device);
+  else (void)hipGetLastError();
+}
+extern "C" int olap_memcpy_to_host(void *host, const void *device, uint64_t bytes) {
+  if (bytes && (!host || !device)) return fail(OLAP_ERR_INVALID_ARGUMENT, "host/device pointer is NULL");
+  int rc = require_device();
+  if (rc) return rc;
+  if (!bytes) return OLAP_OK;
+  DeviceGuard guard;
+  enter_device_of(device);
+  HIP_TRY(hipMemcpy(host, device, bytes, hipMemcpyDeviceToHost));
+  return OLAP_OK;
+}
+extern "C" int olap_memcpy_to_device(void *device, const void *host, uint64_t bytes) {
+  if (bytes && (!host || !device)) return fail(OLAP_ERR_INVALID_ARGUMENT, "host/device pointer is NULL");
+  int rc = require_device();
+  if (rc) return rc;
+  if (!bytes) return OLAP_OK;
+  DeviceGuard guard;
+  enter_device_of(device);
+  HIP_TRY(hipMemcpy(device, host, bytes, hipMemcpyHostToDevice));
+  return OLAP_OK;
+}
+
+// the box's achievable read ceiling: the simplest possible streaming read (tools/ceilings.hip's `read nt`)
+__global__ __launch_bounds__(kBlock) void diag_read_kernel(const float4 *__restrict__ src, uint64_t n_vec, float *scratch) {
+  float acc = 0.f;
+  const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+  uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  for (; i + 3 * stride < n_vec; i += 4 * stride) {
+    const Vec<float, 4> a = load_stream<float, 4>((const float *)(src + i));
+    const Vec<float, 4> b = load_stream<float, 4>((const float *)(src + i + stride));
+    const Vec<float, 4> c = load_stream<float, 4>((const float *)(src + i + 2 * stride));
+    const Vec<float, 4> d = load_stream<float, 4>((const float *)(src + i + 3 * stride));
+    acc += a.v[0] + a.v[1] + a.v[2] + a.v[3] + b.v[0] + b.v[1] + b.v[2] + b.v[3] + c.v[0] + c.v[1] + c.v[2] + c.v[3] + d.v[0] + d.v[1] +
+           d.v[2] + d.v[3];
+  }
+  for (; i < n_vec; i += stride) {
+    const Vec<float, 4> a = load_stream<float, 4>((const float *)(src + i));
+    acc += a.v[0] + a.v[1] + a.v[2] + a.v[3];
+  }
+  if (acc == 123456.789f) scratch[blockIdx.x] = acc;  // keeps the loads alive without a store per lane
+}
+
+extern "C" int olap_diag_read_ceiling(const void *device, uint64_t bytes, void *scratch, void *stream) {
+  if (!device || !scratch) return fail(OLAP_ERR_INVALID_ARGUMENT, "device/scratch is NULL");
+  if (((uintptr_t)device & 15u) != 0) return fail(OLAP_ERR_INVALID_ARGUMENT, "buffer must be 16-byte aligned");
+  int rc = require_device();
+  if (rc) return rc;
+  hipLaunchKernelGGL(diag_read_kernel, 2048, kBlock, 0, (hipStream_t)stream, (const float4 *)device, bytes / 16, (float *)scratch);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return hip_fail(e, "diag_read_kernel");
   return OLAP_OK;
 }
 
@@ -1676,19 +1739,13 @@ extern "C" int olap_total(const void *values, const int32_t *status, uint64_t n,
 // so bulk operations neither read nor write it and it is built on first request
 // (olap_store_get_status / _status_ptr / _get_keys).  Integer cells under a NaN default are the one
 // case where the mask carries information of its own; such stores always hold it.
-struct olap_store {
-  uint64_t size;
-  int dtype;
-  int default_kind;
-  void *values;
-  mutable int32_t *status;  // nullptr until needed (see above)
-};
+// (struct olap_store: olap_internal.hpp)
 
-static bool mask_is_primary(const olap_store *s) {
+bool mask_is_primary(const olap_store *s) {
   return s->default_kind == OLAP_DEFAULT_NAN && (s->dtype == OLAP_INT32 || s->dtype == OLAP_UINT32);
 }
 
-static int store_alloc(olap_store **out, uint64_t size, int dtype, int default_kind) {
+int store_alloc(olap_store **out, uint64_t size, int dtype, int default_kind) {
   olap_store *s = new (std::nothrow) olap_store();
   if (!s) return fail(OLAP_ERR_OUT_OF_MEMORY, "out of host memory");
   s->size = size;
@@ -1696,6 +1753,8 @@ static int store_alloc(olap_store **out, uint64_t size, int dtype, int default_k
   s->default_kind = default_kind;
   s->values = nullptr;
   s->status = nullptr;
+  s->device = 0;
+  (void)hipGetDevice(&s->device);
   const size_t vb = (size ? size : 1) * olap_dtype_size(dtype), sb = (size ? size : 1) * sizeof(int32_t);
   hipError_t e = dev_alloc(&s->values, vb);
   if (e == hipSuccess && mask_is_primary(s)) e = dev_alloc((void **)&s->status, sb);
@@ -1709,7 +1768,7 @@ static int store_alloc(olap_store **out, uint64_t size, int dtype, int default_k
 }
 
 // builds the mask from the values when it has not been materialised yet
-static int ensure_status(const olap_store *s) {
+int ensure_status(const olap_store *s) {
   if (s->status) return OLAP_OK;
   int32_t *st = nullptr;
   HIP_TRY(dev_alloc((void **)&st, (s->size ? s->size : 1) * sizeof(int32_t)));
@@ -1794,7 +1853,7 @@ static int check_length(const olap_store *s, uint64_t n) {
 }
 
 // a bulk write replaces every cell: a lazily built mask is dropped, a primary one is rewritten
-static void drop_lazy_status(olap_store *s) {
+void drop_lazy_status(olap_store *s) {
   if (s->status && !mask_is_primary(s)) {
     dev_free(s->status);
     s->status = nullptr;
@@ -2084,7 +2143,7 @@ extern "C" int olap_store_from_sparse(olap_store **store, uint64_t size, int dty
 
 // Integer cells under a NaN default are the one case where the mask carries information the
 // values cannot; everywhere else the kernels derive "set" from the value and skip the mask read.
-static const int32_t *mask_needed(const olap_store *s) { return mask_is_primary(s) ? s->status : nullptr; }
+const int32_t *mask_needed(const olap_store *s) { return mask_is_primary(s) ? s->status : nullptr; }
 
 // ---- plan cache of the handle layer ------------------------------------------------------------
 // A dashboard issues the same few queries over and over; building a plan costs two or three small
@@ -2093,6 +2152,12 @@ static const int32_t *mask_needed(const olap_store *s) { return mask_is_primary(
 namespace {
 struct PlanKey {
   std::string bytes;
+  PlanKey() {  // a plan's tables and scratch live on the device that was current when it was built
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    raw(&dev, sizeof dev);
+  }
+  bool empty() const { return bytes.size() <= sizeof(int); }
   void raw(const void *p, size_t n) { bytes.append((const char *)p, n); }
   void i32(int32_t v) { raw(&v, sizeof v); }
   void u64(uint64_t v) { raw(&v, sizeof v); }
@@ -2109,27 +2174,48 @@ struct PlanCache {
   std::unordered_map<std::string, std::pair<olap_plan *, uint64_t>> map;  // key -> (plan, last use)
   uint64_t tick = 0;
   static constexpr size_t kMax = 128;
+  // find() pins the plan: an eviction by another thread between find() and release() only marks it,
+  // and the last release() destroys it
   olap_plan *find(const std::string &key) {
     std::lock_guard<std::mutex> lock(mu);
     auto it = map.find(key);
     if (it == map.end()) return nullptr;
     it->second.second = ++tick;
+    it->second.first->cache_refs++;
     return it->second.first;
   }
+  // inserts a freshly built plan, pinned for its builder
   void insert(const std::string &key, olap_plan *plan) {
     olap_plan *evicted = nullptr;
     {
       std::lock_guard<std::mutex> lock(mu);
+      auto dup = map.find(key);
+      if (dup != map.end()) {  // another thread built the same plan meanwhile: ours stays private
+        plan->cache_refs = 1;
+        plan->cache_evicted = true;
+        return;
+      }
       if (map.size() >= kMax) {
         auto oldest = map.begin();
         for (auto it = map.begin(); it != map.end(); ++it)
           if (it->second.second < oldest->second.second) oldest = it;
-        evicted = oldest->second.first;
+        olap_plan *o = oldest->second.first;
         map.erase(oldest);
+        if (o->cache_refs > 0) o->cache_evicted = true;
+        else evicted = o;
       }
+      plan->cache_refs = 1;
       map[key] = {plan, ++tick};
     }
     if (evicted) olap_plan_destroy(evicted);
+  }
+  void release(olap_plan *plan) {
+    bool destroy = false;
+    {
+      std::lock_guard<std::mutex> lock(mu);
+      destroy = --plan->cache_refs == 0 && plan->cache_evicted;
+    }
+    if (destroy) olap_plan_destroy(plan);
   }
 };
 PlanCache &plan_cache() {
@@ -2144,6 +2230,11 @@ PlanCache &plan_cache() {
 // data-dependent error (in-memory.js:397-398) must surface from this call.
 static int run_to_new_store(olap_plan *plan, const olap_store *in, olap_store **out) {
   olap_store *o = nullptr;
+  {
+    int cur = -1;
+    if (hipGetDevice(&cur) == hipSuccess && cur != in->device)
+      return fail(OLAP_ERR_INVALID_ARGUMENT, "store lives on device %d but the current device is %d", in->device, cur);
+  }
   int rc = store_alloc(&o, olap_plan_out_cells(plan), in->dtype, in->default_kind);
   if (!rc) rc = olap_plan_run(plan, in->values, mask_needed(in), o->values, o->status, nullptr);
   if (!rc && plan->kind == PLAN_DRILLDOWN && plan->dd.dist) {
@@ -2188,7 +2279,7 @@ extern "C" int olap_store_drillup(const olap_store *s, olap_store **out, int ndi
   if (!plan) {
     int rc = olap_drillup_plan(&plan, s->dtype, s->default_kind, method, ndim, old_len, new_len, maps);
     if (rc) return rc;
-    if (!key.bytes.empty()) plan_cache().insert(key.bytes, plan);
+    if (!key.empty()) plan_cache().insert(key.bytes, plan);
     else {
       rc = check_store_cells(s, plan);
       if (!rc) rc = run_to_new_store(plan, s, out);
@@ -2197,7 +2288,9 @@ extern "C" int olap_store_drillup(const olap_store *s, olap_store **out, int ndi
     }
   }
   int rc = check_store_cells(s, plan);
-  return rc ? rc : run_to_new_store(plan, s, out);
+  if (!rc) rc = run_to_new_store(plan, s, out);
+  plan_cache().release(plan);
+  return rc;
 }
 
 extern "C" int olap_store_drilldown(const olap_store *s, olap_store **out, int ndim, const uint32_t *old_len,
@@ -2235,7 +2328,7 @@ extern "C" int olap_store_dice(const olap_store *s, olap_store **out, int ndim, 
   if (!plan) {
     int rc = olap_dice_plan(&plan, s->dtype, s->default_kind, ndim, old_len, new_len, sel);
     if (rc) return rc;
-    if (!key.bytes.empty()) plan_cache().insert(key.bytes, plan);
+    if (!key.empty()) plan_cache().insert(key.bytes, plan);
     else {
       rc = check_store_cells(s, plan);
       if (!rc) rc = run_to_new_store(plan, s, out);
@@ -2244,7 +2337,9 @@ extern "C" int olap_store_dice(const olap_store *s, olap_store **out, int ndim, 
     }
   }
   int rc = check_store_cells(s, plan);
-  return rc ? rc : run_to_new_store(plan, s, out);
+  if (!rc) rc = run_to_new_store(plan, s, out);
+  plan_cache().release(plan);
+  return rc;
 }
 
 extern "C" int olap_store_dice_drillup(const olap_store *s, olap_store **out, int ndim, const uint32_t *old_len,
@@ -2269,7 +2364,7 @@ extern "C" int olap_store_dice_drillup(const olap_store *s, olap_store **out, in
   if (!plan) {
     int rc = olap_dice_drillup_plan(&plan, s->dtype, s->default_kind, method, ndim, old_len, mid_len, new_len, sel, maps);
     if (rc) return rc;
-    if (!key.bytes.empty()) plan_cache().insert(key.bytes, plan);
+    if (!key.empty()) plan_cache().insert(key.bytes, plan);
     else {
       rc = check_store_cells(s, plan);
       if (!rc) rc = run_to_new_store(plan, s, out);
@@ -2278,7 +2373,9 @@ extern "C" int olap_store_dice_drillup(const olap_store *s, olap_store **out, in
     }
   }
   int rc = check_store_cells(s, plan);
-  return rc ? rc : run_to_new_store(plan, s, out);
+  if (!rc) rc = run_to_new_store(plan, s, out);
+  plan_cache().release(plan);
+  return rc;
 }
 
 extern "C" int olap_store_reorder(const olap_store *s, olap_store **out, int ndim, const uint32_t *old_len,
@@ -2296,7 +2393,7 @@ extern "C" int olap_store_reorder(const olap_store *s, olap_store **out, int ndi
   if (!plan) {
     int rc = olap_reorder_plan(&plan, s->dtype, s->default_kind, ndim, old_len, perm);
     if (rc) return rc;
-    if (!key.bytes.empty()) plan_cache().insert(key.bytes, plan);
+    if (!key.empty()) plan_cache().insert(key.bytes, plan);
     else {
       rc = check_store_cells(s, plan);
       if (!rc) rc = run_to_new_store(plan, s, out);
@@ -2305,7 +2402,9 @@ extern "C" int olap_store_reorder(const olap_store *s, olap_store **out, int ndi
     }
   }
   int rc = check_store_cells(s, plan);
-  return rc ? rc : run_to_new_store(plan, s, out);
+  if (!rc) rc = run_to_new_store(plan, s, out);
+  plan_cache().release(plan);
+  return rc;
 }
 
 extern "C" int olap_store_load(olap_store *s, const olap_store *other, int ndim, const uint32_t *my_len,

@@ -1,0 +1,1358 @@
+// olap_sharded.hip — the multi-GPU part of libolapgpu's C ABI (include/olap_hip.h, "Multi-GPU"):
+// communicators, the sharded drillUp of dimension 0 (local partial + ONE collective + finish) and
+// the sharded store handle the Node.js host binds.
+//
+// Reference call site this sits behind: the per-measure store call of Cube.drillUp,
+// /root/reference/src/cube.js:1012-1020 (newCube.storedMeasures[m] = store.drillUp(old, new, rule)),
+// store method /root/reference/src/store/in-memory.js:265-334.  The reference itself has no
+// distributed code; the partitioning follows BASELINE.json's north_star and SURVEY.md §8(e).
+//
+// RCCL is bound at run time (dlopen of librccl.so.1): hosts that never shard do not pay for loading
+// it, and a process that has torch loaded shares torch's copy (same soname).
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "olap_device.hpp"
+#include "olap_internal.hpp"
+
+using namespace olap;
+
+// ------------------------------------------------------------------ RCCL, bound lazily
+namespace {
+struct Rccl {
+  void *handle = nullptr;
+  decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+  decltype(&ncclCommInitRank) CommInitRank = nullptr;
+  decltype(&ncclCommInitAll) CommInitAll = nullptr;
+  decltype(&ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&ncclReduce) Reduce = nullptr;
+  decltype(&ncclBroadcast) Broadcast = nullptr;
+  decltype(&ncclAllReduce) AllReduce = nullptr;
+  decltype(&ncclReduceScatter) ReduceScatter = nullptr;
+  decltype(&ncclAllGather) AllGather = nullptr;
+  decltype(&ncclGroupStart) GroupStart = nullptr;
+  decltype(&ncclGroupEnd) GroupEnd = nullptr;
+  decltype(&ncclGetErrorString) GetErrorString = nullptr;
+  std::string error;
+};
+
+Rccl *rccl() {
+  static std::mutex mu;
+  static Rccl *r = nullptr;
+  std::lock_guard<std::mutex> lock(mu);
+  if (r) return r;
+  r = new Rccl();
+  const char *names[] = {"librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"};
+  for (const char *n : names) {
+    r->handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+    if (r->handle) break;
+  }
+  if (!r->handle) {
+    r->error = std::string("cannot load RCCL: ") + (dlerror() ? dlerror() : "librccl.so.1 not found");
+    return r;
+  }
+#define OLAP_BIND(name)                                                              \
+  r->name = (decltype(r->name))dlsym(r->handle, "nccl" #name);                        \
+  if (!r->name && r->error.empty()) r->error = "RCCL lacks the symbol nccl" #name;
+  OLAP_BIND(GetUniqueId)
+  OLAP_BIND(CommInitRank)
+  OLAP_BIND(CommInitAll)
+  OLAP_BIND(CommDestroy)
+  OLAP_BIND(Reduce)
+  OLAP_BIND(Broadcast)
+  OLAP_BIND(AllReduce)
+  OLAP_BIND(ReduceScatter)
+  OLAP_BIND(AllGather)
+  OLAP_BIND(GroupStart)
+  OLAP_BIND(GroupEnd)
+  OLAP_BIND(GetErrorString)
+#undef OLAP_BIND
+  return r;
+}
+
+int rccl_fail(ncclResult_t res, const char *what) {
+  Rccl *r = rccl();
+  return fail(OLAP_ERR_HIP, "%s: %s", what, (r && r->GetErrorString) ? r->GetErrorString(res) : "RCCL error");
+}
+
+#define RCCL_TRY(expr)                                          \
+  do {                                                          \
+    ncclResult_t r__ = (expr);                                  \
+    if (r__ != ncclSuccess) return rccl_fail(r__, #expr);       \
+  } while (0)
+
+ncclDataType_t nccl_type(int dtype) {
+  switch (dtype) {
+    case OLAP_INT32: return ncclInt32;
+    case OLAP_UINT32: return ncclUint32;
+    case OLAP_FLOAT32: return ncclFloat32;
+    default: return ncclFloat64;
+  }
+}
+
+enum Transport { TRANSPORT_RCCL = 0, TRANSPORT_DIRECT = 1, TRANSPORT_DETACHED = 2 };
+}  // namespace
+
+struct olap_comm {
+  struct Local {
+    int rank = 0;
+    int device = 0;
+    ncclComm_t nccl = nullptr;
+    hipStream_t xstream = nullptr;  // exchange + finishing kernels of this rank
+  };
+  int world = 1;
+  int transport = TRANSPORT_DETACHED;
+  std::vector<Local> local;
+};
+
+static int comm_make_streams(olap_comm *c) {
+  DeviceGuard guard;
+  for (auto &l : c->local) {
+    HIP_TRY(hipSetDevice(l.device));
+    HIP_TRY(hipStreamCreateWithFlags(&l.xstream, hipStreamNonBlocking));
+  }
+  return OLAP_OK;
+}
+
+static int check_device_index(int device) {
+  int rc = require_device();
+  if (rc) return rc;
+  const int n = olap_device_count();
+  if (device < 0 || device >= n) return fail(OLAP_ERR_INVALID_ARGUMENT, "device %d out of range [0, %d)", device, n);
+  return OLAP_OK;
+}
+
+extern "C" int olap_comm_unique_id(char id[OLAP_UNIQUE_ID_BYTES]) {
+  if (!id) return fail(OLAP_ERR_INVALID_ARGUMENT, "id is NULL");
+  static_assert(sizeof(ncclUniqueId) == OLAP_UNIQUE_ID_BYTES, "unique id size");
+  Rccl *r = rccl();
+  if (!r->error.empty()) return fail(OLAP_ERR_NO_DEVICE, "%s", r->error.c_str());
+  ncclUniqueId u;
+  RCCL_TRY(r->GetUniqueId(&u));
+  memcpy(id, &u, sizeof u);
+  return OLAP_OK;
+}
+
+extern "C" int olap_comm_init_rank(olap_comm **comm, const char id[OLAP_UNIQUE_ID_BYTES], int world, int rank, int device) {
+  if (!comm || !id) return fail(OLAP_ERR_INVALID_ARGUMENT, "comm/id is NULL");
+  *comm = nullptr;
+  if (world < 1 || rank < 0 || rank >= world) return fail(OLAP_ERR_INVALID_ARGUMENT, "rank %d outside a world of %d", rank, world);
+  int rc = check_device_index(device);
+  if (rc) return rc;
+  Rccl *r = rccl();
+  if (!r->error.empty()) return fail(OLAP_ERR_NO_DEVICE, "%s", r->error.c_str());
+  olap_comm *c = new (std::nothrow) olap_comm();
+  if (!c) return fail(OLAP_ERR_OUT_OF_MEMORY, "out of host memory");
+  c->world = world;
+  c->transport = TRANSPORT_RCCL;
+  c->local.resize(1);
+  c->local[0].rank = rank;
+  c->local[0].device = device;
+  DeviceGuard guard;
+  hipError_t e = hipSetDevice(device);
+  if (e != hipSuccess) {
+    delete c;
+    return hip_fail(e, "hipSetDevice");
+  }
+  ncclUniqueId u;
+  memcpy(&u, id, sizeof u);
+  ncclResult_t res = r->CommInitRank(&c->local[0].nccl, world, u, rank);
+  if (res != ncclSuccess) {
+    delete c;
+    return rccl_fail(res, "ncclCommInitRank");
+  }
+  if ((rc = comm_make_streams(c))) {
+    olap_comm_destroy(c);
+    return rc;
+  }
+  *comm = c;
+  return OLAP_OK;
+}
+
+extern "C" int olap_comm_init_all(olap_comm **comm, const int *devices, int n) {
+  if (!comm || !devices) return fail(OLAP_ERR_INVALID_ARGUMENT, "comm/devices is NULL");
+  *comm = nullptr;
+  if (n < 1 || n > 1024) return fail(OLAP_ERR_INVALID_ARGUMENT, "device list of %d entries", n);
+  int rc;
+  for (int i = 0; i < n; ++i)
+    if ((rc = check_device_index(devices[i]))) return rc;
+  bool all_same = true, all_distinct = true;
+  for (int i = 0; i < n; ++i)
+    for (int j = i + 1; j < n; ++j) {
+      if (devices[i] == devices[j]) all_distinct = false;
+      else all_same = false;
+    }
+  if (!all_distinct && !all_same)
+    return fail(OLAP_ERR_INVALID_ARGUMENT, "device list must name distinct devices (RCCL over xGMI) or one device repeated (direct exchange)");
+  olap_comm *c = new (std::nothrow) olap_comm();
+  if (!c) return fail(OLAP_ERR_OUT_OF_MEMORY, "out of host memory");
+  c->world = n;
+  c->local.resize(n);
+  for (int i = 0; i < n; ++i) {
+    c->local[i].rank = i;
+    c->local[i].device = devices[i];
+  }
+  if (all_distinct) {
+    Rccl *r = rccl();
+    if (!r->error.empty()) {
+      delete c;
+      return fail(OLAP_ERR_NO_DEVICE, "%s", r->error.c_str());
+    }
+    c->transport = TRANSPORT_RCCL;
+    std::vector<ncclComm_t> comms(n);
+    DeviceGuard guard;
+    ncclResult_t res = r->CommInitAll(comms.data(), n, devices);
+    if (res != ncclSuccess) {
+      delete c;
+      return rccl_fail(res, "ncclCommInitAll");
+    }
+    for (int i = 0; i < n; ++i) c->local[i].nccl = comms[i];
+  } else {
+    c->transport = TRANSPORT_DIRECT;  // every rank on one device: peers' buffers are read directly
+  }
+  if ((rc = comm_make_streams(c))) {
+    olap_comm_destroy(c);
+    return rc;
+  }
+  *comm = c;
+  return OLAP_OK;
+}
+
+extern "C" int olap_comm_init_detached(olap_comm **comm, int world, int rank, int device) {
+  if (!comm) return fail(OLAP_ERR_INVALID_ARGUMENT, "comm is NULL");
+  *comm = nullptr;
+  if (world < 1 || rank < 0 || rank >= world) return fail(OLAP_ERR_INVALID_ARGUMENT, "rank %d outside a world of %d", rank, world);
+  int rc = check_device_index(device);
+  if (rc) return rc;
+  olap_comm *c = new (std::nothrow) olap_comm();
+  if (!c) return fail(OLAP_ERR_OUT_OF_MEMORY, "out of host memory");
+  c->world = world;
+  c->transport = TRANSPORT_DETACHED;
+  c->local.resize(1);
+  c->local[0].rank = rank;
+  c->local[0].device = device;
+  if ((rc = comm_make_streams(c))) {
+    olap_comm_destroy(c);
+    return rc;
+  }
+  *comm = c;
+  return OLAP_OK;
+}
+
+extern "C" void olap_comm_destroy(olap_comm *c) {
+  if (!c) return;
+  DeviceGuard guard;
+  Rccl *r = c->transport == TRANSPORT_RCCL ? rccl() : nullptr;
+  for (auto &l : c->local) {
+    (void)hipSetDevice(l.device);
+    if (l.xstream) {
+      (void)hipStreamSynchronize(l.xstream);
+      (void)hipStreamDestroy(l.xstream);
+    }
+    if (l.nccl && r && r->CommDestroy) (void)r->CommDestroy(l.nccl);
+  }
+  delete c;
+}
+
+extern "C" int olap_comm_world(const olap_comm *c) { return c ? c->world : 0; }
+extern "C" int olap_comm_local_count(const olap_comm *c) { return c ? (int)c->local.size() : 0; }
+extern "C" int olap_comm_local_rank(const olap_comm *c, int local) {
+  return (c && local >= 0 && local < (int)c->local.size()) ? c->local[local].rank : -1;
+}
+extern "C" int olap_comm_local_device(const olap_comm *c, int local) {
+  return (c && local >= 0 && local < (int)c->local.size()) ? c->local[local].device : -1;
+}
+extern "C" const char *olap_comm_transport(const olap_comm *c) {
+  if (!c) return "";
+  return c->transport == TRANSPORT_RCCL ? "rccl" : c->transport == TRANSPORT_DIRECT ? "direct" : "detached";
+}
+
+// ------------------------------------------------------------------ host-only partition arithmetic
+extern "C" int olap_shard_bounds(uint32_t n_rows, int world, uint32_t *bounds) {
+  if (!bounds) return fail(OLAP_ERR_INVALID_ARGUMENT, "bounds is NULL");
+  if (world < 1) return fail(OLAP_ERR_INVALID_ARGUMENT, "world must be >= 1");
+  const uint32_t base = n_rows / (uint32_t)world, extra = n_rows % (uint32_t)world;
+  bounds[0] = 0;
+  for (int r = 0; r < world; ++r) bounds[r + 1] = bounds[r] + base + ((uint32_t)r < extra ? 1u : 0u);
+  return OLAP_OK;
+}
+
+extern "C" int olap_shard_dice_bounds(const uint32_t *bounds, int world, const int32_t *rows, uint32_t n_sel, uint32_t *new_bounds) {
+  if (!bounds || !new_bounds || (n_sel && !rows)) return fail(OLAP_ERR_INVALID_ARGUMENT, "bounds/rows is NULL");
+  if (world < 1) return fail(OLAP_ERR_INVALID_ARGUMENT, "world must be >= 1");
+  const uint32_t n_rows = bounds[world];
+  for (uint32_t i = 0; i < n_sel; ++i) {
+    if (rows[i] < 0 || (uint32_t)rows[i] >= n_rows || (i > 0 && rows[i] <= rows[i - 1]))
+      return fail(OLAP_ERR_INVALID_ARGUMENT,
+                  "sharded: a dice of the sharded dimension takes strictly ascending existing rows (entry %u = %d); gather first", i, rows[i]);
+  }
+  for (int r = 0; r <= world; ++r)
+    new_bounds[r] = (uint32_t)(std::lower_bound(rows, rows + n_sel, (int32_t)std::min<uint32_t>(bounds[r], 0x7FFFFFFFu)) - rows);
+  return OLAP_OK;
+}
+
+static bool is_float_dtype(int dtype) { return dtype == OLAP_FLOAT32 || dtype == OLAP_FLOAT64; }
+
+extern "C" int olap_shard_recipe_get(int dtype, int default_kind, int method, olap_shard_recipe *rc) {
+  if (!rc) return fail(OLAP_ERR_INVALID_ARGUMENT, "recipe is NULL");
+  int e;
+  if ((e = check_dtype(dtype)) || (e = check_default(default_kind))) return e;
+  if (method < OLAP_SUM || method > OLAP_PRODUCT) return fail(OLAP_ERR_UNSUPPORTED_METHOD, "Unsupported aggregation method: %d", method);
+  memset(rc, 0, sizeof *rc);
+  const bool def_nan = default_kind == OLAP_DEFAULT_NAN;
+  const bool primary = def_nan && !is_float_dtype(dtype);  // the mask carries information the values cannot
+  rc->payload_dtype[0] = dtype;
+  rc->payload_dtype[1] = OLAP_INT32;
+  if (method == OLAP_SUM) {
+    rc->local_method = OLAP_SUM;
+    rc->payload_op[0] = OLAP_XCHG_SUM;
+    if (!def_nan) {  // set <=> value != 0: a rank without contributions ships 0, the neutral element
+      rc->n_payloads = 1;
+      rc->finish = OLAP_FINISH_NONE;
+    } else {  // NaN must never enter an additive collective; the masks are OR-ed (MAX of 0 / 0x2)
+      rc->n_payloads = 2;
+      rc->payload_op[1] = OLAP_XCHG_MAX;
+      rc->zero_unset = is_float_dtype(dtype);
+      rc->finish = OLAP_FINISH_RESTORE;
+    }
+  } else if (method == OLAP_AVERAGE) {
+    rc->local_method = OLAP_PARTIAL_AVERAGE;  // (sum, contribution count) in one local pass
+    rc->n_payloads = 2;
+    rc->payload_op[0] = OLAP_XCHG_SUM;
+    rc->payload_op[1] = OLAP_XCHG_SUM;
+    rc->zero_unset = def_nan && is_float_dtype(dtype);
+    rc->finish = OLAP_FINISH_AVERAGE;
+  } else {
+    // highest / lowest / first / last / product are associative in rank order (ranks own ascending
+    // row ranges): gather the partials, run the same drillUp over the rank axis
+    rc->local_method = method;
+    rc->n_payloads = primary ? 2 : 1;  // elsewhere set <=> value != default
+    rc->payload_op[0] = OLAP_XCHG_GATHER;
+    rc->payload_op[1] = OLAP_XCHG_GATHER;
+    rc->finish = OLAP_FINISH_COMBINE;
+  }
+  return OLAP_OK;
+}
+
+// ------------------------------------------------------------------ small kernels of the exchange
+namespace {
+// unset partial cells are shipped as 0 (float cells over a NaN default would poison a sum)
+template <typename T>
+__global__ __launch_bounds__(kBlock) void zero_unset_kernel(T *values, const int32_t *flags, uint64_t n) {
+  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kBlock) {
+    const T v = values[i];
+    values[i] = (flags[i] != 0 && v == v) ? v : T(0);
+  }
+}
+// after a SUM of zeroed partials + MAX of masks: cells nobody contributed to get the default back
+template <typename T>
+__global__ __launch_bounds__(kBlock) void restore_default_kernel(T *values, int32_t *flags, uint64_t n, int def_nan) {
+  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kBlock) {
+    const bool set = (flags[i] & OLAP_STATUS_SET) != 0 && !Cell<T>::is_default(values[i], def_nan != 0);
+    if (!set) values[i] = Cell<T>::default_value(def_nan != 0);
+    flags[i] = set ? OLAP_STATUS_SET : 0;
+  }
+}
+template <typename T>
+__global__ __launch_bounds__(kBlock) void fill_default_kernel(T *values, uint64_t n, int def_nan) {
+  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kBlock)
+    values[i] = Cell<T>::default_value(def_nan != 0);
+}
+// direct transport: dst[i] = op over the ranks q of src[q][first + i]
+template <typename T, int OP>
+__global__ __launch_bounds__(kBlock) void direct_combine_kernel(const T *const *src, int n_src, T *dst, uint64_t first, uint64_t n) {
+  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kBlock) {
+    T acc = src[0][first + i];
+    for (int q = 1; q < n_src; ++q) {
+      const T v = src[q][first + i];
+      if constexpr (OP == OLAP_XCHG_SUM) acc = acc + v;
+      else acc = v > acc ? v : acc;
+    }
+    dst[i] = acc;
+  }
+}
+
+unsigned grid_for_n(uint64_t n) {
+  const uint64_t want = (n + kBlock - 1) / kBlock;
+  return (unsigned)(want < 1 ? 1 : (want < 2048 ? want : 2048));
+}
+
+#define SHARD_DISPATCH(dtype, CALL)                        \
+  switch (dtype) {                                         \
+    case OLAP_INT32: { using T = int32_t; CALL; break; }   \
+    case OLAP_UINT32: { using T = uint32_t; CALL; break; } \
+    case OLAP_FLOAT32: { using T = float; CALL; break; }   \
+    default: { using T = double; CALL; break; }            \
+  }
+
+int launch_check(const char *what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return hip_fail(e, what);
+  return OLAP_OK;
+}
+}  // namespace
+
+// ------------------------------------------------------------------ sharded drillUp of dimension 0
+namespace {
+struct BufSet {
+  void *send[2] = {nullptr, nullptr};      // partial values / partial mask-or-counts
+  void *recv[2] = {nullptr, nullptr};      // combined (or gathered) payloads
+  void *result = nullptr;                  // FINISH_COMBINE only (else the result is recv[0] in place)
+  int32_t *result_status = nullptr;
+  const void **peers[2] = {nullptr, nullptr};  // direct transport: device table of every rank's send[p]
+  hipEvent_t local_done = nullptr, xchg_done = nullptr;
+  bool in_flight = false;
+};
+struct RankState {
+  olap_plan *local_plan = nullptr;
+  olap_plan *combine_plan = nullptr;
+  uint64_t local_cells = 0;
+  BufSet set[2];
+};
+}  // namespace
+
+struct olap_shard_drillup {
+  olap_comm *comm = nullptr;
+  olap_shard_recipe recipe{};
+  int dtype = 0, default_kind = 0, method = 0, placement = 0, depth = 1;
+  uint64_t n_out = 0, per = 0, n_send = 0;
+  bool mask_primary = false;
+  int cur = 0;       // buffer set of the last step
+  std::vector<RankState> ranks;
+};
+
+static size_t payload_size(const olap_shard_drillup *op, int p) { return olap_dtype_size(op->recipe.payload_dtype[p]); }
+
+// cells of recv[p] on a rank
+static uint64_t recv_cells(const olap_shard_drillup *op, int p) {
+  if (op->recipe.payload_op[p] == OLAP_XCHG_GATHER) return op->n_out * (uint64_t)op->comm->world;
+  return op->placement == OLAP_PLACE_SCATTER ? op->per : op->n_out;
+}
+
+extern "C" void olap_shard_drillup_destroy(olap_shard_drillup *op) {
+  if (!op) return;
+  DeviceGuard guard;
+  for (size_t i = 0; i < op->ranks.size(); ++i) {
+    const auto &l = op->comm->local[i];
+    (void)hipSetDevice(l.device);
+    (void)hipStreamSynchronize(l.xstream);
+    RankState &rs = op->ranks[i];
+    if (rs.local_plan) olap_plan_destroy(rs.local_plan);
+    if (rs.combine_plan) olap_plan_destroy(rs.combine_plan);
+    for (BufSet &b : rs.set) {
+      for (int p = 0; p < 2; ++p) {
+        if (b.send[p]) dev_free(b.send[p]);
+        if (b.recv[p]) dev_free(b.recv[p]);
+        if (b.peers[p]) dev_free((void *)b.peers[p]);
+      }
+      if (b.result) dev_free(b.result);
+      if (b.result_status) dev_free(b.result_status);
+      if (b.local_done) (void)hipEventDestroy(b.local_done);
+      if (b.xchg_done) (void)hipEventDestroy(b.xchg_done);
+    }
+  }
+  delete op;
+}
+
+extern "C" int olap_shard_drillup_create(olap_shard_drillup **out, olap_comm *comm, int dtype, int default_kind, int method,
+                                         int ndim, const uint32_t *lens, const uint32_t *new_len, const uint32_t *bounds,
+                                         const uint32_t *const *maps, int placement, int depth) {
+  if (!out) return fail(OLAP_ERR_INVALID_ARGUMENT, "op out-pointer is NULL");
+  *out = nullptr;
+  if (!comm) return fail(OLAP_ERR_INVALID_ARGUMENT, "comm is NULL");
+  if (ndim < 1 || ndim > OLAP_MAX_DIMS || !lens || !new_len || !bounds || !maps)
+    return fail(OLAP_ERR_INVALID_ARGUMENT, "a sharded drillUp needs at least one dimension, its lengths, bounds and maps");
+  if (placement < OLAP_PLACE_SCATTER || placement > OLAP_PLACE_ROOT) return fail(OLAP_ERR_INVALID_ARGUMENT, "placement %d", placement);
+  if (depth != 1 && depth != 2) return fail(OLAP_ERR_INVALID_ARGUMENT, "depth must be 1 or 2");
+  olap_shard_recipe recipe;
+  int rc = olap_shard_recipe_get(dtype, default_kind, method, &recipe);
+  if (rc) return rc;
+  const int world = comm->world;
+  if (bounds[0] != 0 || bounds[world] != lens[0]) return fail(OLAP_ERR_INVALID_ARGUMENT, "bounds must run from 0 to the extent of dimension 0");
+  for (int r = 0; r < world; ++r)
+    if (bounds[r + 1] < bounds[r]) return fail(OLAP_ERR_INVALID_ARGUMENT, "bounds must ascend");
+  for (int d = 0; d < ndim; ++d) {
+    if (lens[d] && !maps[d]) return fail(OLAP_ERR_INVALID_ARGUMENT, "maps[%d] is NULL", d);
+    for (uint32_t k = 0; k < lens[d]; ++k)
+      if (maps[d][k] >= new_len[d])
+        return fail(OLAP_ERR_INDEX_RANGE, "drillUp map of dimension %d: entry %u = %u is outside the new dimension (%u items)", d, k, maps[d][k], new_len[d]);
+  }
+  if ((rc = require_device())) return rc;
+
+  olap_shard_drillup *op = new (std::nothrow) olap_shard_drillup();
+  if (!op) return fail(OLAP_ERR_OUT_OF_MEMORY, "out of host memory");
+  op->comm = comm;
+  op->recipe = recipe;
+  op->dtype = dtype;
+  op->default_kind = default_kind;
+  op->method = method;
+  op->depth = depth;
+  op->mask_primary = default_kind == OLAP_DEFAULT_NAN && !is_float_dtype(dtype);
+  // gathered partials are combined on every rank, so their result is whole everywhere
+  op->placement = recipe.finish == OLAP_FINISH_COMBINE ? OLAP_PLACE_ALL : placement;
+  uint64_t n_out = 1;
+  for (int d = 0; d < ndim; ++d) n_out *= new_len[d];
+  op->n_out = n_out;
+  op->per = (n_out + (uint64_t)world - 1) / (uint64_t)world;
+  op->n_send = op->placement == OLAP_PLACE_SCATTER ? op->per * (uint64_t)world : n_out;  // padded so that it divides
+  op->ranks.resize(comm->local.size());
+
+  DeviceGuard guard;
+  const bool def_nan = default_kind == OLAP_DEFAULT_NAN;
+  std::vector<uint32_t> local_len(lens, lens + ndim);
+  std::vector<const uint32_t *> local_maps(maps, maps + ndim);
+  for (size_t i = 0; i < op->ranks.size() && !rc; ++i) {
+    const auto &l = comm->local[i];
+    RankState &rs = op->ranks[i];
+    hipError_t e = hipSetDevice(l.device);
+    if (e != hipSuccess) {
+      rc = hip_fail(e, "hipSetDevice");
+      break;
+    }
+    const uint32_t lo = bounds[l.rank], hi = bounds[l.rank + 1];
+    local_len[0] = hi - lo;
+    local_maps[0] = maps[0] + lo;
+    rs.local_cells = 1;
+    for (int d = 0; d < ndim; ++d) rs.local_cells *= local_len[d];
+    if (rs.local_cells > 0)
+      rc = olap_drillup_plan(&rs.local_plan, dtype, default_kind, recipe.local_method, ndim, local_len.data(), new_len, local_maps.data());
+    if (rc) break;
+    if (recipe.finish == OLAP_FINISH_COMBINE) {
+      // the same drillUp over the rank axis: [world, new_len...] -> [1, new_len...]
+      if (ndim + 1 > OLAP_MAX_DIMS) {
+        rc = fail(OLAP_ERR_INVALID_ARGUMENT, "sharded: too many dimensions for a gathered combine");
+        break;
+      }
+      std::vector<uint32_t> cl_old{(uint32_t)world}, cl_new{1u};
+      std::vector<std::vector<uint32_t>> tabs;
+      tabs.emplace_back((size_t)world, 0u);
+      for (int d = 0; d < ndim; ++d) {
+        cl_old.push_back(new_len[d]);
+        cl_new.push_back(new_len[d]);
+        tabs.emplace_back((size_t)new_len[d]);
+        for (uint32_t k = 0; k < new_len[d]; ++k) tabs.back()[k] = k;
+      }
+      std::vector<const uint32_t *> cm;
+      for (auto &t : tabs) cm.push_back(t.data());
+      rc = olap_drillup_plan(&rs.combine_plan, dtype, default_kind, method, ndim + 1, cl_old.data(), cl_new.data(), cm.data());
+      if (rc) break;
+    }
+    for (int k = 0; k < depth && !rc; ++k) {
+      BufSet &b = rs.set[k];
+      for (int p = 0; p < recipe.n_payloads && !rc; ++p) {
+        const size_t es = payload_size(op, p);
+        e = dev_alloc(&b.send[p], std::max<uint64_t>(op->n_send, 1) * es);
+        if (e == hipSuccess) e = hipMemsetAsync(b.send[p], 0, std::max<uint64_t>(op->n_send, 1) * es, nullptr);
+        const bool needs_recv = !(op->placement == OLAP_PLACE_ROOT && l.rank != 0 && recipe.payload_op[p] != OLAP_XCHG_GATHER);
+        if (e == hipSuccess && needs_recv) e = dev_alloc(&b.recv[p], std::max<uint64_t>(recv_cells(op, p), 1) * es);
+        if (e != hipSuccess) rc = hip_fail(e, "hipMalloc(sharded drillUp buffers)");
+      }
+      if (!rc && rs.local_cells == 0 && def_nan && is_float_dtype(dtype) && !recipe.zero_unset) {
+        // a rank without rows ships "unset everywhere": the canonical default
+        SHARD_DISPATCH(dtype, hipLaunchKernelGGL((fill_default_kernel<T>), grid_for_n(n_out), kBlock, 0, nullptr, (T *)b.send[0], n_out, 1));
+        rc = launch_check("fill_default_kernel");
+      }
+      if (!rc && recipe.finish == OLAP_FINISH_COMBINE) {
+        e = dev_alloc(&b.result, std::max<uint64_t>(n_out, 1) * olap_dtype_size(dtype));
+        if (e == hipSuccess) e = dev_alloc((void **)&b.result_status, std::max<uint64_t>(n_out, 1) * sizeof(int32_t));
+        if (e != hipSuccess) rc = hip_fail(e, "hipMalloc(sharded drillUp result)");
+      }
+      if (!rc) {
+        e = hipEventCreateWithFlags(&b.local_done, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&b.xchg_done, hipEventDisableTiming);
+        if (e != hipSuccess) rc = hip_fail(e, "hipEventCreate");
+      }
+    }
+    if (!rc) {
+      e = hipStreamSynchronize(nullptr);
+      if (e != hipSuccess) rc = hip_fail(e, "hipStreamSynchronize");
+    }
+  }
+  // direct transport: every rank's table of its peers' send buffers
+  if (!rc && comm->transport == TRANSPORT_DIRECT) {
+    for (size_t i = 0; i < op->ranks.size() && !rc; ++i) {
+      (void)hipSetDevice(comm->local[i].device);
+      for (int k = 0; k < depth && !rc; ++k)
+        for (int p = 0; p < recipe.n_payloads && !rc; ++p) {
+          std::vector<const void *> tab(world);
+          for (int q = 0; q < world; ++q) tab[q] = op->ranks[q].set[k].send[p];  // all ranks are local, local index == rank
+          void *dev = nullptr;
+          hipError_t e = dev_alloc(&dev, tab.size() * sizeof(void *));
+          if (e == hipSuccess) e = hipMemcpy(dev, tab.data(), tab.size() * sizeof(void *), hipMemcpyHostToDevice);
+          if (e != hipSuccess) rc = hip_fail(e, "hipMalloc(peer table)");
+          op->ranks[i].set[k].peers[p] = (const void **)dev;
+        }
+    }
+  }
+  if (rc) {
+    olap_shard_drillup_destroy(op);
+    return rc;
+  }
+  *out = op;
+  return OLAP_OK;
+}
+
+extern "C" uint64_t olap_shard_drillup_out_cells(const olap_shard_drillup *op) { return op ? op->n_out : 0; }
+extern "C" uint64_t olap_shard_drillup_local_cells(const olap_shard_drillup *op, int local) {
+  return (op && local >= 0 && local < (int)op->ranks.size()) ? op->ranks[local].local_cells : 0;
+}
+extern "C" const char *olap_shard_drillup_kernel_name(const olap_shard_drillup *op, int local) {
+  if (!op || local < 0 || local >= (int)op->ranks.size() || !op->ranks[local].local_plan) return "";
+  return olap_plan_kernel_name(op->ranks[local].local_plan);
+}
+
+static int check_local(const olap_shard_drillup *op, int local) {
+  if (!op) return fail(OLAP_ERR_INVALID_ARGUMENT, "op is NULL");
+  if (local < 0 || local >= (int)op->ranks.size()) return fail(OLAP_ERR_INVALID_ARGUMENT, "local rank %d outside [0, %d)", local, (int)op->ranks.size());
+  return OLAP_OK;
+}
+
+// local phase into buffer set k
+static int shard_local(olap_shard_drillup *op, int local, int k, const void *in_values, const int32_t *in_status, hipStream_t stream) {
+  RankState &rs = op->ranks[local];
+  BufSet &b = rs.set[k];
+  if (!rs.local_plan) return OLAP_OK;  // no rows: the buffers hold "unset" since creation
+  if (op->mask_primary && !in_status)
+    return fail(OLAP_ERR_INVALID_ARGUMENT, "integer cells over a NaN default: the status mask is required");
+  int rc = olap_plan_run(rs.local_plan, in_values, in_status, b.send[0], op->recipe.n_payloads > 1 ? (int32_t *)b.send[1] : nullptr, stream);
+  if (rc) return rc;
+  if (op->recipe.zero_unset) {
+    SHARD_DISPATCH(op->dtype, hipLaunchKernelGGL((zero_unset_kernel<T>), grid_for_n(op->n_out), kBlock, 0, stream, (T *)b.send[0],
+                                                 (const int32_t *)b.send[1], op->n_out));
+    if ((rc = launch_check("zero_unset_kernel"))) return rc;
+  }
+  return OLAP_OK;
+}
+
+extern "C" int olap_shard_drillup_local(olap_shard_drillup *op, int local, const void *in_values, const int32_t *in_status, void *stream) {
+  int rc = check_local(op, local);
+  if (rc) return rc;
+  DeviceGuard guard;
+  HIP_TRY(hipSetDevice(op->comm->local[local].device));
+  return shard_local(op, local, op->cur, in_values, in_status, (hipStream_t)stream);
+}
+
+// finishing kernels of buffer set k on `stream`
+static int shard_finish(olap_shard_drillup *op, int local, int k, hipStream_t stream) {
+  RankState &rs = op->ranks[local];
+  BufSet &b = rs.set[k];
+  const auto &l = op->comm->local[local];
+  if (op->placement == OLAP_PLACE_ROOT && l.rank != 0) return OLAP_OK;  // nothing arrived here
+  const uint64_t n = recv_cells(op, 0);
+  int rc = OLAP_OK;
+  switch (op->recipe.finish) {
+    case OLAP_FINISH_NONE: break;
+    case OLAP_FINISH_RESTORE:
+      SHARD_DISPATCH(op->dtype, hipLaunchKernelGGL((restore_default_kernel<T>), grid_for_n(n), kBlock, 0, stream, (T *)b.recv[0],
+                                                   (int32_t *)b.recv[1], n, op->default_kind == OLAP_DEFAULT_NAN));
+      rc = launch_check("restore_default_kernel");
+      break;
+    case OLAP_FINISH_AVERAGE:
+      rc = olap_average_finish(b.recv[0], (const int32_t *)b.recv[1], (int32_t *)b.recv[1], n, op->dtype, op->default_kind, stream);
+      break;
+    case OLAP_FINISH_COMBINE:
+      rc = olap_plan_run(rs.combine_plan, b.recv[0], op->recipe.n_payloads > 1 ? (const int32_t *)b.recv[1] : nullptr, b.result,
+                         b.result_status, stream);
+      break;
+  }
+  return rc;
+}
+
+extern "C" int olap_shard_drillup_finish(olap_shard_drillup *op, int local, void *stream) {
+  int rc = check_local(op, local);
+  if (rc) return rc;
+  DeviceGuard guard;
+  HIP_TRY(hipSetDevice(op->comm->local[local].device));
+  return shard_finish(op, local, op->cur, (hipStream_t)stream);
+}
+
+// exchange of buffer set k; xs[i] = the stream rank i's collective is enqueued on
+static int shard_exchange(olap_shard_drillup *op, int k, const std::vector<hipStream_t> &xs) {
+  olap_comm *c = op->comm;
+  const olap_shard_recipe &rp = op->recipe;
+  if (c->transport == TRANSPORT_DETACHED)
+    return fail(OLAP_ERR_INVALID_ARGUMENT, "sharded: a detached communicator has no transport; move the payloads yourself (olap_shard_drillup_payload)");
+  if (c->transport == TRANSPORT_RCCL) {
+    Rccl *r = rccl();
+    RCCL_TRY(r->GroupStart());
+    ncclResult_t res = ncclSuccess;
+    for (size_t i = 0; i < op->ranks.size() && res == ncclSuccess; ++i) {
+      BufSet &b = op->ranks[i].set[k];
+      const auto &l = c->local[i];
+      for (int p = 0; p < rp.n_payloads && res == ncclSuccess; ++p) {
+        const ncclDataType_t ty = nccl_type(rp.payload_dtype[p]);
+        if (rp.payload_op[p] == OLAP_XCHG_GATHER) {
+          res = r->AllGather(b.send[p], b.recv[p], op->n_out, ty, l.nccl, xs[i]);
+          continue;
+        }
+        const ncclRedOp_t red = rp.payload_op[p] == OLAP_XCHG_SUM ? ncclSum : ncclMax;
+        if (op->placement == OLAP_PLACE_SCATTER) res = r->ReduceScatter(b.send[p], b.recv[p], op->per, ty, red, l.nccl, xs[i]);
+        else if (op->placement == OLAP_PLACE_ALL) res = r->AllReduce(b.send[p], b.recv[p], op->n_out, ty, red, l.nccl, xs[i]);
+        else res = r->Reduce(b.send[p], b.recv[p] ? b.recv[p] : b.send[p], op->n_out, ty, red, 0, l.nccl, xs[i]);
+      }
+    }
+    ncclResult_t end = r->GroupEnd();
+    if (res != ncclSuccess) return rccl_fail(res, "RCCL collective");
+    if (end != ncclSuccess) return rccl_fail(end, "ncclGroupEnd");
+    return OLAP_OK;
+  }
+  // direct: all ranks live on one device; each destination reads its peers' partials
+  for (size_t i = 0; i < op->ranks.size(); ++i) {
+    BufSet &b = op->ranks[i].set[k];
+    const auto &l = c->local[i];
+    HIP_TRY(hipSetDevice(l.device));
+    for (int p = 0; p < rp.n_payloads; ++p) {
+      const size_t es = payload_size(op, p);
+      if (rp.payload_op[p] == OLAP_XCHG_GATHER) {
+        for (int q = 0; q < c->world; ++q)
+          HIP_TRY(hipMemcpyAsync((char *)b.recv[p] + (size_t)q * op->n_out * es, op->ranks[q].set[k].send[p], op->n_out * es,
+                                 hipMemcpyDeviceToDevice, xs[i]));
+        continue;
+      }
+      if (op->placement == OLAP_PLACE_ROOT && l.rank != 0) continue;
+      const uint64_t first = op->placement == OLAP_PLACE_SCATTER ? (uint64_t)l.rank * op->per : 0;
+      const uint64_t n = op->placement == OLAP_PLACE_SCATTER ? op->per : op->n_out;
+      const bool sum = rp.payload_op[p] == OLAP_XCHG_SUM;
+#define DIRECT_LAUNCH(T)                                                                                                     \
+  do {                                                                                                                       \
+    if (sum) hipLaunchKernelGGL((direct_combine_kernel<T, OLAP_XCHG_SUM>), grid_for_n(n), kBlock, 0, xs[i],                   \
+                                (const T *const *)b.peers[p], c->world, (T *)b.recv[p], first, n);                           \
+    else hipLaunchKernelGGL((direct_combine_kernel<T, OLAP_XCHG_MAX>), grid_for_n(n), kBlock, 0, xs[i],                       \
+                            (const T *const *)b.peers[p], c->world, (T *)b.recv[p], first, n);                               \
+  } while (0)
+      switch (rp.payload_dtype[p]) {
+        case OLAP_INT32: DIRECT_LAUNCH(int32_t); break;
+        case OLAP_UINT32: DIRECT_LAUNCH(uint32_t); break;
+        case OLAP_FLOAT32: DIRECT_LAUNCH(float); break;
+        default: DIRECT_LAUNCH(double); break;
+      }
+#undef DIRECT_LAUNCH
+      int rc = launch_check("direct_combine_kernel");
+      if (rc) return rc;
+    }
+  }
+  return OLAP_OK;
+}
+
+extern "C" int olap_shard_drillup_exchange(olap_shard_drillup *op, void *const *streams) {
+  if (!op) return fail(OLAP_ERR_INVALID_ARGUMENT, "op is NULL");
+  DeviceGuard guard;
+  std::vector<hipStream_t> xs(op->ranks.size());
+  for (size_t i = 0; i < xs.size(); ++i) xs[i] = streams ? (hipStream_t)streams[i] : nullptr;
+  if (op->comm->transport == TRANSPORT_DIRECT && xs.size() > 1) {
+    // a destination reads every peer's partial: when the callers' streams differ they must have been joined
+    for (size_t i = 1; i < xs.size(); ++i)
+      if (xs[i] != xs[0]) return fail(OLAP_ERR_INVALID_ARGUMENT, "sharded: the direct exchange phase needs one common stream (or use olap_shard_drillup_step)");
+  }
+  return shard_exchange(op, op->cur, xs);
+}
+
+extern "C" int olap_shard_drillup_step(olap_shard_drillup *op, const void *const *in_values, const int32_t *const *in_status,
+                                       void *const *streams) {
+  if (!op || !in_values) return fail(OLAP_ERR_INVALID_ARGUMENT, "op/in_values is NULL");
+  DeviceGuard guard;
+  olap_comm *c = op->comm;
+  const int k = op->depth == 2 ? (op->cur ^ 1) : 0;
+  const size_t nl = op->ranks.size();
+  std::vector<hipStream_t> xs(nl);
+  int rc;
+  // 1. local reductions, each on its caller's stream, behind the previous use of this buffer set
+  for (size_t i = 0; i < nl; ++i) {
+    const auto &l = c->local[i];
+    BufSet &b = op->ranks[i].set[k];
+    hipStream_t s = streams ? (hipStream_t)streams[i] : nullptr;
+    xs[i] = l.xstream;
+    HIP_TRY(hipSetDevice(l.device));
+    if (b.in_flight) HIP_TRY(hipStreamWaitEvent(s, b.xchg_done, 0));
+    if ((rc = shard_local(op, (int)i, k, in_values[i], in_status ? in_status[i] : nullptr, s))) return rc;
+    HIP_TRY(hipEventRecord(b.local_done, s));
+  }
+  // 2. the exchange streams wait for the partials they read (with the direct transport: everybody's)
+  for (size_t i = 0; i < nl; ++i) {
+    HIP_TRY(hipSetDevice(c->local[i].device));
+    if (c->transport == TRANSPORT_DIRECT) {
+      for (size_t j = 0; j < nl; ++j) HIP_TRY(hipStreamWaitEvent(xs[i], op->ranks[j].set[k].local_done, 0));
+    } else {
+      HIP_TRY(hipStreamWaitEvent(xs[i], op->ranks[i].set[k].local_done, 0));
+    }
+  }
+  op->cur = k;
+  if ((rc = shard_exchange(op, k, xs))) return rc;
+  // 3. finish behind the collective; depth 1: the caller's stream is ordered behind the whole step
+  for (size_t i = 0; i < nl; ++i) {
+    const auto &l = c->local[i];
+    BufSet &b = op->ranks[i].set[k];
+    HIP_TRY(hipSetDevice(l.device));
+    if ((rc = shard_finish(op, (int)i, k, xs[i]))) return rc;
+    HIP_TRY(hipEventRecord(b.xchg_done, xs[i]));
+    b.in_flight = true;
+  }
+  if (c->transport == TRANSPORT_DIRECT) {
+    // a peer's next local pass overwrites a partial that THIS rank's exchange reads: every caller stream waits for
+    // every exchange of this set before it may reuse it (recorded above; enforced at the next use of set k) —
+    // with one shared device the simplest correct order is to chain them all now
+    for (size_t i = 0; i < nl; ++i) {
+      hipStream_t s = streams ? (hipStream_t)streams[i] : nullptr;
+      for (size_t j = 0; j < nl; ++j) HIP_TRY(hipStreamWaitEvent(s, op->ranks[j].set[k].xchg_done, 0));
+    }
+  } else if (op->depth == 1) {
+    for (size_t i = 0; i < nl; ++i) {
+      HIP_TRY(hipSetDevice(c->local[i].device));
+      HIP_TRY(hipStreamWaitEvent(streams ? (hipStream_t)streams[i] : nullptr, op->ranks[i].set[k].xchg_done, 0));
+    }
+  }
+  return OLAP_OK;
+}
+
+extern "C" int olap_shard_drillup_wait(olap_shard_drillup *op, void *const *streams) {
+  if (!op) return fail(OLAP_ERR_INVALID_ARGUMENT, "op is NULL");
+  DeviceGuard guard;
+  for (size_t i = 0; i < op->ranks.size(); ++i) {
+    HIP_TRY(hipSetDevice(op->comm->local[i].device));
+    for (int k = 0; k < op->depth; ++k)
+      if (op->ranks[i].set[k].in_flight) HIP_TRY(hipStreamWaitEvent(streams ? (hipStream_t)streams[i] : nullptr, op->ranks[i].set[k].xchg_done, 0));
+  }
+  return OLAP_OK;
+}
+
+extern "C" int olap_shard_drillup_payload(const olap_shard_drillup *op, int local, int p, void **send, void **recv,
+                                          uint64_t *count, int *dtype, int *xchg_op) {
+  int rc = check_local(op, local);
+  if (rc) return rc;
+  if (p < 0 || p >= op->recipe.n_payloads) return fail(OLAP_ERR_INVALID_ARGUMENT, "payload %d outside [0, %d)", p, op->recipe.n_payloads);
+  const BufSet &b = op->ranks[local].set[op->cur];
+  if (send) *send = b.send[p];
+  if (recv) *recv = b.recv[p];
+  if (count) *count = op->recipe.payload_op[p] == OLAP_XCHG_GATHER ? op->n_out : op->n_send;
+  if (dtype) *dtype = op->recipe.payload_dtype[p];
+  if (xchg_op) *xchg_op = op->recipe.payload_op[p];
+  return OLAP_OK;
+}
+
+extern "C" int olap_shard_drillup_result(const olap_shard_drillup *op, int local, void **values, int32_t **status,
+                                         uint64_t *first, uint64_t *count) {
+  int rc = check_local(op, local);
+  if (rc) return rc;
+  const BufSet &b = op->ranks[local].set[op->cur];
+  const int rank = op->comm->local[local].rank;
+  uint64_t f = 0, n = op->n_out;
+  if (op->placement == OLAP_PLACE_SCATTER) {
+    f = std::min<uint64_t>((uint64_t)rank * op->per, op->n_out);
+    n = std::min<uint64_t>(op->per, op->n_out - f);
+  } else if (op->placement == OLAP_PLACE_ROOT && rank != 0) {
+    n = 0;
+  }
+  void *v = nullptr;
+  int32_t *s = nullptr;
+  if (op->recipe.finish == OLAP_FINISH_COMBINE) {
+    v = b.result;
+    s = b.result_status;
+  } else {
+    v = b.recv[0];
+    s = op->recipe.n_payloads > 1 ? (int32_t *)b.recv[1] : nullptr;  // restored / finished in place
+  }
+  if (n == 0) v = nullptr, s = nullptr;
+  if (values) *values = v;
+  if (status) *status = s;
+  if (first) *first = f;
+  if (count) *count = n;
+  return OLAP_OK;
+}
+
+// ------------------------------------------------------------------ sharded store handle
+struct olap_sharded_store {
+  olap_comm *comm = nullptr;
+  std::vector<uint32_t> lens, bounds;
+  int dtype = 0, default_kind = 0;
+  uint64_t inner0 = 1, size = 0;
+  std::vector<olap_store *> shard;  // one per local rank
+};
+
+static uint64_t slab_cells(const olap_sharded_store *s, int local) {
+  const int r = s->comm->local[local].rank;
+  return (uint64_t)(s->bounds[r + 1] - s->bounds[r]) * s->inner0;
+}
+static uint64_t slab_first(const olap_sharded_store *s, int local) {
+  return (uint64_t)s->bounds[s->comm->local[local].rank] * s->inner0;
+}
+
+// the frame of a sharded store (no shards yet)
+static int sharded_frame(olap_sharded_store **out, olap_comm *comm, int ndim, const uint32_t *lens, int dtype, int default_kind,
+                         const uint32_t *bounds) {
+  if (!out) return fail(OLAP_ERR_INVALID_ARGUMENT, "store out-pointer is NULL");
+  *out = nullptr;
+  if (!comm) return fail(OLAP_ERR_INVALID_ARGUMENT, "comm is NULL");
+  int rc;
+  if ((rc = check_default(default_kind)) || (rc = check_dtype(dtype))) return rc;
+  if (ndim < 1 || ndim > OLAP_MAX_DIMS || !lens) return fail(OLAP_ERR_INVALID_ARGUMENT, "a sharded store needs 1..%d dimensions", OLAP_MAX_DIMS);
+  olap_sharded_store *s = new (std::nothrow) olap_sharded_store();
+  if (!s) return fail(OLAP_ERR_OUT_OF_MEMORY, "out of host memory");
+  s->comm = comm;
+  s->lens.assign(lens, lens + ndim);
+  s->dtype = dtype;
+  s->default_kind = default_kind;
+  long double cells = 1;
+  for (int d = 0; d < ndim; ++d) cells *= lens[d];
+  if (cells > 1.0e12L) {
+    delete s;
+    return fail(OLAP_ERR_INVALID_ARGUMENT, "cube too large");
+  }
+  s->inner0 = 1;
+  for (int d = 1; d < ndim; ++d) s->inner0 *= lens[d];
+  s->size = s->inner0 * lens[0];
+  s->bounds.resize(comm->world + 1);
+  if (bounds) {
+    s->bounds.assign(bounds, bounds + comm->world + 1);
+    bool ok = s->bounds[0] == 0 && s->bounds[comm->world] == lens[0];
+    for (int r = 0; r < comm->world; ++r) ok = ok && s->bounds[r + 1] >= s->bounds[r];
+    if (!ok) {
+      delete s;
+      return fail(OLAP_ERR_INVALID_ARGUMENT, "bounds must ascend from 0 to the extent of dimension 0");
+    }
+  } else {
+    olap_shard_bounds(lens[0], comm->world, s->bounds.data());
+  }
+  s->shard.assign(comm->local.size(), nullptr);
+  *out = s;
+  return OLAP_OK;
+}
+
+extern "C" void olap_sharded_store_destroy(olap_sharded_store *s) {
+  if (!s) return;
+  for (olap_store *sh : s->shard) olap_store_destroy(sh);
+  delete s;
+}
+
+extern "C" int olap_sharded_store_create(olap_sharded_store **out, olap_comm *comm, int ndim, const uint32_t *lens, int dtype,
+                                         int default_kind, const uint32_t *bounds) {
+  olap_sharded_store *s = nullptr;
+  int rc = sharded_frame(&s, comm, ndim, lens, dtype, default_kind, bounds);
+  if (rc) return rc;
+  if ((rc = require_device())) {
+    delete s;
+    return rc;
+  }
+  DeviceGuard guard;
+  for (size_t i = 0; i < s->shard.size() && !rc; ++i) {
+    hipError_t e = hipSetDevice(comm->local[i].device);
+    if (e != hipSuccess) rc = hip_fail(e, "hipSetDevice");
+    else rc = olap_store_create(&s->shard[i], slab_cells(s, (int)i), dtype, default_kind);
+  }
+  if (rc) {
+    olap_sharded_store_destroy(s);
+    return rc;
+  }
+  *out = s;
+  return OLAP_OK;
+}
+
+extern "C" uint64_t olap_sharded_store_size(const olap_sharded_store *s) { return s ? s->size : 0; }
+extern "C" int olap_sharded_store_ndim(const olap_sharded_store *s) { return s ? (int)s->lens.size() : 0; }
+extern "C" const uint32_t *olap_sharded_store_lens(const olap_sharded_store *s) { return s ? s->lens.data() : nullptr; }
+extern "C" const uint32_t *olap_sharded_store_bounds(const olap_sharded_store *s) { return s ? s->bounds.data() : nullptr; }
+extern "C" olap_comm *olap_sharded_store_comm(const olap_sharded_store *s) { return s ? s->comm : nullptr; }
+extern "C" olap_store *olap_sharded_store_shard(const olap_sharded_store *s, int local) {
+  return (s && local >= 0 && local < (int)s->shard.size()) ? s->shard[local] : nullptr;
+}
+
+// runs fn(local index, shard) with the shard's device current
+template <typename F>
+static int for_each_shard(const olap_sharded_store *s, F fn) {
+  if (!s) return fail(OLAP_ERR_INVALID_ARGUMENT, "store is NULL");
+  DeviceGuard guard;
+  for (size_t i = 0; i < s->shard.size(); ++i) {
+    HIP_TRY(hipSetDevice(s->comm->local[i].device));
+    int rc = fn((int)i, s->shard[i]);
+    if (rc) return rc;
+  }
+  return OLAP_OK;
+}
+
+extern "C" int olap_sharded_store_fill_seeded(olap_sharded_store *s, uint32_t seed, double frac) {
+  return for_each_shard(s, [&](int i, olap_store *sh) -> int {
+    const uint64_t n = sh->size;
+    if (!n) return OLAP_OK;
+    drop_lazy_status(sh);
+    const bool fnan = sh->default_kind == OLAP_DEFAULT_NAN && is_float_dtype(sh->dtype);
+    int32_t *st = sh->status;
+    int32_t *tmp = nullptr;
+    if (!st && fnan) {
+      HIP_TRY(dev_alloc((void **)&tmp, n * sizeof(int32_t)));
+      st = tmp;
+    }
+    int rc = olap_fill_seeded(sh->values, st, n, slab_first(s, i), sh->dtype, seed, frac, nullptr);
+    if (!rc && fnan) {  // the generator leaves 0 in dropped cells; under a NaN default they hold NaN
+      SHARD_DISPATCH(sh->dtype, hipLaunchKernelGGL((restore_default_kernel<T>), grid_for_n(n), kBlock, 0, nullptr, (T *)sh->values, st, n, 1));
+      rc = launch_check("restore_default_kernel");
+    }
+    hipError_t e = hipStreamSynchronize(nullptr);
+    if (tmp) dev_free(tmp);
+    if (!rc && e != hipSuccess) rc = hip_fail(e, "fill_seeded");
+    return rc;
+  });
+}
+
+extern "C" int olap_sharded_store_set_data_f64(olap_sharded_store *s, const double *host, uint64_t n) {
+  if (!s) return fail(OLAP_ERR_INVALID_ARGUMENT, "store is NULL");
+  if (n != s->size)
+    return fail(OLAP_ERR_LENGTH_MISMATCH, "value length is invalid: %llu !== %llu", (unsigned long long)s->size, (unsigned long long)n);
+  if (n && !host) return fail(OLAP_ERR_INVALID_ARGUMENT, "values is NULL");
+  return for_each_shard(s, [&](int i, olap_store *sh) { return olap_store_set_data_f64(sh, host + slab_first(s, i), sh->size); });
+}
+extern "C" int olap_sharded_store_get_data_f64(const olap_sharded_store *s, double *host) {
+  if (s && s->size && !host) return fail(OLAP_ERR_INVALID_ARGUMENT, "values is NULL");
+  return for_each_shard(s, [&](int i, olap_store *sh) { return olap_store_get_data_f64(sh, host + slab_first(s, i)); });
+}
+extern "C" int olap_sharded_store_get_status(const olap_sharded_store *s, int32_t *host) {
+  if (s && s->size && !host) return fail(OLAP_ERR_INVALID_ARGUMENT, "status is NULL");
+  return for_each_shard(s, [&](int i, olap_store *sh) { return olap_store_get_status(sh, host + slab_first(s, i)); });
+}
+
+// local index of the rank that owns flat cell `index`, or -1
+static int owner_of(const olap_sharded_store *s, uint64_t index, uint64_t *local_index) {
+  const uint64_t row = s->inner0 ? index / s->inner0 : 0;
+  for (size_t i = 0; i < s->shard.size(); ++i) {
+    const int r = s->comm->local[i].rank;
+    if (row >= s->bounds[r] && row < s->bounds[r + 1]) {
+      *local_index = index - (uint64_t)s->bounds[r] * s->inner0;
+      return (int)i;
+    }
+  }
+  return -1;
+}
+
+extern "C" int olap_sharded_store_get_value(const olap_sharded_store *s, uint64_t index, double *value, int *is_set) {
+  if (!s) return fail(OLAP_ERR_INVALID_ARGUMENT, "store is NULL");
+  if (index >= s->size) {
+    if (value) *value = s->default_kind == OLAP_DEFAULT_NAN ? NAN : 0.0;
+    if (is_set) *is_set = 0;
+    return OLAP_OK;
+  }
+  uint64_t li = 0;
+  const int i = owner_of(s, index, &li);
+  if (i < 0) return fail(OLAP_ERR_INDEX_RANGE, "sharded: cell %llu belongs to a rank this process does not drive", (unsigned long long)index);
+  DeviceGuard guard;
+  HIP_TRY(hipSetDevice(s->comm->local[i].device));
+  return olap_store_get_value(s->shard[i], li, value, is_set);
+}
+extern "C" int olap_sharded_store_set_value(olap_sharded_store *s, uint64_t index, double value, int is_null) {
+  if (!s) return fail(OLAP_ERR_INVALID_ARGUMENT, "store is NULL");
+  if (index >= s->size) return fail(OLAP_ERR_INDEX_RANGE, "cell index %llu out of bounds [0, %llu[", (unsigned long long)index, (unsigned long long)s->size);
+  uint64_t li = 0;
+  const int i = owner_of(s, index, &li);
+  if (i < 0) return fail(OLAP_ERR_INDEX_RANGE, "sharded: cell %llu belongs to a rank this process does not drive", (unsigned long long)index);
+  DeviceGuard guard;
+  HIP_TRY(hipSetDevice(s->comm->local[i].device));
+  return olap_store_set_value(s->shard[i], li, value, is_null);
+}
+extern "C" int olap_sharded_store_fill(olap_sharded_store *s, double value) {
+  return for_each_shard(s, [&](int, olap_store *sh) { return olap_store_fill(sh, value); });
+}
+extern "C" int olap_sharded_store_total(const olap_sharded_store *s, double *total) {
+  if (!total) return fail(OLAP_ERR_INVALID_ARGUMENT, "total is NULL");
+  double acc = 0.0;
+  int rc = for_each_shard(s, [&](int, olap_store *sh) {
+    double t = 0.0;
+    int e = olap_store_total(sh, &t);
+    acc += t;  // ranks own ascending index ranges: the reference's order of addition between slabs
+    return e;
+  });
+  *total = acc;
+  return rc;
+}
+
+extern "C" int olap_sharded_store_clone(const olap_sharded_store *s, olap_sharded_store **out) {
+  if (!s || !out) return fail(OLAP_ERR_INVALID_ARGUMENT, "store is NULL");
+  olap_sharded_store *c = nullptr;
+  int rc = sharded_frame(&c, s->comm, (int)s->lens.size(), s->lens.data(), s->dtype, s->default_kind, s->bounds.data());
+  if (rc) return rc;
+  rc = for_each_shard(s, [&](int i, olap_store *sh) { return olap_store_clone(sh, &c->shard[i]); });
+  if (rc) {
+    olap_sharded_store_destroy(c);
+    return rc;
+  }
+  *out = c;
+  return OLAP_OK;
+}
+
+extern "C" int olap_sharded_store_gather(const olap_sharded_store *s, olap_store **out) {
+  if (!s || !out) return fail(OLAP_ERR_INVALID_ARGUMENT, "store is NULL");
+  *out = nullptr;
+  olap_comm *c = s->comm;
+  const bool one_process = (int)c->local.size() == c->world;
+  if (!one_process && c->transport != TRANSPORT_RCCL)
+    return fail(OLAP_ERR_INVALID_ARGUMENT, "sharded: gathering across processes needs the RCCL transport");
+  DeviceGuard guard;
+  // the slabs must be complete before another device (or RCCL's stream) reads them
+  for (size_t i = 0; i < s->shard.size(); ++i) {
+    HIP_TRY(hipSetDevice(c->local[i].device));
+    HIP_TRY(hipStreamSynchronize(nullptr));
+  }
+  HIP_TRY(hipSetDevice(c->local[0].device));
+  olap_store *w = nullptr;
+  int rc = store_alloc(&w, s->size, s->dtype, s->default_kind);
+  if (rc) return rc;
+  const size_t es = olap_dtype_size(s->dtype);
+  hipError_t e = hipSuccess;
+  if (one_process) {
+    for (size_t i = 0; i < s->shard.size() && e == hipSuccess; ++i) {
+      const olap_store *sh = s->shard[i];
+      if (!sh->size) continue;
+      e = hipMemcpyAsync((char *)w->values + slab_first(s, (int)i) * es, sh->values, sh->size * es, hipMemcpyDefault, nullptr);
+      if (e == hipSuccess && w->status)
+        e = hipMemcpyAsync(w->status + slab_first(s, (int)i), sh->status, sh->size * sizeof(int32_t), hipMemcpyDefault, nullptr);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
+  } else {
+    Rccl *r = rccl();
+    const auto &l = c->local[0];
+    ncclResult_t res = r->GroupStart();
+    for (int q = 0; q < c->world && res == ncclSuccess; ++q) {
+      const uint64_t first = (uint64_t)s->bounds[q] * s->inner0, n = (uint64_t)(s->bounds[q + 1] - s->bounds[q]) * s->inner0;
+      if (!n) continue;
+      const void *src = q == l.rank ? s->shard[0]->values : nullptr;
+      res = r->Broadcast(src ? src : (char *)w->values + first * es, (char *)w->values + first * es, n, nccl_type(s->dtype), q, l.nccl, l.xstream);
+      if (res == ncclSuccess && w->status) {
+        const void *ssrc = q == l.rank ? (const void *)s->shard[0]->status : nullptr;
+        res = r->Broadcast(ssrc ? ssrc : (const void *)(w->status + first), w->status + first, n, ncclInt32, q, l.nccl, l.xstream);
+      }
+    }
+    ncclResult_t end = r->GroupEnd();
+    if (res != ncclSuccess || end != ncclSuccess) {
+      olap_store_destroy(w);
+      return rccl_fail(res != ncclSuccess ? res : end, "ncclBroadcast");
+    }
+    e = hipStreamSynchronize(l.xstream);
+  }
+  if (e != hipSuccess) {
+    olap_store_destroy(w);
+    return hip_fail(e, "sharded gather");
+  }
+  *out = w;
+  return OLAP_OK;
+}
+
+extern "C" int olap_sharded_store_scatter(olap_sharded_store **out, olap_comm *comm, const olap_store *whole, int ndim, const uint32_t *lens) {
+  if (!whole) return fail(OLAP_ERR_INVALID_ARGUMENT, "store is NULL");
+  olap_sharded_store *s = nullptr;
+  int rc = sharded_frame(&s, comm, ndim, lens, whole->dtype, whole->default_kind, nullptr);
+  if (rc) return rc;
+  if (s->size != whole->size) {
+    delete s;
+    return fail(OLAP_ERR_LENGTH_MISMATCH, "store holds %llu cells but the dimensions describe %llu", (unsigned long long)whole->size, (unsigned long long)s->size);
+  }
+  const size_t es = olap_dtype_size(s->dtype);
+  {
+    DeviceGuard guard;
+    hipError_t e = hipSetDevice(whole->device);
+    if (e == hipSuccess) e = hipStreamSynchronize(nullptr);  // the source must be complete before peers read it
+    if (e != hipSuccess) {
+      delete s;
+      return hip_fail(e, "sharded scatter");
+    }
+  }
+  rc = for_each_shard(s, [&](int i, olap_store *) -> int {
+    olap_store *sh = nullptr;
+    int e2 = store_alloc(&sh, slab_cells(s, i), s->dtype, s->default_kind);
+    if (e2) return e2;
+    s->shard[i] = sh;
+    if (!sh->size) return OLAP_OK;
+    HIP_TRY(hipMemcpyAsync(sh->values, (const char *)whole->values + slab_first(s, i) * es, sh->size * es, hipMemcpyDefault, nullptr));
+    if (sh->status) HIP_TRY(hipMemcpyAsync(sh->status, whole->status + slab_first(s, i), sh->size * sizeof(int32_t), hipMemcpyDefault, nullptr));
+    HIP_TRY(hipStreamSynchronize(nullptr));
+    return OLAP_OK;
+  });
+  if (rc) {
+    olap_sharded_store_destroy(s);
+    return rc;
+  }
+  *out = s;
+  return OLAP_OK;
+}
+
+static bool identity_map(const uint32_t *m, uint32_t old_len, uint32_t new_len) {
+  if (old_len != new_len) return false;
+  for (uint32_t k = 0; k < old_len; ++k)
+    if (m[k] != k) return false;
+  return true;
+}
+
+// lens of local rank i's slab, with dimension 0 replaced by its row count
+static std::vector<uint32_t> local_lens(const olap_sharded_store *s, int i, const uint32_t *lens) {
+  std::vector<uint32_t> v(lens, lens + s->lens.size());
+  const int r = s->comm->local[i].rank;
+  v[0] = s->bounds[r + 1] - s->bounds[r];
+  return v;
+}
+
+extern "C" int olap_sharded_store_drillup(const olap_sharded_store *s, olap_sharded_store **out_sharded, olap_store **out_whole,
+                                          const uint32_t *new_len, const uint32_t *const *maps, int method) {
+  if (!s || !out_sharded || !out_whole) return fail(OLAP_ERR_INVALID_ARGUMENT, "store/out is NULL");
+  *out_sharded = nullptr;
+  *out_whole = nullptr;
+  const int ndim = (int)s->lens.size();
+  if (!new_len || !maps) return fail(OLAP_ERR_INVALID_ARGUMENT, "new_len/maps is NULL");
+  for (int d = 0; d < ndim; ++d)
+    if (s->lens[d] && !maps[d]) return fail(OLAP_ERR_INVALID_ARGUMENT, "maps[%d] is NULL", d);
+  if (method < OLAP_SUM || method > OLAP_PRODUCT) return fail(OLAP_ERR_UNSUPPORTED_METHOD, "Unsupported aggregation method: %d", method);
+  if (identity_map(maps[0], s->lens[0], new_len[0])) {
+    // the sharded axis is untouched: per shard, no communication
+    olap_sharded_store *o = nullptr;
+    int rc = sharded_frame(&o, s->comm, ndim, new_len, s->dtype, s->default_kind, s->bounds.data());
+    if (rc) return rc;
+    rc = for_each_shard(s, [&](int i, olap_store *sh) {
+      std::vector<uint32_t> ol = local_lens(s, i, s->lens.data()), nl = local_lens(s, i, new_len);
+      std::vector<const uint32_t *> lm(maps, maps + ndim);
+      return olap_store_drillup(sh, &o->shard[i], ndim, ol.data(), nl.data(), lm.data(), method);
+    });
+    if (rc) {
+      olap_sharded_store_destroy(o);
+      return rc;
+    }
+    *out_sharded = o;
+    return OLAP_OK;
+  }
+  // the sharded axis is rolled up: partial + one collective; the result is K0/G0 times smaller and
+  // arrives whole on the device of local rank 0
+  olap_comm *c = s->comm;
+  const bool one_process = (int)c->local.size() == c->world;
+  olap_shard_drillup *op = nullptr;
+  int rc = olap_shard_drillup_create(&op, c, s->dtype, s->default_kind, method, ndim, s->lens.data(), new_len, s->bounds.data(), maps,
+                                     one_process ? OLAP_PLACE_ROOT : OLAP_PLACE_ALL, 1);
+  if (rc) return rc;
+  std::vector<const void *> vals(s->shard.size());
+  std::vector<const int32_t *> stat(s->shard.size());
+  for (size_t i = 0; i < s->shard.size(); ++i) {
+    vals[i] = s->shard[i]->values;
+    stat[i] = mask_needed(s->shard[i]);
+  }
+  rc = olap_shard_drillup_step(op, vals.data(), stat.data(), nullptr);
+  olap_store *w = nullptr;
+  if (!rc) {
+    DeviceGuard guard;
+    hipError_t e = hipSetDevice(c->local[0].device);
+    if (e != hipSuccess) rc = hip_fail(e, "hipSetDevice");
+    if (!rc) rc = store_alloc(&w, op->n_out, s->dtype, s->default_kind);
+    if (!rc) {
+      void *rv = nullptr;
+      int32_t *rs = nullptr;
+      uint64_t first = 0, count = 0;
+      rc = olap_shard_drillup_result(op, 0, &rv, &rs, &first, &count);
+      if (!rc && count != op->n_out) rc = fail(OLAP_ERR_INVALID_ARGUMENT, "sharded: local rank 0 does not hold the whole result");
+      if (!rc && count) {
+        // (the null stream is already ordered behind the step)
+        e = hipMemcpyAsync(w->values, rv, count * olap_dtype_size(s->dtype), hipMemcpyDeviceToDevice, nullptr);
+        if (e == hipSuccess && w->status) {
+          if (rs) e = hipMemcpyAsync(w->status, rs, count * sizeof(int32_t), hipMemcpyDeviceToDevice, nullptr);
+          else rc = olap_canonicalize(w->values, w->status, count, s->dtype, s->default_kind, 0, nullptr);
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(nullptr);  // the op's buffers are released below
+        if (e != hipSuccess) rc = hip_fail(e, "sharded drillUp result");
+      }
+    }
+  }
+  olap_shard_drillup_destroy(op);
+  if (rc) {
+    olap_store_destroy(w);
+    return rc;
+  }
+  *out_whole = w;
+  return OLAP_OK;
+}
+
+extern "C" int olap_sharded_store_dice(const olap_sharded_store *s, olap_sharded_store **out, const uint32_t *new_len, const int32_t *const *sel) {
+  if (!s || !out) return fail(OLAP_ERR_INVALID_ARGUMENT, "store/out is NULL");
+  *out = nullptr;
+  const int ndim = (int)s->lens.size();
+  if (!new_len || !sel) return fail(OLAP_ERR_INVALID_ARGUMENT, "new_len/sel is NULL");
+  for (int d = 0; d < ndim; ++d)
+    if (new_len[d] && !sel[d]) return fail(OLAP_ERR_INVALID_ARGUMENT, "sel[%d] is NULL", d);
+  std::vector<uint32_t> nb(s->comm->world + 1);
+  int rc = olap_shard_dice_bounds(s->bounds.data(), s->comm->world, sel[0], new_len[0], nb.data());
+  if (rc) return rc;
+  olap_sharded_store *o = nullptr;
+  if ((rc = sharded_frame(&o, s->comm, ndim, new_len, s->dtype, s->default_kind, nb.data()))) return rc;
+  rc = for_each_shard(s, [&](int i, olap_store *sh) {
+    const int r = s->comm->local[i].rank;
+    std::vector<uint32_t> ol = local_lens(s, i, s->lens.data()), nl(new_len, new_len + ndim);
+    nl[0] = nb[r + 1] - nb[r];
+    std::vector<int32_t> rows(sel[0] + nb[r], sel[0] + nb[r + 1]);
+    for (auto &x : rows) x -= (int32_t)s->bounds[r];
+    std::vector<const int32_t *> ls(sel, sel + ndim);
+    ls[0] = rows.data();
+    return olap_store_dice(sh, &o->shard[i], ndim, ol.data(), nl.data(), ls.data());
+  });
+  if (rc) {
+    olap_sharded_store_destroy(o);
+    return rc;
+  }
+  *out = o;
+  return OLAP_OK;
+}
+
+extern "C" int olap_sharded_store_drilldown(const olap_sharded_store *s, olap_sharded_store **out, const uint32_t *new_len,
+                                            const uint32_t *const *maps, int method, const double *distributions, uint64_t n_dist) {
+  if (!s || !out) return fail(OLAP_ERR_INVALID_ARGUMENT, "store/out is NULL");
+  *out = nullptr;
+  const int ndim = (int)s->lens.size();
+  if (!new_len || !maps) return fail(OLAP_ERR_INVALID_ARGUMENT, "new_len/maps is NULL");
+  for (int d = 0; d < ndim; ++d)
+    if (new_len[d] && !maps[d]) return fail(OLAP_ERR_INVALID_ARGUMENT, "maps[%d] is NULL", d);
+  if (!identity_map(maps[0], new_len[0], s->lens[0]))
+    return fail(OLAP_ERR_INVALID_ARGUMENT, "sharded: refining the sharded dimension changes the partition; gather first");
+  if (distributions)
+    return fail(OLAP_ERR_INVALID_ARGUMENT, "sharded: drillDown with distributions indexes weights by the global cell index; gather first");
+  (void)n_dist;
+  olap_sharded_store *o = nullptr;
+  int rc = sharded_frame(&o, s->comm, ndim, new_len, s->dtype, s->default_kind, s->bounds.data());
+  if (rc) return rc;
+  rc = for_each_shard(s, [&](int i, olap_store *sh) {
+    std::vector<uint32_t> ol = local_lens(s, i, s->lens.data()), nl = local_lens(s, i, new_len);
+    std::vector<uint32_t> rows(nl[0]);
+    for (uint32_t k = 0; k < nl[0]; ++k) rows[k] = k;
+    std::vector<const uint32_t *> lm(maps, maps + ndim);
+    lm[0] = rows.data();
+    return olap_store_drilldown(sh, &o->shard[i], ndim, ol.data(), nl.data(), lm.data(), method, nullptr, 0);
+  });
+  if (rc) {
+    olap_sharded_store_destroy(o);
+    return rc;
+  }
+  *out = o;
+  return OLAP_OK;
+}
+
+extern "C" int olap_sharded_store_reorder(const olap_sharded_store *s, olap_sharded_store **out, const int32_t *perm) {
+  if (!s || !out) return fail(OLAP_ERR_INVALID_ARGUMENT, "store/out is NULL");
+  *out = nullptr;
+  const int ndim = (int)s->lens.size();
+  if (!perm) return fail(OLAP_ERR_INVALID_ARGUMENT, "perm is NULL");
+  if (perm[0] != 0) return fail(OLAP_ERR_INVALID_ARGUMENT, "sharded: moving the sharded dimension needs an all-to-all; gather first");
+  std::vector<uint32_t> nl(ndim);
+  for (int d = 0; d < ndim; ++d) {
+    if (perm[d] < 0 || perm[d] >= ndim) return fail(OLAP_ERR_INVALID_ARGUMENT, "perm[%d] = %d out of range", d, perm[d]);
+    nl[d] = s->lens[perm[d]];
+  }
+  olap_sharded_store *o = nullptr;
+  int rc = sharded_frame(&o, s->comm, ndim, nl.data(), s->dtype, s->default_kind, s->bounds.data());
+  if (rc) return rc;
+  rc = for_each_shard(s, [&](int i, olap_store *sh) {
+    std::vector<uint32_t> ol = local_lens(s, i, s->lens.data());
+    return olap_store_reorder(sh, &o->shard[i], ndim, ol.data(), perm);
+  });
+  if (rc) {
+    olap_sharded_store_destroy(o);
+    return rc;
+  }
+  *out = o;
+  return OLAP_OK;
+}

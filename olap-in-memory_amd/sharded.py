@@ -1,36 +1,406 @@
-"""Multi-GPU host: one process per GPU, the cube partitioned along its outermost dimension.
+"""Multi-GPU host: a thin ctypes view of libolapgpu's sharded entry points (include/olap_hip.h,
+"Multi-GPU"; implementation olap-in-memory_amd/csrc/olap_sharded.hip).
 
-Row-major layout makes a dim0 partition a set of contiguous slabs (src/cube.js:709-728: last
-dimension fastest): rank r owns rows [row_lo, row_hi) of dimension 0, i.e. the flat range
-[row_lo*inner0, row_hi*inner0).  Every store operation that leaves dimension 0 alone runs per
-shard with no communication.  drillUp ON dimension 0 (in-memory.js:265-334 with a non-identity
-map on the sharded axis) reduces each rank's own rows into a partial [G, inner0] cube with the
-same kernel and a row sub-map, then ONE collective combines the partials:
+The cube is partitioned along its outermost dimension (row-major layout, src/cube.js:709-728, makes
+the slabs contiguous).  Everything that matters lives behind the C ABI — the row partition, the row
+sub-maps, what a sharded drillUp ships (olap_shard_recipe), the RCCL collectives and the finishing
+kernels — so that the Node.js host reaches it too.  What is left here:
 
-  sum      -> reduce-scatter (all-reduce when the output does not divide) with ncclSum over xGMI
-  average  -> the same on (float sum, int32 contribution count) pairs produced in ONE local pass
-              (OLAP_PARTIAL_AVERAGE), divided afterwards (olap_average_finish)
-  other    -> all-gather of (value, status) partials, then the same drillUp kernel over the rank
-              axis: highest / lowest / first / last / product are associative in rank order
-
-torch.distributed provides the process group only (backend "nccl" is RCCL on ROCm; with "gloo"
-device tensors are staged through host memory, for rehearsals).  All cell arithmetic goes through
-an engine object; the package ships exactly one, HipEngine (libolapgpu).  CPU tests inject their
-own engine to rehearse the partition/collective logic without a GPU.
+  Comm           olap_comm: init_rank (one process per GPU; the unique id travels over
+                 torch.distributed's store), init_all (one process, a device list), detached
+  ShardedStore   olap_sharded_store: one measure, dimension 0 split over the ranks
+  ShardDrillUp   olap_shard_drillup: the reusable "local partial + one collective + finish" step
+                 that bench.py times at N > 1
+  exchange_over_process_group
+                 rehearsal aid: moves a detached op's payloads through host memory and a
+                 torch.distributed group (gloo), so N processes sharing ONE GPU can run the N > 1
+                 code path; RCCL refuses two ranks on one device
+  HipEngine      torch tensors as device-memory plumbing for bench.py and tools/
 """
+import ctypes as C
+
 import numpy as np
 
 from . import capi
-from .hipstore import Plan
+from .capi import check
+from .hipstore import HipStore, Plan, _default_kind, _method_code, _tables, _u32
+
+NP_OF_DTYPE = {0: np.int32, 1: np.uint32, 2: np.float32, 3: np.float64}
 
 
 def partition_rows(n_rows, world):
-    """Contiguous, balanced split of dimension 0: the first (n_rows % world) ranks get one more."""
-    base, extra = divmod(int(n_rows), int(world))
-    bounds = [0]
-    for r in range(world):
-        bounds.append(bounds[-1] + base + (1 if r < extra else 0))
-    return bounds
+    """olap_shard_bounds: contiguous, balanced split of dimension 0 (the first n_rows % world ranks get one more)."""
+    b = np.zeros(int(world) + 1, np.uint32)
+    check(capi.lib().olap_shard_bounds(int(n_rows), int(world), b.ctypes.data_as(capi._pu32)))
+    return [int(x) for x in b]
+
+
+def dice_bounds(bounds, rows):
+    """olap_shard_dice_bounds: the partition left by a dice of dimension 0 with ascending `rows`."""
+    b = _u32(bounds)
+    r = np.ascontiguousarray(np.asarray(rows, dtype=np.int32))
+    out = np.zeros(b.size, np.uint32)
+    check(capi.lib().olap_shard_dice_bounds(b.ctypes.data_as(capi._pu32), b.size - 1, r.ctypes.data_as(capi._pi32), r.size,
+                                            out.ctypes.data_as(capi._pu32)))
+    return [int(x) for x in out]
+
+
+def recipe(dtype, default, method):
+    """olap_shard_recipe_get as a dict (what one sharded drillUp of dimension 0 ships, and how it is combined)."""
+    r = capi.ShardRecipe()
+    check(capi.lib().olap_shard_recipe_get(capi.DTYPES[dtype], _default_kind(default), _method_code(method), C.byref(r)))
+    return {"local_method": r.local_method, "zero_unset": bool(r.zero_unset), "n_payloads": r.n_payloads,
+            "payload_dtype": list(r.payload_dtype), "payload_op": list(r.payload_op), "finish": r.finish}
+
+
+class Comm:
+    def __init__(self, handle):
+        self._h = handle
+
+    @staticmethod
+    def unique_id():
+        buf = C.create_string_buffer(capi.UNIQUE_ID_BYTES)
+        check(capi.lib().olap_comm_unique_id(buf))
+        return buf.raw
+
+    @classmethod
+    def init_rank(cls, unique_id, world, rank, device):
+        h = C.c_void_p()
+        check(capi.lib().olap_comm_init_rank(C.byref(h), bytes(unique_id), int(world), int(rank), int(device)))
+        return cls(h)
+
+    @classmethod
+    def init_all(cls, devices):
+        d = (C.c_int * len(devices))(*[int(x) for x in devices])
+        h = C.c_void_p()
+        check(capi.lib().olap_comm_init_all(C.byref(h), d, len(devices)))
+        return cls(h)
+
+    @classmethod
+    def detached(cls, world, rank, device=0):
+        h = C.c_void_p()
+        check(capi.lib().olap_comm_init_detached(C.byref(h), int(world), int(rank), int(device)))
+        return cls(h)
+
+    @classmethod
+    def from_process_group(cls, dist, device, group=None):
+        """One process per GPU: rank 0 makes the RCCL unique id, torch.distributed carries it."""
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        box = [cls.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0, group=group)
+        return cls.init_rank(box[0], world, rank, device)
+
+    @property
+    def world(self):
+        return capi.lib().olap_comm_world(self._h)
+
+    @property
+    def local_count(self):
+        return capi.lib().olap_comm_local_count(self._h)
+
+    def local_rank(self, i=0):
+        return capi.lib().olap_comm_local_rank(self._h, i)
+
+    def local_device(self, i=0):
+        return capi.lib().olap_comm_local_device(self._h, i)
+
+    @property
+    def transport(self):
+        return capi.lib().olap_comm_transport(self._h).decode()
+
+    def destroy(self):
+        if self._h:
+            capi.lib().olap_comm_destroy(self._h)
+            self._h = None
+
+
+def _ptr_array(ptrs):
+    arr = (C.c_void_p * max(len(ptrs), 1))()
+    for i, p in enumerate(ptrs):
+        arr[i] = p or None
+    return arr
+
+
+class ShardDrillUp:
+    """olap_shard_drillup: drillUp of the sharded dimension as local partial + ONE collective + finish."""
+
+    def __init__(self, comm, dtype, default, method, lens, new_len, bounds, maps, placement=capi.PLACE_SCATTER, depth=1):
+        self.comm = comm
+        self.dtype = dtype
+        ol, nl, bd = _u32(lens), _u32(new_len), _u32(bounds)
+        keep, arr = _tables(maps, np.uint32, C.c_uint32)
+        h = C.c_void_p()
+        check(capi.lib().olap_shard_drillup_create(C.byref(h), comm._h, capi.DTYPES[dtype], _default_kind(default),
+                                                   _method_code(method), len(ol), ol.ctypes.data_as(capi._pu32),
+                                                   nl.ctypes.data_as(capi._pu32), bd.ctypes.data_as(capi._pu32), arr,
+                                                   int(placement), int(depth)))
+        self._h = h
+        self.recipe = recipe(dtype, default, method)
+        # gathered partials are combined on every rank: their result is whole everywhere
+        self.placement = capi.PLACE_ALL if self.recipe["finish"] == capi.FINISH_COMBINE else int(placement)
+
+    @property
+    def out_cells(self):
+        return int(capi.lib().olap_shard_drillup_out_cells(self._h))
+
+    def local_cells(self, i=0):
+        return int(capi.lib().olap_shard_drillup_local_cells(self._h, i))
+
+    def kernel_name(self, i=0):
+        return capi.lib().olap_shard_drillup_kernel_name(self._h, i).decode()
+
+    def step(self, in_values, in_status=None, streams=None):
+        """in_values / in_status / streams: one device address per local rank."""
+        v = _ptr_array(in_values)
+        s = _ptr_array(in_status) if in_status is not None else None
+        st = _ptr_array(streams) if streams is not None else None
+        check(capi.lib().olap_shard_drillup_step(self._h, v, s, st))
+
+    def wait(self, streams=None):
+        check(capi.lib().olap_shard_drillup_wait(self._h, _ptr_array(streams) if streams is not None else None))
+
+    def local(self, i, in_values, in_status=None, stream=None):
+        check(capi.lib().olap_shard_drillup_local(self._h, i, in_values or None, in_status or None, stream or None))
+
+    def exchange(self, streams=None):
+        check(capi.lib().olap_shard_drillup_exchange(self._h, _ptr_array(streams) if streams is not None else None))
+
+    def finish(self, i, stream=None):
+        check(capi.lib().olap_shard_drillup_finish(self._h, i, stream or None))
+
+    def payload(self, i, p):
+        send, recv, n, dt, op = C.c_void_p(), C.c_void_p(), C.c_uint64(), C.c_int(), C.c_int()
+        check(capi.lib().olap_shard_drillup_payload(self._h, i, p, C.byref(send), C.byref(recv), C.byref(n), C.byref(dt), C.byref(op)))
+        return send.value, recv.value, n.value, dt.value, op.value
+
+    def result(self, i=0):
+        """-> (values address, status address or None, first flat cell, cell count) of the last step."""
+        v, s, f, n = C.c_void_p(), C.c_void_p(), C.c_uint64(), C.c_uint64()
+        check(capi.lib().olap_shard_drillup_result(self._h, i, C.byref(v), C.byref(s), C.byref(f), C.byref(n)))
+        return v.value, s.value, f.value, n.value
+
+    def result_host(self, i=0):
+        """(values, status or None, first) of the last step copied to host arrays (blocking)."""
+        v, s, f, n = self.result(i)
+        vals = np.zeros(max(n, 1), NP_OF_DTYPE[capi.DTYPES[self.dtype]])
+        if n:
+            check(capi.lib().olap_memcpy_to_host(vals.ctypes.data_as(C.c_void_p), v, n * vals.itemsize))
+        stat = None
+        if s and n:
+            stat = np.zeros(n, np.int32)
+            check(capi.lib().olap_memcpy_to_host(stat.ctypes.data_as(C.c_void_p), s, n * 4))
+        return vals[:n], stat, f
+
+    def destroy(self):
+        if self._h:
+            capi.lib().olap_shard_drillup_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+
+def exchange_over_process_group(op, dist, group=None):
+    """Rehearsal aid for a DETACHED communicator: plays olap_shard_drillup_exchange() through host memory and
+    a torch.distributed group (gloo), honouring the op's placement by filling `recv` exactly as RCCL would."""
+    import torch
+
+    L = capi.lib()
+    check(L.olap_device_synchronize())
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    for p in range(op.recipe["n_payloads"]):
+        send, recv, n, dt, xop = op.payload(0, p)
+        host = np.zeros(max(n, 1), NP_OF_DTYPE[dt])
+        check(L.olap_memcpy_to_host(host.ctypes.data_as(C.c_void_p), send, n * host.itemsize))
+        wire = host.view(np.int32) if dt == capi.DTYPES["uint32"] else host  # gloo has no uint32; sums wrap alike
+        t = torch.from_numpy(wire)
+        if xop == capi.XCHG_GATHER:
+            outs = [torch.empty_like(t) for _ in range(world)]
+            dist.all_gather(outs, t, group=group)
+            full = np.concatenate([o.numpy() for o in outs])
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM if xop == capi.XCHG_SUM else dist.ReduceOp.MAX, group=group)
+            full = t.numpy()
+            if op.placement == capi.PLACE_SCATTER:  # this rank keeps its own block of the padded payload
+                per = n // world
+                full = full[rank * per:(rank + 1) * per]
+        if recv:
+            full = np.ascontiguousarray(full)
+            check(L.olap_memcpy_to_device(recv, full.ctypes.data_as(C.c_void_p), full.size * full.itemsize))
+
+
+class ShardedStore:
+    """olap_sharded_store: one measure of a cube whose dimension 0 is split over the ranks of a Comm."""
+
+    def __init__(self, comm, lens, dtype="float32", default=0.0, bounds=None, _handle=None):
+        self.comm = comm
+        self._lib = capi.lib()
+        if _handle is not None:
+            self._h = _handle
+        else:
+            ol = _u32(lens)
+            bd = _u32(bounds) if bounds is not None else None
+            h = C.c_void_p()
+            check(self._lib.olap_sharded_store_create(C.byref(h), comm._h, len(ol), ol.ctypes.data_as(capi._pu32), capi.DTYPES[dtype],
+                                                      _default_kind(default), bd.ctypes.data_as(capi._pu32) if bd is not None else None))
+            self._h = h
+        self.dtype = dtype
+        self.default = default
+
+    def _wrap(self, handle):
+        return ShardedStore(self.comm, None, self.dtype, self.default, _handle=handle)
+
+    def __del__(self):
+        try:
+            if self._h:
+                self._lib.olap_sharded_store_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    @property
+    def size(self):
+        return int(self._lib.olap_sharded_store_size(self._h))
+
+    @property
+    def lens(self):
+        n = self._lib.olap_sharded_store_ndim(self._h)
+        p = self._lib.olap_sharded_store_lens(self._h)
+        return [int(p[i]) for i in range(n)]
+
+    @property
+    def bounds(self):
+        p = self._lib.olap_sharded_store_bounds(self._h)
+        return [int(p[i]) for i in range(self.comm.world + 1)]
+
+    @property
+    def inner0(self):
+        return int(np.prod(self.lens[1:])) if len(self.lens) > 1 else 1
+
+    def shard(self, i=0):
+        """Borrowed HipStore view of local rank i's slab (do not destroy)."""
+        h = self._lib.olap_sharded_store_shard(self._h, i)
+        s = HipStore(0, _handle=C.c_void_p(h))
+        s._borrowed = self  # keeps the owner alive
+        s.__class__ = _BorrowedStore
+        return s
+
+    def local_range(self, i=0):
+        b, r = self.bounds, self.comm.local_rank(i)
+        return b[r] * self.inner0, b[r + 1] * self.inner0
+
+    def fill_seeded(self, seed=20240807, frac=1.0):
+        check(self._lib.olap_sharded_store_fill_seeded(self._h, int(seed), float(frac)))
+        return self
+
+    def set_data_f64(self, values):
+        v = np.ascontiguousarray(np.asarray(values, dtype=np.float64).ravel())
+        check(self._lib.olap_sharded_store_set_data_f64(self._h, v.ctypes.data_as(capi._pdbl), v.size))
+        return self
+
+    def get_data_f64(self):
+        """Full-size array; only the rows of this process' ranks are filled (the rest stay NaN)."""
+        out = np.full(max(self.size, 1), np.nan)
+        check(self._lib.olap_sharded_store_get_data_f64(self._h, out.ctypes.data_as(capi._pdbl)))
+        return out[: self.size]
+
+    def get_status(self):
+        out = np.full(max(self.size, 1), -1, np.int32)
+        check(self._lib.olap_sharded_store_get_status(self._h, out.ctypes.data_as(capi._pi32)))
+        return out[: self.size]
+
+    def get_value(self, index):
+        v, s = C.c_double(), C.c_int()
+        check(self._lib.olap_sharded_store_get_value(self._h, int(index), C.byref(v), C.byref(s)))
+        return v.value, bool(s.value)
+
+    def set_value(self, index, value):
+        if value is None:
+            check(self._lib.olap_sharded_store_set_value(self._h, int(index), 0.0, 1))
+        else:
+            check(self._lib.olap_sharded_store_set_value(self._h, int(index), float(value), 0))
+
+    def fill(self, value):
+        check(self._lib.olap_sharded_store_fill(self._h, float(value)))
+
+    @property
+    def total(self):
+        t = C.c_double()
+        check(self._lib.olap_sharded_store_total(self._h, C.byref(t)))
+        return t.value
+
+    def clone(self):
+        h = C.c_void_p()
+        check(self._lib.olap_sharded_store_clone(self._h, C.byref(h)))
+        return self._wrap(h)
+
+    def gather(self):
+        h = C.c_void_p()
+        check(self._lib.olap_sharded_store_gather(self._h, C.byref(h)))
+        return HipStore(0, _handle=h)
+
+    @classmethod
+    def scatter(cls, comm, whole, lens):
+        ol = _u32(lens)
+        h = C.c_void_p()
+        check(capi.lib().olap_sharded_store_scatter(C.byref(h), comm._h, whole._h, len(ol), ol.ctypes.data_as(capi._pu32)))
+        return cls(comm, None, whole.type, float("nan") if whole.default_is_nan else 0.0, _handle=h)
+
+    # ---- bulk operations (names follow in-memory.js)
+    def drill_up(self, new_len, maps, method="sum"):
+        """-> ShardedStore (dimension 0 untouched) or HipStore (dimension 0 rolled up: one collective)."""
+        nl = _u32(new_len)
+        keep, arr = _tables(maps, np.uint32, C.c_uint32)
+        hs, hw = C.c_void_p(), C.c_void_p()
+        check(self._lib.olap_sharded_store_drillup(self._h, C.byref(hs), C.byref(hw), nl.ctypes.data_as(capi._pu32), arr, _method_code(method)))
+        return self._wrap(hs) if hs.value else HipStore(0, _handle=hw)
+
+    def dice(self, new_len, sel):
+        nl = _u32(new_len)
+        keep, arr = _tables(sel, np.int32, C.c_int32)
+        h = C.c_void_p()
+        check(self._lib.olap_sharded_store_dice(self._h, C.byref(h), nl.ctypes.data_as(capi._pu32), arr))
+        return self._wrap(h)
+
+    def drill_down(self, new_len, maps, method="sum", distributions=None):
+        nl = _u32(new_len)
+        keep, arr = _tables(maps, np.uint32, C.c_uint32)
+        if distributions is not None:
+            d = np.ascontiguousarray(np.asarray(distributions, dtype=np.float64))
+            dp, dn = d.ctypes.data_as(capi._pdbl), d.size
+        else:
+            dp, dn = None, 0
+        h = C.c_void_p()
+        check(self._lib.olap_sharded_store_drilldown(self._h, C.byref(h), nl.ctypes.data_as(capi._pu32), arr, _method_code(method), dp, dn))
+        return self._wrap(h)
+
+    def reorder(self, perm):
+        p = np.ascontiguousarray(np.asarray(perm, dtype=np.int32))
+        h = C.c_void_p()
+        check(self._lib.olap_sharded_store_reorder(self._h, C.byref(h), p.ctypes.data_as(capi._pi32)))
+        return self._wrap(h)
+
+    def plan_drillup_dim0(self, row_map, n_groups, method="sum", placement=capi.PLACE_SCATTER, depth=1):
+        """The reusable step bench.py times: drillUp of dimension 0 with `row_map`, other dimensions kept."""
+        lens = self.lens
+        maps = [np.asarray(row_map, dtype=np.uint32)] + [np.arange(l, dtype=np.uint32) for l in lens[1:]]
+        return ShardDrillUp(self.comm, self.dtype, self.default, method, lens, [int(n_groups)] + lens[1:], self.bounds, maps, placement, depth)
+
+    def step_inputs(self):
+        """(values addresses, status addresses) of the local slabs, as ShardDrillUp.step() takes them."""
+        n = self.comm.local_count
+        primary = self.default != self.default and self.dtype in ("int32", "uint32")
+        vals = [self._lib.olap_store_values_ptr(self._lib.olap_sharded_store_shard(self._h, i)) for i in range(n)]
+        stat = [self._lib.olap_store_status_ptr(self._lib.olap_sharded_store_shard(self._h, i)) for i in range(n)] if primary else None
+        return vals, stat
+
+
+class _BorrowedStore(HipStore):
+    def __del__(self):  # the slab belongs to its ShardedStore
+        self._h = None
 
 
 class _HipDrillUp:
@@ -43,7 +413,7 @@ class _HipDrillUp:
 
 
 class HipEngine:
-    """Cell arithmetic on the current HIP device; torch tensors are the device-memory plumbing."""
+    """torch tensors as device-memory plumbing for raw-pointer plans (bench.py, tools/)."""
 
     name = "hip"
 
@@ -74,259 +444,5 @@ class HipEngine:
         return _HipDrillUp(self, Plan.drilldown(dtype, default, method, old_len, new_len, maps))
 
     def fill_seeded(self, values, status, n, first_cell, dtype, seed, frac):
-        capi.check(capi.lib().olap_fill_seeded(values.data_ptr(), status.data_ptr(), int(n), int(first_cell),
-                                               capi.DTYPES[dtype], int(seed), float(frac), self.stream()))
-
-    def average_finish(self, values, counts, status, dtype, default):
-        kind = capi.DEFAULT_NAN if default != default else capi.DEFAULT_ZERO
-        capi.check(capi.lib().olap_average_finish(values.data_ptr(), counts.data_ptr(),
-                                                  status.data_ptr() if status is not None else None, values.numel(),
-                                                  capi.DTYPES[dtype], kind, self.stream()))
-
-
-class ShardedStore:
-    """One measure of a cube whose dimension 0 is split across the ranks of a process group."""
-
-    def __init__(self, lens, dtype="float32", default=0.0, rank=0, world=1, engine=None, group=None, bounds=None):
-        if engine is None:
-            raise ValueError("an engine is required (HipEngine on a GPU box)")
-        self.lens = [int(x) for x in lens]
-        self.dtype, self.default = dtype, default
-        self.rank, self.world, self.group = int(rank), int(world), group
-        self.engine = engine
-        # `bounds`: an explicit (possibly uneven) row partition, e.g. what a dice of dimension 0 leaves
-        self.bounds = partition_rows(self.lens[0], self.world) if bounds is None else [int(b) for b in bounds]
-        if len(self.bounds) != self.world + 1 or self.bounds[0] != 0 or self.bounds[-1] != self.lens[0]:
-            raise ValueError("bounds must list world+1 ascending row offsets from 0 to the extent of dimension 0")
-        self.row_lo, self.row_hi = self.bounds[self.rank], self.bounds[self.rank + 1]
-        self.inner0 = int(np.prod(self.lens[1:])) if len(self.lens) > 1 else 1
-        self.local_cells = (self.row_hi - self.row_lo) * self.inner0
-        self.values = engine.empty(self.local_cells, dtype)
-        self.status = engine.empty(self.local_cells, "int32")
-
-    @property
-    def local_lens(self):
-        return [self.row_hi - self.row_lo] + self.lens[1:]
-
-    def fill_seeded(self, seed=20240807, frac=1.0):
-        """SURVEY §8(d) synthetic measure; each rank generates its own slab of the global stream."""
-        self.engine.fill_seeded(self.values, self.status, self.local_cells, self.row_lo * self.inner0, self.dtype,
-                                seed, frac)
-        return self
-
-    def drillup_other_axis(self, axis, axis_map, n_groups, method="sum"):
-        """drillUp on a non-sharded axis: per shard, no communication; the partition is kept."""
-        if axis < 1:
-            raise ValueError("use plan_drillup_dim0 for the sharded axis")
-        old_len = self.local_lens
-        new_len = list(old_len)
-        new_len[axis] = int(n_groups)
-        maps = [np.arange(l, dtype=np.uint32) for l in old_len]
-        maps[axis] = np.asarray(axis_map, dtype=np.uint32)
-        out = ShardedStore([self.lens[0]] + new_len[1:], self.dtype, self.default, self.rank, self.world, self.engine,
-                           self.group)
-        op = self.engine.make_drillup(self.dtype, self.default, method, old_len, new_len, maps)
-        op.run(self.values, None, out.values, out.status)
-        out._keepalive = op
-        return out
-
-    def _local(self, op, new_tail, bounds=None, new_rows=None):
-        """Runs a per-shard plan (no communication) into a new store with the same partition."""
-        rows = self.lens[0] if new_rows is None else new_rows
-        out = ShardedStore([rows] + list(new_tail), self.dtype, self.default, self.rank, self.world, self.engine, self.group,
-                           self.bounds if bounds is None else bounds)
-        op.run(self.values, None, out.values, out.status)
-        out._keepalive = op
-        return out
-
-    def dice_other_axes(self, selections):
-        """dice on non-sharded dimensions (in-memory.js:213-263): selections[d] lists the OLD item index
-        of every new item of dimension d (-1: unknown item), None keeps a dimension; selections[0]
-        must be None.  Per shard, no communication, partition kept."""
-        if selections[0] is not None:
-            raise ValueError("dimension 0 is the sharded axis: use dice_dim0")
-        old_len = self.local_lens
-        sel = [np.arange(l, dtype=np.int32) if s is None else np.asarray(s, dtype=np.int32) for l, s in zip(old_len, selections)]
-        new_len = [len(x) for x in sel]
-        return self._local(self.engine.make_dice(self.dtype, self.default, old_len, new_len, sel), new_len[1:])
-
-    def drilldown_other_axis(self, axis, child_to_parent, method="sum"):
-        """drillDown of a non-sharded dimension (in-memory.js:336-430): child_to_parent[new item] = old
-        item.  Per shard, no communication, partition kept."""
-        if axis < 1:
-            raise ValueError("refining the sharded axis changes the partition: not provided")
-        old_len = self.local_lens
-        child = np.asarray(child_to_parent, dtype=np.uint32)
-        new_len = list(old_len)
-        new_len[axis] = len(child)
-        maps = [np.arange(l, dtype=np.uint32) for l in old_len]
-        maps[axis] = child
-        return self._local(self.engine.make_drilldown(self.dtype, self.default, method, old_len, new_len, maps), new_len[1:])
-
-    def dice_dim0(self, rows):
-        """dice of the sharded dimension by an ASCENDING list of global rows: every rank keeps those of
-        its own rows that were selected — no data moves, the partition becomes uneven.  (A selection
-        that reorders rows across ranks would need an all-to-all; the reference's dice keeps item
-        order unless asked otherwise, src/cube.js:821-857.)"""
-        rows = np.asarray(rows, dtype=np.int64)
-        if rows.size and (np.any(np.diff(rows) <= 0) or rows[0] < 0 or rows[-1] >= self.lens[0]):
-            raise ValueError("dice_dim0 takes strictly ascending row indices inside dimension 0")
-        bounds = [int(np.searchsorted(rows, b)) for b in self.bounds]
-        mine = rows[bounds[self.rank]:bounds[self.rank + 1]] - self.row_lo
-        old_len = self.local_lens
-        sel = [mine.astype(np.int32)] + [np.arange(l, dtype=np.int32) for l in old_len[1:]]
-        new_len = [len(mine)] + old_len[1:]
-        return self._local(self.engine.make_dice(self.dtype, self.default, old_len, new_len, sel), self.lens[1:], bounds, len(rows))
-
-    def plan_drillup_dim0(self, row_map, n_groups, method="sum", always_collective=False):
-        """Prepares drillUp of the sharded axis: row_map[global row] -> group (< n_groups)."""
-        return Dim0DrillUp(self, row_map, n_groups, method, always_collective)
-
-
-class Dim0DrillUp:
-    """Reusable step: local partial + one collective.  `step()` is what bench.py times at N > 1."""
-
-    def __init__(self, store, row_map, n_groups, method="sum", always_collective=False):
-        import torch.distributed as dist
-
-        self.dist = dist
-        self.s = s = store
-        self.method = method
-        # always_collective: run the collective even in a one-rank group (lets a single-GPU box
-        # exercise the RCCL code path; with one rank every collective is the identity)
-        self.collective = store.world > 1 or always_collective
-        row_map = np.asarray(row_map, dtype=np.uint32)
-        if row_map.size != s.lens[0]:
-            raise ValueError("row_map must have one entry per row of dimension 0")
-        n_groups = int(n_groups)
-        old_len = s.local_lens
-        new_len = [n_groups] + s.lens[1:]
-        maps = [row_map[s.row_lo:s.row_hi]] + [np.arange(l, dtype=np.uint32) for l in s.lens[1:]]
-        eng = s.engine
-        w = s.world
-        self.n_out = n_groups * s.inner0
-        self.additive = method in ("sum", "average")
-        local_method = capi.PARTIAL_AVERAGE if (method == "average" and self.collective) else method
-        self.local = eng.make_drillup(s.dtype, s.default, local_method, old_len, new_len, maps)
-        self.partial = eng.empty(self.n_out, s.dtype)
-        # `sum` over a zero default: the mask is a function of the value (set <=> value != 0), so the
-        # path neither writes nor ships it.  `average` ships contribution counts in its place.
-        zero_default = not (s.default != s.default)
-        self.partial_status = None if (method == "sum" and zero_default) else eng.empty(self.n_out, "int32")
-        self.scatter = self.additive and self.collective and self.n_out % w == 0
-        self.staged = self.collective and dist.get_backend(s.group) == "gloo" and getattr(self.partial, "is_cuda", False)
-        if not self.collective:
-            self.result, self.result_status = self.partial, self.partial_status
-        elif self.additive:
-            n_res = self.n_out // w if self.scatter else self.n_out
-            self.result = eng.empty(n_res, s.dtype)
-            self.result_status = None if self.partial_status is None else eng.empty(n_res, "int32")
-            self.result_counts = eng.empty(n_res, "int32") if method == "average" else None
-        else:
-            self.gathered = eng.empty(self.n_out * w, s.dtype)
-            self.gathered_status = eng.empty(self.n_out * w, "int32")
-            self.result = eng.empty(self.n_out, s.dtype)
-            self.result_status = eng.empty(self.n_out, "int32")
-            self.combine = eng.make_drillup(s.dtype, s.default, method, [w, self.n_out], [1, self.n_out],
-                                            [np.zeros(w, np.uint32), np.arange(self.n_out, dtype=np.uint32)])
-
-    @property
-    def result_range(self):
-        """Flat range of the global output held in `result` on this rank."""
-        if self.scatter:
-            per = self.n_out // self.s.world
-            return self.s.rank * per, (self.s.rank + 1) * per
-        return 0, self.n_out
-
-    def _sum_across_ranks(self, src, dst):
-        """dst <- element-wise sum of every rank's src (scattered when the output divides)."""
-        s, dist = self.s, self.dist
-        a = src.cpu() if self.staged else src
-        b = a.new_empty(dst.numel()) if self.staged else dst
-        if self.scatter and dist.get_backend(s.group) != "gloo":
-            dist.reduce_scatter_tensor(b, a, op=dist.ReduceOp.SUM, group=s.group)
-        elif self.scatter:  # gloo has no reduce_scatter: all-reduce, keep this rank's slice
-            full = a.clone()
-            dist.all_reduce(full, op=dist.ReduceOp.SUM, group=s.group)
-            lo, hi = self.result_range
-            b.copy_(full[lo:hi])
-        else:
-            b.copy_(a)
-            dist.all_reduce(b, op=dist.ReduceOp.SUM, group=s.group)
-        if self.staged:
-            dst.copy_(b)
-
-    # ---- pipelined form for streams of independent queries (bench.py at N > 1) ----------------
-    def step_pipelined(self):
-        """Same work as step() for `sum`, but the collective is asynchronous and ping-pongs between two
-        (partial, result) buffer pairs: the reduce-scatter of query i runs on RCCL's stream while the
-        local reduction of query i+1 runs on the compute stream.  Returns the result tensor of THIS
-        query; it is complete after its work handle (or flush()) has been waited for."""
-        s, dist = self.s, self.dist
-        if not self.collective or self.method != "sum" or self.partial_status is not None or self.staged:
-            return self.step()
-        if not hasattr(self, "_pipe"):
-            eng = s.engine
-            self._pipe = {"i": 0, "partial": [self.partial, eng.empty(self.n_out, s.dtype)],
-                          "result": [self.result, eng.empty(self.result.numel(), s.dtype)], "work": [None, None]}
-        p = self._pipe
-        k = p["i"] & 1
-        p["i"] += 1
-        if p["work"][k] is not None:
-            p["work"][k].wait()  # the collective that last read partial[k] / wrote result[k]
-        self.local.run(s.values, None, p["partial"][k], None)
-        p["work"][k] = self._sum_across_ranks_async(p["partial"][k], p["result"][k])
-        return p["result"][k]
-
-    def _sum_across_ranks_async(self, src, dst):
-        """Asynchronous form of _sum_across_ranks; returns an object with wait()."""
-        s, dist = self.s, self.dist
-        if self.scatter and dist.get_backend(s.group) != "gloo":
-            return dist.reduce_scatter_tensor(dst, src, op=dist.ReduceOp.SUM, group=s.group, async_op=True)
-        if self.scatter:  # gloo rehearsal: all-reduce a copy, keep this rank's slice when it lands
-            full = src.clone()
-            work = dist.all_reduce(full, op=dist.ReduceOp.SUM, group=s.group, async_op=True)
-            lo, hi = self.result_range
-
-            class _Slice:
-                def wait(self_inner):
-                    work.wait()
-                    dst.copy_(full[lo:hi])
-
-            return _Slice()
-        dst.copy_(src)
-        return dist.all_reduce(dst, op=dist.ReduceOp.SUM, group=s.group, async_op=True)
-
-    def flush(self):
-        """Waits (on the current stream) for every outstanding pipelined collective."""
-        if hasattr(self, "_pipe"):
-            for k in (0, 1):
-                if self._pipe["work"][k] is not None:
-                    self._pipe["work"][k].wait()
-                    self._pipe["work"][k] = None
-
-    def step(self):
-        s, dist = self.s, self.dist
-        self.local.run(s.values, None, self.partial, self.partial_status)
-        if not self.collective:
-            return self.result
-        if self.additive:
-            self._sum_across_ranks(self.partial, self.result)
-            if self.method == "average":
-                self._sum_across_ranks(self.partial_status, self.result_counts)
-                s.engine.average_finish(self.result, self.result_counts, self.result_status, s.dtype, s.default)
-            elif self.partial_status is not None:  # sum over a NaN default: set where any rank was set
-                self._sum_across_ranks(self.partial_status, self.result_status)
-            return self.result
-        if self.staged:
-            g = self.partial.cpu().new_empty(self.n_out * s.world)
-            g_st = self.partial_status.cpu().new_empty(self.n_out * s.world)
-            dist.all_gather_into_tensor(g, self.partial.cpu(), group=s.group)
-            dist.all_gather_into_tensor(g_st, self.partial_status.cpu(), group=s.group)
-            self.gathered.copy_(g)
-            self.gathered_status.copy_(g_st)
-        else:
-            dist.all_gather_into_tensor(self.gathered, self.partial, group=s.group)
-            dist.all_gather_into_tensor(self.gathered_status, self.partial_status, group=s.group)
-        self.combine.run(self.gathered, self.gathered_status, self.result, self.result_status)
-        return self.result
+        capi.check(capi.lib().olap_fill_seeded(values.data_ptr(), status.data_ptr() if status is not None else None, int(n),
+                                               int(first_cell), capi.DTYPES[dtype], int(seed), float(frac), self.stream()))

@@ -24,6 +24,24 @@ def build(force=False):
     return _LIB_PATH
 
 
+def build_flat(force=False):
+    """oracle/flat_baseline.c -> libflat_baseline.so (bench.py's dense CPU baselines)."""
+    path = os.path.join(_HERE, "libflat_baseline.so")
+    src = os.path.join(_HERE, "flat_baseline.c")
+    if force or not os.path.exists(path) or os.path.getmtime(src) > os.path.getmtime(path):
+        subprocess.check_call(["make", "-s", "-C", _HERE, "-B", "libflat_baseline.so"])
+    return path
+
+
+def flat_baseline():
+    """ctypes view of flat_baseline.c: (lib, max threads)."""
+    L = C.CDLL(build_flat())
+    L.flat_drillup_sum.restype = C.c_double
+    L.flat_drillup_sum.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_int]
+    L.flat_max_threads.restype = C.c_int
+    return L, int(L.flat_max_threads())
+
+
 _lib = None
 
 

@@ -62,3 +62,38 @@ def config_cube(n_cells, seed=20240807, frac=1.0):
     vals = (0.5 + u[0::2]).astype(np.float32)
     keep = u[1::2] < frac
     return np.where(keep, vals, np.float32(0)), keep
+
+
+# ---- what a TYPED store holds for an oracle (float64 Map) result -------------------------------
+# The reference keeps float64 numbers until serialize() (in-memory.js:77-92); this implementation
+# stores cells in the declared type after every operation, so an expectation is
+# the oracle's result after TypedArray conversion, and a result that converts to the default is unset.
+# tests/test_typed_storage_differences.py pins where that differs from the reference's getData().
+def is_default_typed(vals, type_name, default_is_nan):
+    if type_name in ("float32", "float64"):
+        return np.isnan(vals) if default_is_nan else (vals == 0)
+    return np.zeros(vals.shape, dtype=bool) if default_is_nan else (vals == 0)
+
+
+def expected_typed(ostore):
+    """Oracle store -> (typed values with the default in unset cells, Int32 status mask)."""
+    from oracle.oracle import to_typed
+
+    vals, pres = ostore.dense()
+    t = to_typed(vals, ostore.type)
+    nan = ostore.default_is_nan
+    pres = pres & ~is_default_typed(t, ostore.type, nan)
+    if ostore.type in ("float32", "float64"):
+        dflt = np.nan if nan else 0.0
+    else:
+        dflt = 0
+    t = np.where(pres, t, np.asarray(dflt, dtype=t.dtype))
+    return t, np.where(pres, 2, 0).astype(np.int32)
+
+
+def same_typed(a, b):
+    if a.dtype.kind == "f":
+        u = {4: np.uint32, 8: np.uint64}[a.dtype.itemsize]
+        nan = np.isnan(a) & np.isnan(b)
+        return bool(np.all(nan | (a.view(u) == b.view(u))))
+    return bool(np.array_equal(a, b))

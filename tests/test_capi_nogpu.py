@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
     L = capi.lib()
     for name in header_functions():
         assert hasattr(L, name), name
-    assert L.olap_abi_version() == 1
+    assert L.olap_abi_version() == 2
 
 
 def test_names_and_sizes():

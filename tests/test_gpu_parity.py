@@ -12,7 +12,7 @@ import numpy as np
 import pytest
 
 from conftest import load_package
-from golden_util import GOLDEN, config_cube, dec_num, dec_store, default_of, load_cases
+from golden_util import GOLDEN, config_cube, dec_num, dec_store, default_of, expected_typed, is_default_typed, load_cases, same_typed
 from oracle.oracle import OracleStore, to_typed
 
 pytestmark = pytest.mark.gpu
@@ -21,34 +21,6 @@ pkg = load_package()
 KAT = load_cases("store_kat.json")
 RND = load_cases("store_random.json")
 CFG = load_cases("configs.json")
-
-
-def is_default_typed(vals, type_name, default_is_nan):
-    if type_name in ("float32", "float64"):
-        return np.isnan(vals) if default_is_nan else (vals == 0)
-    return np.zeros(vals.shape, dtype=bool) if default_is_nan else (vals == 0)
-
-
-def expected_typed(ostore):
-    """Oracle store -> (typed values with the default in unset cells, Int32 status mask)."""
-    vals, pres = ostore.dense()
-    t = to_typed(vals, ostore.type)
-    nan = ostore.default_is_nan
-    pres = pres & ~is_default_typed(t, ostore.type, nan)
-    if ostore.type in ("float32", "float64"):
-        dflt = np.nan if nan else 0.0
-    else:
-        dflt = 0
-    t = np.where(pres, t, np.asarray(dflt, dtype=t.dtype))
-    return t, np.where(pres, 2, 0).astype(np.int32)
-
-
-def same_typed(a, b):
-    if a.dtype.kind == "f":
-        u = {4: np.uint32, 8: np.uint64}[a.dtype.itemsize]
-        nan = np.isnan(a) & np.isnan(b)
-        return bool(np.all(nan | (a.view(u) == b.view(u))))
-    return bool(np.array_equal(a, b))
 
 
 def dense_input(case, key="in", default_key="default"):

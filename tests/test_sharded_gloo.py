@@ -1,8 +1,11 @@
-"""world_size-2 rehearsal of the dim0-sharded drillUp (olap-in-memory_amd/sharded.py) over gloo.
+"""Multi-rank rehearsal of the dim0-sharded path (include/olap_hip.h "Multi-GPU",
+olap-in-memory_amd/csrc/olap_sharded.hip) over gloo, world sizes 2 and 3.
 
-CPU run: the oracle stands in for the local kernels (injected engine), so what is under test is
-the row partition, the row sub-maps, the collective choice and the rank-ordered combine.
-GPU run (-m gpu): the same worker with the HIP engine, two ranks sharing the one GPU of the box."""
+CPU run: partition, row sub-maps and the recipe come from libolapgpu's host-only entry points, the
+oracle plays the local kernels: what is under test is the MATHS of "local partial + one collective
++ finish" for every store kind (NaN / 0 default, float / integer cells, ranks without rows).
+GPU runs (-m gpu): the product path itself — ranks sharing the one GPU over gloo, one process with
+the direct transport, and RCCL on a one-rank communicator."""
 import json
 import os
 import subprocess
@@ -11,8 +14,9 @@ import sys
 import numpy as np
 import pytest
 
-from golden_util import config_cube
+from golden_util import expected_typed
 from oracle.oracle import OracleStore
+from sharded_cases import CASES, case_data, methods_of
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 
@@ -25,89 +29,135 @@ def run_workers(engine, tmp_path, world=2):
         e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
         procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "_sharded_worker.py"), engine, out], env=e,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
-    logs = [p.communicate(timeout=300)[0] for p in procs]
+    logs = [p.communicate(timeout=600)[0] for p in procs]
     for p, log in zip(procs, logs):
         assert p.returncode == 0, log
     return [json.load(open("%s.%d" % (out, r))) for r in range(world)]
 
 
-def check(results):
-    lens = [7, 6, 10]
-    row_map = np.array([0, 1, 0, 2, 1, 0, 2], np.uint32)
-    maps = [row_map, np.arange(6, dtype=np.uint32), np.arange(10, dtype=np.uint32)]
-    for frac in (1.0, 0.4):
-        v, _ = config_cube(420, 77, frac)
-        o = OracleStore(420, "float32", 0.0)
-        o.set_data(v.astype(np.float64))
-        for method in ("sum", "average", "highest", "lowest", "first", "last", "product"):
-            ev, _ = o.drill_up(lens, [3, 6, 10], maps, method).typed()
-            got = np.full(180, np.nan)
-            for res in results:
-                r = res["%s_%s" % (method, frac)]
-                got[r["range"][0]:r["range"][1]] = r["values"]
-            if method in ("sum", "average", "product"):  # float32 partials combined across ranks: 1e-5 relative (north star)
-                assert np.allclose(got, ev, rtol=1e-5, atol=0), method
+def expected_dim0(case, method):
+    lens = case["lens"]
+    maps = [np.asarray(case["row_map"], np.uint32)] + [np.arange(l, dtype=np.uint32) for l in lens[1:]]
+    o = OracleStore(int(np.prod(lens)), case["dtype"], case["default"])
+    o.set_data(case_data(case))
+    return expected_typed(o.drill_up(lens, [case["groups"]] + lens[1:], maps, method))
+
+
+def assemble(results, key, n):
+    """flat result cells from every rank's (first, values) piece; whole pieces must agree"""
+    vals, stat = np.full(n, np.nan), np.full(n, -1, np.int64)
+    for res in results:
+        r = res[key]
+        v, s = np.asarray(r["values"], np.float64), np.asarray(r["status"], np.int64)
+        f = r["first"]
+        vals[f:f + v.size] = v
+        stat[f:f + s.size] = s
+    return vals, stat
+
+
+def check_dim0(results):
+    for name, case in CASES.items():
+        n_out = case["groups"] * int(np.prod(case["lens"][1:]))
+        for method in methods_of(case):
+            ev, es = expected_dim0(case, method)
+            gv, gs = assemble(results, "%s/%s" % (name, method), n_out)
+            what = "%s %s" % (name, method)
+            assert np.array_equal(gs, es), what + ": status mask (must be 0 / 0x2 everywhere, OR-ed across ranks)"
+            assert set(np.unique(gs)) <= {0, 2}, what
+            e64 = ev.astype(np.float64)
+            if method in ("sum", "average", "product") and case["dtype"].startswith("float"):
+                # partials are rounded to the cell type per rank and combined in another order: 1e-5 relative (north star)
+                assert np.allclose(gv, e64, rtol=1e-5, atol=0, equal_nan=True), what
             else:
-                assert np.array_equal(got.astype(np.float32), ev), method
-        ev, _ = o.drill_up(lens, [3, 6, 10], maps, "sum").typed()
-        got = np.full(180, np.nan)
-        for res in results:
-            r = res["pipelined_%s" % frac]
-            got[r["range"][0]:r["range"][1]] = r["values"]
-        assert np.allclose(got, ev, rtol=1e-5, atol=0), "pipelined sum"
-        e2, _ = o.drill_up(lens, [7, 6, 2], [np.arange(7, dtype=np.uint32), np.arange(6, dtype=np.uint32),
-                                             (np.arange(10) % 2).astype(np.uint32)], "sum").typed()
-        got = np.full(84, np.nan)
-        for res in results:
-            r = res["axis2_%s" % frac]
-            got[r["range"][0]:r["range"][1]] = r["values"]
-        assert np.array_equal(got.astype(np.float32), e2)
-
-        def gathered(key, n):
-            out = np.full(n, np.nan)
-            for res in results:
-                r = res["%s_%s" % (key, frac)]
-                out[r["range"][0]:r["range"][1]] = r["values"]
-            return out.astype(np.float32)
-
-        ident = lambda l: np.arange(l, dtype=np.int32)  # noqa: E731
-        e3, _ = o.dice(lens, [7, 4, 3], [ident(7), np.array([4, 0, -1, 2], np.int32), np.array([9, 8, 1], np.int32)]).typed()
-        assert np.array_equal(gathered("dice12", 84), e3)
-        e4, _ = o.drill_down(lens, [7, 6, 30], [np.arange(7, dtype=np.uint32), np.arange(6, dtype=np.uint32),
-                                                  np.repeat(np.arange(10), 3).astype(np.uint32)], "sum").typed()
-        assert np.array_equal(gathered("down2", 1260), e4)
-        picked = o.dice(lens, [4, 6, 10], [np.array([1, 2, 4, 6], np.int32), ident(6), ident(10)])
-        e5, _ = picked.typed()
-        assert np.array_equal(gathered("rows", 240), e5)
-        e6, _ = picked.drill_up([4, 6, 10], [4, 1, 10], [np.arange(4, dtype=np.uint32), np.zeros(6, np.uint32), np.arange(10, dtype=np.uint32)], "sum").typed()
-        assert np.array_equal(gathered("rows_then_sum", 40), e6)
+                assert np.array_equal(gv, e64, equal_nan=True), what
+    # the round-1 failure, spelled out
+    gv, gs = assemble(results, "f32_nan_disjoint/sum", 3)
+    assert gv.tolist() == [1.0, 7.0, 5.0] and gs.tolist() == [2, 2, 2]
 
 
-def test_partition_rows():
+def test_partition_and_recipe_host_only():
+    """olap_shard_bounds / olap_shard_dice_bounds / olap_shard_recipe_get need no device."""
     from conftest import load_package
     load_package()
-    from olap_in_memory_amd.sharded import partition_rows
+    from olap_in_memory_amd import capi
+    from olap_in_memory_amd.sharded import dice_bounds, partition_rows, recipe
     assert partition_rows(10, 8) == [0, 2, 4, 5, 6, 7, 8, 9, 10]
     assert partition_rows(320, 8) == list(range(0, 321, 40))
     assert partition_rows(3, 4) == [0, 1, 2, 3, 3]
+    assert dice_bounds([0, 4, 7], [1, 2, 4, 6]) == [0, 2, 4]
+    with pytest.raises(capi.OlapError, match="sharded:"):
+        dice_bounds([0, 4, 7], [2, 1])
+    nan = float("nan")
+    r = recipe("float32", 0.0, "sum")
+    assert (r["n_payloads"], r["payload_op"][0], r["finish"], r["zero_unset"]) == (1, capi.XCHG_SUM, capi.FINISH_NONE, False)
+    r = recipe("float32", nan, "sum")  # NaN never enters an additive collective; masks are OR-ed, not added
+    assert (r["n_payloads"], r["payload_op"], r["finish"], r["zero_unset"]) == (2, [capi.XCHG_SUM, capi.XCHG_MAX], capi.FINISH_RESTORE, True)
+    r = recipe("int32", nan, "sum")
+    assert (r["n_payloads"], r["payload_op"][1], r["zero_unset"]) == (2, capi.XCHG_MAX, False)
+    r = recipe("float32", nan, "average")
+    assert (r["local_method"], r["payload_op"], r["finish"], r["zero_unset"]) == (capi.PARTIAL_AVERAGE, [capi.XCHG_SUM, capi.XCHG_SUM], capi.FINISH_AVERAGE, True)
+    for m in ("highest", "lowest", "first", "last", "product"):
+        assert recipe("float32", nan, m)["n_payloads"] == 1 and recipe("int32", nan, m)["n_payloads"] == 2
+        assert recipe("float32", 0.0, m)["finish"] == capi.FINISH_COMBINE
+    with pytest.raises(capi.OlapError, match="Unsupported aggregation method"):
+        recipe("float32", 0.0, 7)
 
 
 @pytest.mark.parametrize("world", [2, 3])
 def test_sharded_drillup_gloo_cpu(tmp_path, world):
-    """7 rows over 2 ranks (4 + 3) and over 3 ranks (3 + 2 + 2): ragged partitions."""
-    check(run_workers("oracle", tmp_path, world))
+    """7 rows over 2 ranks (4 + 3) and 3 ranks (3 + 2 + 2); 2 rows over 3 ranks (one rank has none)."""
+    results = run_workers("oracle", tmp_path, world)
+    check_dim0(results)
+    from olap_in_memory_amd.sharded import partition_rows
+    assert results[0]["dice_bounds"] == [int(np.searchsorted([1, 2, 4, 6], b)) for b in partition_rows(7, world)]
+
+
+def gathered(results, key, n):
+    vals, stat = np.full(n, np.nan), np.full(n, -1, np.int64)
+    for res in results:
+        r = res[key]
+        vals[r["range"][0]:r["range"][1]] = r["values"]
+        stat[r["range"][0]:r["range"][1]] = r["status"]
+    return vals, stat
 
 
 @pytest.mark.gpu
-def test_sharded_drillup_gloo_gpu(tmp_path):
-    check(run_workers("hip", tmp_path))
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_store_shared_gpu(tmp_path, world):
+    """The product's sharded store and drillUp op, `world` processes sharing the one GPU, gloo carrying the payloads."""
+    results = run_workers("hip", tmp_path, world)
+    check_dim0(results)
+    case = CASES["f32_zero"]
+    for method in ("sum", "average"):  # the whole-result placement agrees with the scattered one
+        ev, _ = expected_dim0(case, method)
+        assert np.allclose(results[0]["f32_zero/%s/all" % method]["values"], ev.astype(np.float64), rtol=1e-5, atol=0)
+    lens = case["lens"]
+    o = OracleStore(420, "float32", 0.0)
+    o.set_data(case_data(case))
+    ident = lambda l: np.arange(l, dtype=np.uint32)  # noqa: E731
+    sel = lambda l: np.arange(l, dtype=np.int32)  # noqa: E731
+
+    def same(key, store):
+        ev, es = expected_typed(store)
+        gv, gs = gathered(results, key, ev.size)
+        assert np.array_equal(gv, ev.astype(np.float64), equal_nan=True) and np.array_equal(gs, es), key
+
+    same("axis2", o.drill_up(lens, [7, 6, 2], [ident(7), ident(6), (np.arange(10) % 2).astype(np.uint32)], "sum"))
+    same("dice12", o.dice(lens, [7, 4, 3], [sel(7), np.array([4, 0, -1, 2], np.int32), np.array([9, 8, 1], np.int32)]))
+    same("down2", o.drill_down(lens, [7, 6, 30], [ident(7), ident(6), np.repeat(np.arange(10), 3).astype(np.uint32)], "sum"))
+    same("swap12", o.reorder(lens, [0, 2, 1]))
+    picked = o.dice(lens, [4, 6, 10], [np.array([1, 2, 4, 6], np.int32), sel(6), sel(10)])
+    same("rows", picked)
+    same("rows_then_sum", picked.drill_up([4, 6, 10], [4, 1, 10], [ident(4), np.zeros(6, np.uint32), ident(10)], "sum"))
+    from olap_in_memory_amd.sharded import partition_rows
+    assert results[0]["rows"]["bounds"] == [int(np.searchsorted([1, 2, 4, 6], b)) for b in partition_rows(7, world)]
 
 
 @pytest.mark.gpu
-def test_rccl_code_path_single_rank():
-    """The exact torch.distributed / RCCL calls bench.py makes at N > 1 (reduce_scatter_tensor sync and
-    async, all_reduce, all_gather_into_tensor), on a one-rank nccl group: catches API misuse that the
-    gloo rehearsal cannot (device tensors, stream semantics) before the driver's 8-GPU run."""
-    r = subprocess.run([sys.executable, os.path.join(HERE, "_rccl_single_rank.py")], stdout=subprocess.PIPE,
-                       stderr=subprocess.STDOUT, text=True, timeout=600)
-    assert r.returncode == 0 and "rccl single-rank ok" in r.stdout, r.stdout[-4000:]
+def test_sharded_single_process():
+    """One process: the direct transport (ranks sharing cuda:0, e.g. devices [0, 0, 0]) through
+    olap_shard_drillup_step with its event ordering, and RCCL itself on one-rank communicators made by
+    olap_comm_init_all and olap_comm_init_rank."""
+    r = subprocess.run([sys.executable, os.path.join(HERE, "_sharded_single_process.py")], stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, text=True, timeout=900)
+    assert r.returncode == 0 and "sharded single-process ok" in r.stdout, r.stdout[-6000:]
