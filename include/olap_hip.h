@@ -201,9 +201,9 @@ int olap_eval_formula(const int32_t *code, int n_code, const double *consts, int
  * HIP binding of their own (blocking). */
 int olap_memcpy_to_host(void *host, const void *device, uint64_t bytes);
 int olap_memcpy_to_device(void *device, const void *host, uint64_t bytes);
-/* Diagnostic: a plain grid-stride 16-byte streaming read of `bytes` bytes that keeps one float sum
- * per workgroup (the achievable read ceiling of the box, measured in the same run as
- * the kernels it is compared with).  `scratch` needs 4 * 2048 bytes.  Asynchronous on `stream`. */
+/* Diagnostic: a plain 16-byte streaming read of `bytes` bytes that computes (and drops) one float sum per
+ * lane (the achievable read ceiling of the box, measured in the same run as the kernels
+ * it is compared with).  `scratch` needs 4 * 2048 bytes.  Asynchronous on `stream`. */
 int olap_diag_read_ceiling(const void *device, uint64_t bytes, void *scratch, void *stream);
 /* `total` getter (in-memory.js:22-28): float64 sum of the set cells, and their count.
  * Synchronises `stream`. */

@@ -1607,24 +1607,16 @@ extern "C" int olap_memcpy_to_device(void *device, const void *host, uint64_t by
   return OLAP_OK;
 }
 
-// the box's achievable read ceiling: the simplest possible streaming read (tools/ceilings.hip's `read nt`)
-__global__ __launch_bounds__(kBlock) void diag_read_kernel(const float4 *__restrict__ src, uint64_t n_vec, float *scratch) {
+// the box's achievable read ceiling: the best plain streaming read of tools/ceilings.hip's sweep — one tile of
+// 2 x 256 sixteen-byte groups per workgroup, both loads in flight, non-temporal (profiles/ceilings_r01.txt)
+__global__ __launch_bounds__(kBlock) void diag_read_kernel(const float *__restrict__ src, uint64_t n_vec, float *scratch) {
+  const uint64_t base = (uint64_t)blockIdx.x * (2 * kBlock) + threadIdx.x;
   float acc = 0.f;
-  const uint64_t stride = (uint64_t)gridDim.x * kBlock;
-  uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
-  for (; i + 3 * stride < n_vec; i += 4 * stride) {
-    const Vec<float, 4> a = load_stream<float, 4>((const float *)(src + i));
-    const Vec<float, 4> b = load_stream<float, 4>((const float *)(src + i + stride));
-    const Vec<float, 4> c = load_stream<float, 4>((const float *)(src + i + 2 * stride));
-    const Vec<float, 4> d = load_stream<float, 4>((const float *)(src + i + 3 * stride));
-    acc += a.v[0] + a.v[1] + a.v[2] + a.v[3] + b.v[0] + b.v[1] + b.v[2] + b.v[3] + c.v[0] + c.v[1] + c.v[2] + c.v[3] + d.v[0] + d.v[1] +
-           d.v[2] + d.v[3];
-  }
-  for (; i < n_vec; i += stride) {
-    const Vec<float, 4> a = load_stream<float, 4>((const float *)(src + i));
-    acc += a.v[0] + a.v[1] + a.v[2] + a.v[3];
-  }
-  if (acc == 123456.789f) scratch[blockIdx.x] = acc;  // keeps the loads alive without a store per lane
+  Vec<float, 4> a{}, b{};
+  if (base < n_vec) a = load_stream<float, 4>(src + base * 4);
+  if (base + kBlock < n_vec) b = load_stream<float, 4>(src + (base + kBlock) * 4);
+  acc = a.v[0] + a.v[1] + a.v[2] + a.v[3] + b.v[0] + b.v[1] + b.v[2] + b.v[3];
+  if (acc == 123456.789f) scratch[blockIdx.x & 2047] = acc;  // keeps the loads alive without a store per lane
 }
 
 extern "C" int olap_diag_read_ceiling(const void *device, uint64_t bytes, void *scratch, void *stream) {
@@ -1632,7 +1624,10 @@ extern "C" int olap_diag_read_ceiling(const void *device, uint64_t bytes, void *
   if (((uintptr_t)device & 15u) != 0) return fail(OLAP_ERR_INVALID_ARGUMENT, "buffer must be 16-byte aligned");
   int rc = require_device();
   if (rc) return rc;
-  hipLaunchKernelGGL(diag_read_kernel, 2048, kBlock, 0, (hipStream_t)stream, (const float4 *)device, bytes / 16, (float *)scratch);
+  const uint64_t n_vec = bytes / 16;
+  const uint64_t grid = (n_vec + 2 * kBlock - 1) / (2 * kBlock);
+  if (grid == 0 || grid > 0x7FFFFFFFull) return fail(OLAP_ERR_INVALID_ARGUMENT, "buffer size out of range for the read diagnostic");
+  hipLaunchKernelGGL(diag_read_kernel, (unsigned)grid, kBlock, 0, (hipStream_t)stream, (const float *)device, n_vec, (float *)scratch);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return hip_fail(e, "diag_read_kernel");
   return OLAP_OK;

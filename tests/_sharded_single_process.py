@@ -45,7 +45,10 @@ def run_steps(comm, what):
         lens, dtype, default = case["lens"], case["dtype"], case["default"]
         o = oracle_store(case)
         s = ShardedStore(comm, lens, dtype, default).set_data_f64(case_data(case))
-        assert np.array_equal(s.get_data_f64(), expected_typed(o)[0].astype(np.float64), equal_nan=True), name
+        want = expected_typed(o)[0].astype(np.float64)
+        if default != default and dtype in ("int32", "uint32"):  # getValue of an unset integer cell under a NaN default: NaN (:118-120)
+            want = np.where(expected_typed(o)[1] == 2, want, np.nan)
+        assert np.array_equal(s.get_data_f64(), want, equal_nan=True), name
         assert np.array_equal(s.get_status(), expected_typed(o)[1]), name
         maps = [np.asarray(case["row_map"], np.uint32)] + [np.arange(l, dtype=np.uint32) for l in lens[1:]]
         new_len = [case["groups"]] + lens[1:]

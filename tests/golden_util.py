@@ -55,6 +55,17 @@ def mulberry32_stream(seed, n):
     return r.astype(np.float64) / 4294967296.0
 
 
+def mulberry32_at(seed, positions):
+    """mulberry32 draws at the given 1-based stream positions (uint64 array), as olap_fill_seeded addresses them."""
+    i = np.asarray(positions, dtype=np.uint64)
+    a = ((np.uint64(seed) + i * np.uint64(0x6D2B79F5)) & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+    with np.errstate(over="ignore"):
+        t = (a ^ (a >> np.uint32(15))) * (np.uint32(1) | a)
+        t = (t + ((t ^ (t >> np.uint32(7))) * (np.uint32(61) | t))) ^ t
+        r = t ^ (t >> np.uint32(14))
+    return r.astype(np.float64) / 4294967296.0
+
+
 def config_cube(n_cells, seed=20240807, frac=1.0):
     """SURVEY §8(d) synthetic cube: values fround(0.5+u1), cell kept iff u2 < frac.
     Returns (float32 values with 0 where unset, bool present)."""

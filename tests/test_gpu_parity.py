@@ -12,7 +12,7 @@ import numpy as np
 import pytest
 
 from conftest import load_package
-from golden_util import GOLDEN, config_cube, dec_num, dec_store, default_of, expected_typed, is_default_typed, load_cases, same_typed
+from golden_util import GOLDEN, config_cube, mulberry32_at, dec_num, dec_store, default_of, expected_typed, is_default_typed, load_cases, same_typed
 from oracle.oracle import OracleStore, to_typed
 
 pytestmark = pytest.mark.gpu
@@ -201,6 +201,122 @@ def test_full_size_properties(shape, axis):
         ref[:, gmap[k], :] += x[:, k, :]
     assert np.array_equal(got, ref.astype(np.float32).ravel())
     assert np.all(out.get_status() == 2)
+    assert abs(out.total - s.total) <= 1e-6 * s.total
+
+
+def _day_to_month():
+    """time(day, 2010-01-01 .. 2019-12-31) -> month index: an independent Gregorian computation (datetime), the map
+    TimeDimension.getGroupIndexFromRootIndexMap('month') yields (src/dimension/time.js:182-197)."""
+    import datetime
+
+    d0 = datetime.date(2010, 1, 1)
+    days = [d0 + datetime.timedelta(days=i) for i in range(3652)]
+    assert days[-1] == datetime.date(2019, 12, 31)
+    return np.array([(d.year - 2010) * 12 + d.month - 1 for d in days], np.uint32)
+
+
+def _numpy_rollup(x, gmap, G, method):
+    """[outer, K, inner] float64 + presence -> the reference's drillUp in ascending-k order (in-memory.js:282-331):
+    only set cells contribute; average divides by the number of contributions (< 65536 here)."""
+    vals, pres = x
+    outer, K, inner = vals.shape
+    acc = np.zeros((outer, G, inner))
+    cnt = np.zeros((outer, G, inner), np.int64)
+    for k in range(K):
+        g = gmap[k]
+        v, p = vals[:, k, :], pres[:, k, :]
+        if method in ("sum", "average"):
+            acc[:, g, :] += np.where(p, v, 0.0)
+        elif method == "first":
+            acc[:, g, :] = np.where(p & (cnt[:, g, :] == 0), v, acc[:, g, :])
+        elif method == "last":
+            acc[:, g, :] = np.where(p, v, acc[:, g, :])
+        cnt[:, g, :] += p
+    if method == "average":
+        acc = np.where(cnt > 0, acc / np.maximum(cnt, 1), 0.0)
+    return acc, cnt > 0
+
+
+def test_config5_as_written():
+    """BASELINE configs[4] at full size: time(day)=3652 x location(city)=100 x sku=274 (1.0006e8 cells), four measures
+    with rules sum / average / first / last; drillUp(time, month) with the REAL calendar map (runs of 28-31 days),
+    then drillUp(location, country) on the result.  Expected values: numpy float64 in ascending-k order, rounded to
+    Float32 after each operation as the typed store does — bit-exact (in-memory.js:282-331)."""
+    lens = [3652, 100, 274]
+    n = int(np.prod(lens))
+    d2m = _day_to_month()
+    assert d2m.max() == 119 and np.bincount(d2m).min() == 28 and np.bincount(d2m).max() == 31
+    c2c = (np.arange(100) // 10).astype(np.uint32)  # 10 cities per country
+    ident = lambda l: np.arange(l, dtype=np.uint32)  # noqa: E731
+    for m, method in enumerate(("sum", "average", "first", "last")):
+        s = pkg.HipStore(n, "float32", 0.0)
+        pkg.capi.check(pkg.lib().olap_fill_seeded(s.values_ptr, None, n, 0, 2, 20240807 + m, 0.9, None))  # 10 % of the cells unset
+        months = s.drill_up(lens, [120, 100, 274], [d2m, ident(100), ident(274)], method)
+        countries = months.drill_up([120, 100, 274], [120, 10, 274], [ident(120), c2c, ident(274)], method)
+        x = s.get_data().astype(np.float64).reshape(1, 3652, 27400)
+        assert 0.89 < np.count_nonzero(x) / n < 0.91
+        ref1, set1 = _numpy_rollup((x, x != 0), d2m, 120, method)
+        ref1 = ref1.astype(np.float32)  # the typed store rounds after every operation
+        assert np.array_equal(months.get_data(), ref1.ravel()), method + " day->month"
+        assert np.array_equal(months.get_status() == 2, (set1 & (ref1 != 0)).ravel()), method
+        y = ref1.astype(np.float64).reshape(120, 100, 274)
+        ref2, set2 = _numpy_rollup((y, y != 0), c2c, 10, method)
+        ref2 = ref2.astype(np.float32)
+        assert np.array_equal(countries.get_data(), ref2.ravel()), method + " city->country"
+        assert np.array_equal(countries.get_status() == 2, (set2 & (ref2 != 0)).ravel()), method
+        del s, months, countries, x, y
+
+
+@pytest.mark.parametrize("type_name,default", [("float32", 0.0), ("float32", float("nan")), ("int32", float("nan"))])
+def test_config5_chain_against_the_oracle(type_name, default):
+    """The same chain (real calendar map over 2010-2011, then city -> country; sum / average / first / last) at a size
+    the oracle covers, against OracleStore."""
+    d2m = _day_to_month()[:730]
+    lens = [730, 20, 9]
+    n = int(np.prod(lens))
+    c2c = (np.arange(20) // 5).astype(np.uint32)
+    ident = lambda l: np.arange(l, dtype=np.uint32)  # noqa: E731
+    rng = np.random.default_rng(5)
+    vals = rng.integers(-20, 21, size=n).astype(np.float64)
+    vals = np.where(rng.random(n) < 0.8, vals, default)
+    for method in ("sum", "average", "first", "last"):
+        o = OracleStore(n, type_name, default)
+        o.set_data(vals)
+        g = pkg.HipStore(n, type_name, default)
+        g.set_data_f64(vals)
+        m1 = [d2m, ident(20), ident(9)]
+        m2 = [ident(24), c2c, ident(9)]
+        og = o.drill_up(lens, [24, 20, 9], m1, method)
+        gg = g.drill_up(lens, [24, 20, 9], m1, method)
+        ev, es = expected_typed(og)
+        assert same_typed(gg.get_data(), ev) and np.array_equal(gg.get_status(), es), method
+        # second step from what the typed store holds (it rounds after every operation; see test_typed_storage_differences)
+        o2 = OracleStore(24 * 20 * 9, type_name, default)
+        o2.set_data(np.where(es == 2, ev.astype(np.float64), default))
+        ev2, es2 = expected_typed(o2.drill_up([24, 20, 9], [24, 4, 9], m2, method))
+        g2 = gg.drill_up([24, 20, 9], [24, 4, 9], m2, method)
+        assert same_typed(g2.get_data(), ev2) and np.array_equal(g2.get_status(), es2), method
+
+
+@pytest.mark.parametrize("shape", [[10] * 9, [320, 5, 5, 5, 5, 5, 5, 10, 20]], ids=["literal", "friendly"])
+def test_config4_shapes_on_one_gpu(shape):
+    """BASELINE configs[3]'s 10^9-cell cube, both shapes of SURVEY 8(e), whole on ONE GPU: drillUp(sum) of dimension 0
+    -> all against float64 column sums on slices of the output (the N = 1 point of the sharded series)."""
+    n = int(np.prod(shape))
+    n_out = n // shape[0]
+    s = pkg.HipStore(n, "float32", 0.0)
+    pkg.capi.check(pkg.lib().olap_fill_seeded(s.values_ptr, None, n, 0, 2, 20240807, 1.0, None))
+    maps = [np.zeros(shape[0], np.uint32)] + [np.arange(l, dtype=np.uint32) for l in shape[1:]]
+    out = s.drill_up(shape, [1] + shape[1:], maps, "sum")
+    got = out.get_data()
+    assert got.size == n_out
+    # the generator is position-addressed: recompute three slices of every row on the host
+    for lo in (0, n_out // 2 - 500, n_out - 1000):
+        cols = np.zeros(1000)
+        for r in range(shape[0]):
+            u = mulberry32_at(20240807, 2 * (np.arange(r * n_out + lo, r * n_out + lo + 1000, dtype=np.uint64)) + 1)
+            cols += (0.5 + u).astype(np.float32).astype(np.float64)
+        assert np.array_equal(got[lo:lo + 1000], cols.astype(np.float32)), (shape[0], lo)
     assert abs(out.total - s.total) <= 1e-6 * s.total
 
 

@@ -14,11 +14,13 @@ import sys
 import numpy as np
 import pytest
 
+from conftest import load_package
 from golden_util import expected_typed
 from oracle.oracle import OracleStore
 from sharded_cases import CASES, case_data, methods_of
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+load_package()
 
 
 def run_workers(engine, tmp_path, world=2):
@@ -77,8 +79,6 @@ def check_dim0(results):
 
 def test_partition_and_recipe_host_only():
     """olap_shard_bounds / olap_shard_dice_bounds / olap_shard_recipe_get need no device."""
-    from conftest import load_package
-    load_package()
     from olap_in_memory_amd import capi
     from olap_in_memory_amd.sharded import dice_bounds, partition_rows, recipe
     assert partition_rows(10, 8) == [0, 2, 4, 5, 6, 7, 8, 9, 10]
