@@ -397,6 +397,10 @@ uint64_t olap_sharded_store_size(const olap_sharded_store *store);
 int olap_sharded_store_ndim(const olap_sharded_store *store);
 const uint32_t *olap_sharded_store_lens(const olap_sharded_store *store);
 const uint32_t *olap_sharded_store_bounds(const olap_sharded_store *store);  /* world + 1 entries */
+/* Re-describes the dimensions without moving a cell (the reference's Cube inserts and drops one-item
+ * dimensions around store calls, src/cube.js:919-927, :950-964): lens[0] must stay the sharded extent and
+ * the product of the others the row size; otherwise OLAP_ERR_INVALID_ARGUMENT, message "sharded: ...". */
+int olap_sharded_store_reshape(olap_sharded_store *store, int ndim, const uint32_t *lens);
 olap_comm *olap_sharded_store_comm(const olap_sharded_store *store);
 olap_store *olap_sharded_store_shard(const olap_sharded_store *store, int local);  /* borrowed */
 int olap_sharded_store_fill_seeded(olap_sharded_store *store, uint32_t seed, double frac);

@@ -133,6 +133,7 @@ SIGNATURES = {
     "olap_sharded_store_ndim": (_i32, [_vp]),
     "olap_sharded_store_lens": (_pu32, [_vp]),
     "olap_sharded_store_bounds": (_pu32, [_vp]),
+    "olap_sharded_store_reshape": (_i32, [_vp, _i32, _pu32]),
     "olap_sharded_store_comm": (_vp, [_vp]),
     "olap_sharded_store_shard": (_vp, [_vp, _i32]),
     "olap_sharded_store_fill_seeded": (_i32, [_vp, C.c_uint32, _dbl]),

@@ -959,6 +959,16 @@ extern "C" uint64_t olap_sharded_store_size(const olap_sharded_store *s) { retur
 extern "C" int olap_sharded_store_ndim(const olap_sharded_store *s) { return s ? (int)s->lens.size() : 0; }
 extern "C" const uint32_t *olap_sharded_store_lens(const olap_sharded_store *s) { return s ? s->lens.data() : nullptr; }
 extern "C" const uint32_t *olap_sharded_store_bounds(const olap_sharded_store *s) { return s ? s->bounds.data() : nullptr; }
+extern "C" int olap_sharded_store_reshape(olap_sharded_store *s, int ndim, const uint32_t *lens) {
+  if (!s) return fail(OLAP_ERR_INVALID_ARGUMENT, "store is NULL");
+  if (ndim < 1 || ndim > OLAP_MAX_DIMS || !lens) return fail(OLAP_ERR_INVALID_ARGUMENT, "sharded: a sharded store keeps at least its sharded dimension");
+  uint64_t inner = 1;
+  for (int d = 1; d < ndim; ++d) inner *= lens[d];
+  if (lens[0] != s->lens[0] || inner != s->inner0)
+    return fail(OLAP_ERR_INVALID_ARGUMENT, "sharded: the dimensions [%u, ...] do not keep the sharded extent %u in front; gather first", lens[0], s->lens[0]);
+  s->lens.assign(lens, lens + ndim);
+  return OLAP_OK;
+}
 extern "C" olap_comm *olap_sharded_store_comm(const olap_sharded_store *s) { return s ? s->comm : nullptr; }
 extern "C" olap_store *olap_sharded_store_shard(const olap_sharded_store *s, int local) {
   return (s && local >= 0 && local < (int)s->shard.size()) ? s->shard[local] : nullptr;

@@ -20,6 +20,8 @@ const entries = {
   HipStore: lazy('./store/hip'),
   TimeSlot: lazy('./calendar'),
   wire: lazy('./wire'),
+  setDevices: lazy('./backend', 'setDevices'),
+  shardWorld: lazy('./backend', 'shardWorld'),
 };
 
 for (const name of Object.keys(entries)) Object.defineProperty(exports, name, { enumerable: true, get: entries[name] });

@@ -38,7 +38,7 @@ class CellMapView {
   }
 
   get size() {
-    return this._store._native.countSet();
+    return this._store._whole.countSet();
   }
 
   has(index) {
@@ -50,17 +50,19 @@ class CellMapView {
   }
 
   *keys() {
-    for (const k of this._store._native.getKeys()) yield k;
+    for (const k of this._store._whole.getKeys()) yield k;
   }
 
   *values() {
-    const data = this._store._native.getDataF64();
-    for (const k of this._store._native.getKeys()) yield data[k];
+    const whole = this._store._whole;
+    const data = whole.getDataF64();
+    for (const k of whole.getKeys()) yield data[k];
   }
 
   *entries() {
-    const data = this._store._native.getDataF64();
-    for (const k of this._store._native.getKeys()) yield [k, data[k]];
+    const whole = this._store._whole;
+    const data = whole.getDataF64();
+    for (const k of whole.getKeys()) yield [k, data[k]];
   }
 
   [Symbol.iterator]() {
@@ -96,6 +98,22 @@ function visibleDims(pending, lengths) {
   return v === lengths.length ? at : null;
 }
 
+/**
+ * Calls `native[method](...args)`.  A sharded measure answers in place whatever leaves its outermost
+ * dimension alone (and the roll-up of that dimension itself: one collective); for the rest the C ABI
+ * refuses with a message starting "sharded:" (include/olap_hip.h) and the measure is gathered onto one
+ * device first — same result, one copy more.
+ */
+function onShards(native, method, args) {
+  if (!native.isSharded) return native[method](...args);
+  try {
+    return native[method](...args);
+  } catch (e) {
+    if (!/^sharded:/.test(e.message)) throw e;
+    return native.gather()[method](...args);
+  }
+}
+
 class HipStore {
   /**
    * `native` is the addon Store, or — for the result of dice() — a pending selection
@@ -103,7 +121,7 @@ class HipStore {
    * that follows (slice, removeDimension, drillUp after dice) runs fused and never writes the diced
    * intermediate cube (K5, DESIGN.md §3).
    */
-  constructor(size, type = 'float32', defaultValue = Number.NaN, native = undefined) {
+  constructor(size, type = 'float32', defaultValue = Number.NaN, native = undefined, lengths = undefined) {
     // same checks, order and messages as in-memory.js:56-60
     if (!Number.isNaN(defaultValue) && defaultValue !== 0) throw new Error('Invalid default value, only NaN and 0 are supported');
     if (!Object.prototype.hasOwnProperty.call(TYPE_CODE, type)) throw new Error('Invalid type');
@@ -116,19 +134,38 @@ class HipStore {
       this._pending = native;
       this._nativeStore = null;
     } else {
-      this._nativeStore = native || new (backend.load().Store)(size, TYPE_CODE[type], Number.isNaN(defaultValue) ? 1 : 0);
+      this._nativeStore = native || HipStore._create(size, type, defaultValue, lengths);
     }
     this._dataMap = new CellMapView(this);
   }
 
-  /** The device store; a pending dice is executed on first use. */
+  /**
+   * A new device store.  When a device list is set (backend.setDevices / OLAP_DEVICES) and the caller says
+   * how the cells are laid out (`lengths`, what Cube passes), the measure is split along dimension 0 over
+   * those devices; the reference's bare `new Store(size, type, default)` stays on one device.
+   */
+  static _create(size, type, defaultValue, lengths) {
+    const addon = backend.load();
+    const def = Number.isNaN(defaultValue) ? 1 : 0;
+    const world = addon.shardWorld();
+    if (world >= 2 && lengths && lengths.length >= 1 && lengths[0] >= world) return new addon.ShardedStore(Uint32Array.from(lengths), TYPE_CODE[type], def);
+    return new addon.Store(size, TYPE_CODE[type], def);
+  }
+
+  /** The device store (one device, or sharded); a pending dice is executed on first use. */
   get _native() {
     if (!this._nativeStore) {
       const p = this._pending;
-      this._nativeStore = p.source.dice(p.oldLen, p.midLen, p.sel);
+      this._nativeStore = onShards(p.source, 'dice', [p.oldLen, p.midLen, p.sel]);
       this._pending = null;
     }
     return this._nativeStore;
+  }
+
+  /** The measure as ONE device store: a sharded measure is gathered (what the shards cannot answer in place). */
+  get _whole() {
+    const native = this._native;
+    return native.isSharded ? native.gather() : native;
   }
 
   /**
@@ -168,7 +205,8 @@ class HipStore {
 
   set data(values) {
     if (this._size !== values.length) throw new Error(`value length is invalid: ${this._size} !== ${values.length}`);
-    if (ArrayBuffer.isView(values) && !(values instanceof Float64Array) && values.constructor.name.toLowerCase().startsWith(this._type)) {
+    if (ArrayBuffer.isView(values) && !(values instanceof Float64Array) && values.constructor.name.toLowerCase().startsWith(this._type) &&
+        !this._native.isSharded) {
       this._writable.setData(values); // a typed array of the store's own element type: no conversion
       return;
     }
@@ -199,7 +237,7 @@ class HipStore {
   drillUp(oldDimensions, newDimensions, method = 'sum') {
     const code = backend.load().methodFromName(method); // throws 'Unsupported aggregation method: <m>'
     const maps = newDimensions.map((dim, i) => Uint32Array.from(oldDimensions[i].getGroupIndexFromRootIndexMap(dim.rootAttribute)));
-    const at = this._pending ? visibleDims(this._pending, lengthsOf(oldDimensions)) : null;
+    const at = this._pending && !this._pending.source.isSharded ? visibleDims(this._pending, lengthsOf(oldDimensions)) : null;
     if (at) {
       const rolled = maps.filter((map, i) => map.length !== newDimensions[i].numItems || map.some((g, k) => g !== k)).length;
       const p = this._pending;
@@ -218,14 +256,14 @@ class HipStore {
         return this._wrap(p.source.diceDrillUp(p.oldLen, p.midLen, newLen, p.sel, allMaps, code));
       }
     }
-    return this._wrap(this._native.drillUp(lengthsOf(oldDimensions), lengthsOf(newDimensions), maps, code));
+    return this._wrap(onShards(this._native, 'drillUp', [lengthsOf(oldDimensions), lengthsOf(newDimensions), maps, code]));
   }
 
   /** in-memory.js:336-430 — any method other than 'sum' copies the parent value (:421-423) */
   drillDown(oldDimensions, newDimensions, method = 'sum', distributions = null) {
     const maps = oldDimensions.map((dim, i) => Uint32Array.from(newDimensions[i].getGroupIndexFromRootIndexMap(dim.rootAttribute)));
     const weights = distributions ? toFloat64(distributions, Number.NaN) : null;
-    return this._wrap(this._native.drillDown(lengthsOf(oldDimensions), lengthsOf(newDimensions), maps, method === 'sum' ? 0 : 4, weights));
+    return this._wrap(onShards(this._native, 'drillDown', [lengthsOf(oldDimensions), lengthsOf(newDimensions), maps, method === 'sum' ? 0 : 4, weights]));
   }
 
   /** in-memory.js:213-263 — the new dimensions' item ORDER decides where cells land */
@@ -257,7 +295,7 @@ class HipStore {
   /** in-memory.js:178-211 */
   reorder(oldDimensions, newDimensions) {
     const perm = Int32Array.from(newDimensions, (dim) => oldDimensions.indexOf(dim));
-    return this._wrap(this._native.reorder(lengthsOf(oldDimensions), perm));
+    return this._wrap(onShards(this._native, 'reorder', [lengthsOf(oldDimensions), perm]));
   }
 
   /** in-memory.js:139-176 — mutates this store */
@@ -272,7 +310,10 @@ class HipStore {
       retyped.data = otherStore.data;
       otherStore = retyped;
     }
-    this._writable.load(otherStore._native, lengthsOf(myDimensions), lengthsOf(hisDimensions), hisToMine);
+    // hydration scatters cells across the whole index space: a sharded measure is gathered for it and
+    // stays on one device afterwards
+    if (this._native.isSharded) this._nativeStore = this._native.gather();
+    this._writable.load(otherStore._whole, lengthsOf(myDimensions), lengthsOf(hisDimensions), hisToMine);
   }
 
   /**
@@ -280,7 +321,7 @@ class HipStore {
    * (set cells -> ascending index / value lists) runs on the device.
    */
   serialize() {
-    const sparse = this._native.toSparse();
+    const sparse = this._whole.toSparse();
     return toBuffer({ size: this._size, type: this._type, defaultValue: this._defaultValue, indexes: sparse.indexes, dataBuffer: sparse.values });
   }
 

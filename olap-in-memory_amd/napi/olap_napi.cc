@@ -450,6 +450,30 @@ static napi_value bad_args(napi_env env, const char *what) {
   return nullptr;
 }
 
+// the caller's current view of the dimensions (oldLen) is applied to the handle first: Cube adds and drops
+// one-item dimensions around store calls without touching the cells
+static bool sharded_view(napi_env env, olap_sharded_store *s, napi_value old_len) {
+  std::vector<uint32_t> lens;
+  if (!get_u32_vec(env, old_len, lens)) {
+    napi_throw_type_error(env, nullptr, "oldLen must be a Uint32Array");
+    return false;
+  }
+  int rc = olap_sharded_store_reshape(s, (int)lens.size(), lens.data());
+  if (rc) {
+    throw_olap(env, rc);
+    return false;
+  }
+  return true;
+}
+
+static bool decode_lens_tables(napi_env env, napi_value lens, napi_value tables, size_t ndim, std::vector<uint32_t> &len_out,
+                               std::vector<std::vector<uint32_t>> &tab_out, std::vector<const uint32_t *> &ptrs) {
+  if (!get_u32_vec(env, lens, len_out) || !get_tables(env, tables, tab_out)) return false;
+  if (len_out.size() != ndim || tab_out.size() != ndim) return false;
+  for (auto &t : tab_out) ptrs.push_back(t.empty() ? &OpArgs::dummy : t.data());
+  return true;
+}
+
 // drillUp(oldLen, newLen, maps, methodCode)
 static napi_value StoreDrillUp(napi_env env, napi_callback_info info) {
   STORE_METHOD_PROLOGUE(4)
@@ -585,6 +609,380 @@ static napi_value EvalFormula(napi_env env, napi_callback_info info) {
   return ta;
 }
 
+// ---- ShardedStore: a measure split along dimension 0 over the devices of setDevices() -----------
+// Wraps olap_sharded_store* (include/olap_hip.h, "Multi-GPU").  Method names and argument shapes are
+// those of Store, so the JS HipStore drives either; what a sharded store cannot do in place throws an
+// Error whose message starts with "sharded:" and the JS side gathers first.
+struct CommRef {
+  olap_comm *comm;
+  int refs;      // live ShardedStore wrappers + 1 while it is the current communicator
+};
+static CommRef *g_comm = nullptr;
+static napi_ref g_sharded_ctor = nullptr;
+
+static void comm_release(CommRef *c) {
+  if (c && --c->refs == 0) {
+    olap_comm_destroy(c->comm);
+    delete c;
+  }
+}
+
+struct ShardedBox {
+  olap_sharded_store *store;
+  CommRef *comm;
+  int64_t bytes;
+};
+
+static void finalize_sharded(napi_env env, void *data, void *) {
+  ShardedBox *box = (ShardedBox *)data;
+  if (box->store) {
+    account(env, -box->bytes);
+    olap_sharded_store_destroy(box->store);
+  }
+  comm_release(box->comm);
+  delete box;
+}
+
+static ShardedBox *unwrap_sharded(napi_env env, napi_value v) {
+  void *p = nullptr;
+  if (napi_unwrap(env, v, &p) != napi_ok || !p || !((ShardedBox *)p)->store) {
+    napi_throw_type_error(env, nullptr, "not a ShardedStore");
+    return nullptr;
+  }
+  return (ShardedBox *)p;
+}
+
+struct ShardedInit {
+  olap_sharded_store *store;
+  CommRef *comm;
+};
+
+static int64_t sharded_bytes(const olap_sharded_store *s) {
+  const olap_store *first = olap_sharded_store_shard(s, 0);
+  return (int64_t)(olap_sharded_store_size(s) * olap_dtype_size(first ? olap_store_dtype(first) : OLAP_FLOAT32));
+}
+
+static napi_value wrap_new_sharded(napi_env env, olap_sharded_store *s, CommRef *comm) {
+  napi_value ctor, obj, ext;
+  ShardedInit init{s, comm};
+  NAPI_OK(napi_get_reference_value(env, g_sharded_ctor, &ctor));
+  NAPI_OK(napi_create_external(env, &init, nullptr, nullptr, &ext));
+  if (napi_new_instance(env, ctor, 1, &ext, &obj) != napi_ok) {
+    olap_sharded_store_destroy(s);
+    return nullptr;
+  }
+  return obj;
+}
+
+// new ShardedStore(lens: Uint32Array, dtypeCode, defaultKind)  |  new ShardedStore(external) [internal]
+static napi_value ShardedNew(napi_env env, napi_callback_info info) {
+  size_t argc = 3;
+  napi_value argv[3], self;
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, &self, nullptr));
+  napi_valuetype t;
+  NAPI_OK(napi_typeof(env, argv[0], &t));
+  olap_sharded_store *s = nullptr;
+  CommRef *comm = nullptr;
+  if (argc == 1 && t == napi_external) {
+    void *p;
+    NAPI_OK(napi_get_value_external(env, argv[0], &p));
+    s = ((ShardedInit *)p)->store;
+    comm = ((ShardedInit *)p)->comm;
+  } else {
+    if (!g_comm) {
+      napi_throw_error(env, nullptr, "sharded: no device list; call setDevices([...]) first");
+      return nullptr;
+    }
+    std::vector<uint32_t> lens;
+    int32_t dtype = 0, def = 0;
+    if (argc < 3 || !get_u32_vec(env, argv[0], lens) || napi_get_value_int32(env, argv[1], &dtype) != napi_ok ||
+        napi_get_value_int32(env, argv[2], &def) != napi_ok) {
+      napi_throw_type_error(env, nullptr, "new ShardedStore(lens: Uint32Array, dtype: number, default: number)");
+      return nullptr;
+    }
+    comm = g_comm;
+    int rc = olap_sharded_store_create(&s, comm->comm, (int)lens.size(), lens.data(), dtype, def, nullptr);
+    if (rc) return throw_olap(env, rc);
+  }
+  ShardedBox *box = new ShardedBox{s, comm, sharded_bytes(s)};
+  comm->refs++;
+  if (napi_wrap(env, self, box, finalize_sharded, nullptr, nullptr) != napi_ok) {
+    olap_sharded_store_destroy(s);
+    comm_release(comm);
+    delete box;
+    napi_throw_error(env, nullptr, "napi_wrap failed");
+    return nullptr;
+  }
+  account(env, box->bytes);
+  return self;
+}
+
+#define SHARDED_PROLOGUE(MAXARGS)                                          \
+  size_t argc = MAXARGS;                                                   \
+  napi_value argv[MAXARGS > 0 ? MAXARGS : 1], self;                        \
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, &self, nullptr));       \
+  ShardedBox *box = unwrap_sharded(env, self);                             \
+  if (!box) return nullptr;                                                \
+  olap_sharded_store *s = box->store;
+
+static napi_value ShardedSize(napi_env env, napi_callback_info info) {
+  SHARDED_PROLOGUE(0)
+  return num(env, (double)olap_sharded_store_size(s));
+}
+static napi_value ShardedByteLength(napi_env env, napi_callback_info info) {
+  SHARDED_PROLOGUE(0)
+  return num(env, (double)box->bytes);
+}
+static napi_value ShardedDtype(napi_env env, napi_callback_info info) {
+  SHARDED_PROLOGUE(0)
+  return num(env, olap_store_dtype(olap_sharded_store_shard(s, 0)));
+}
+static napi_value ShardedDefault(napi_env env, napi_callback_info info) {
+  SHARDED_PROLOGUE(0)
+  return num(env, olap_store_default(olap_sharded_store_shard(s, 0)));
+}
+static napi_value ShardedIsSharded(napi_env env, napi_callback_info) {
+  napi_value t;
+  napi_get_boolean(env, true, &t);
+  return t;
+}
+// rows of dimension 0 owned by each rank: bounds[r] .. bounds[r+1]
+static napi_value ShardedBounds(napi_env env, napi_callback_info info) {
+  SHARDED_PROLOGUE(0)
+  const int world = olap_comm_world(olap_sharded_store_comm(s));
+  void *data;
+  napi_value ta = make_ta(env, napi_uint32_array, 4, (size_t)world + 1, &data);
+  if (!ta) return nullptr;
+  memcpy(data, olap_sharded_store_bounds(s), ((size_t)world + 1) * 4);
+  return ta;
+}
+
+// setData(Float64Array): JS numbers, converted on the devices like a TypedArray store would
+static napi_value ShardedSetData(napi_env env, napi_callback_info info) {
+  SHARDED_PROLOGUE(1)
+  napi_typedarray_type type;
+  size_t len;
+  void *data;
+  bool is_ta = false;
+  NAPI_OK(napi_is_typedarray(env, argv[0], &is_ta));
+  if (!is_ta || napi_get_typedarray_info(env, argv[0], &type, &len, &data, nullptr, nullptr) != napi_ok || type != napi_float64_array) {
+    napi_throw_type_error(env, nullptr, "ShardedStore.setData expects a Float64Array");
+    return nullptr;
+  }
+  int rc = olap_sharded_store_set_data_f64(s, (const double *)data, len);
+  if (rc) return throw_olap(env, rc);
+  return nullptr;
+}
+static napi_value ShardedGetDataF64(napi_env env, napi_callback_info info) {
+  SHARDED_PROLOGUE(0)
+  void *data;
+  napi_value ta = make_ta(env, napi_float64_array, 8, olap_sharded_store_size(s), &data);
+  if (!ta) return nullptr;
+  int rc = olap_sharded_store_get_data_f64(s, (double *)data);
+  if (rc) return throw_olap(env, rc);
+  return ta;
+}
+static napi_value ShardedGetStatus(napi_env env, napi_callback_info info) {
+  SHARDED_PROLOGUE(0)
+  void *data;
+  napi_value ta = make_ta(env, napi_int32_array, 4, olap_sharded_store_size(s), &data);
+  if (!ta) return nullptr;
+  int rc = olap_sharded_store_get_status(s, (int32_t *)data);
+  if (rc) return throw_olap(env, rc);
+  return ta;
+}
+static napi_value ShardedGetValue(napi_env env, napi_callback_info info) {
+  SHARDED_PROLOGUE(1)
+  double idx = 0;
+  NAPI_OK(napi_get_value_double(env, argv[0], &idx));
+  napi_value undef;
+  napi_get_undefined(env, &undef);
+  if (!(idx >= 0) || idx != std::floor(idx)) return undef;
+  double v = 0;
+  int is_set = 0;
+  int rc = olap_sharded_store_get_value(s, (uint64_t)idx, &v, &is_set);
+  if (rc) return throw_olap(env, rc);
+  return is_set ? num(env, v) : undef;
+}
+static napi_value ShardedSetValue(napi_env env, napi_callback_info info) {
+  SHARDED_PROLOGUE(2)
+  double idx = 0, v = 0;
+  NAPI_OK(napi_get_value_double(env, argv[0], &idx));
+  napi_valuetype t = napi_undefined;
+  if (argc > 1) NAPI_OK(napi_typeof(env, argv[1], &t));
+  int is_null = (t == napi_undefined || t == napi_null);
+  if (!is_null) {
+    napi_value coerced;
+    NAPI_OK(napi_coerce_to_number(env, argv[1], &coerced));
+    NAPI_OK(napi_get_value_double(env, coerced, &v));
+  }
+  int rc = olap_sharded_store_set_value(s, (uint64_t)idx, v, is_null);
+  if (rc) return throw_olap(env, rc);
+  return nullptr;
+}
+static napi_value ShardedFill(napi_env env, napi_callback_info info) {
+  SHARDED_PROLOGUE(1)
+  double v = 0;
+  napi_value coerced;
+  NAPI_OK(napi_coerce_to_number(env, argv[0], &coerced));
+  NAPI_OK(napi_get_value_double(env, coerced, &v));
+  int rc = olap_sharded_store_fill(s, v);
+  if (rc) return throw_olap(env, rc);
+  return nullptr;
+}
+static napi_value ShardedTotal(napi_env env, napi_callback_info info) {
+  SHARDED_PROLOGUE(0)
+  double t = 0;
+  int rc = olap_sharded_store_total(s, &t);
+  if (rc) return throw_olap(env, rc);
+  return num(env, t);
+}
+static napi_value ShardedClone(napi_env env, napi_callback_info info) {
+  SHARDED_PROLOGUE(0)
+  olap_sharded_store *c = nullptr;
+  int rc = olap_sharded_store_clone(s, &c);
+  if (rc) return throw_olap(env, rc);
+  return wrap_new_sharded(env, c, box->comm);
+}
+// gather() -> Store: the whole measure on the first device
+static napi_value ShardedGather(napi_env env, napi_callback_info info) {
+  SHARDED_PROLOGUE(0)
+  olap_store *w = nullptr;
+  int rc = olap_sharded_store_gather(s, &w);
+  if (rc) return throw_olap(env, rc);
+  return wrap_new_store(env, w);
+}
+
+// drillUp(oldLen, newLen, maps, method) -> ShardedStore (dimension 0 kept) | Store (dimension 0 rolled up: one collective)
+static napi_value ShardedDrillUp(napi_env env, napi_callback_info info) {
+  SHARDED_PROLOGUE(4)
+  if (argc < 1 || !sharded_view(env, s, argv[0])) return nullptr;
+  std::vector<uint32_t> new_len;
+  std::vector<std::vector<uint32_t>> tables;
+  std::vector<const uint32_t *> ptrs;
+  int32_t method = 0;
+  if (argc < 4 || !decode_lens_tables(env, argv[1], argv[2], (size_t)olap_sharded_store_ndim(s), new_len, tables, ptrs) ||
+      napi_get_value_int32(env, argv[3], &method) != napi_ok)
+    return bad_args(env, "drillUp(oldLen, newLen, maps, method)");
+  olap_sharded_store *os = nullptr;
+  olap_store *ow = nullptr;
+  int rc = olap_sharded_store_drillup(s, &os, &ow, new_len.data(), ptrs.data(), method);
+  if (rc) return throw_olap(env, rc);
+  return os ? wrap_new_sharded(env, os, box->comm) : wrap_new_store(env, ow);
+}
+// dice(oldLen, newLen, sel)
+static napi_value ShardedDice(napi_env env, napi_callback_info info) {
+  SHARDED_PROLOGUE(3)
+  if (argc < 1 || !sharded_view(env, s, argv[0])) return nullptr;
+  std::vector<uint32_t> new_len;
+  std::vector<std::vector<uint32_t>> tables;
+  std::vector<const uint32_t *> ptrs;
+  if (argc < 3 || !decode_lens_tables(env, argv[1], argv[2], (size_t)olap_sharded_store_ndim(s), new_len, tables, ptrs))
+    return bad_args(env, "dice(oldLen, newLen, sel)");
+  olap_sharded_store *os = nullptr;
+  int rc = olap_sharded_store_dice(s, &os, new_len.data(), (const int32_t *const *)ptrs.data());
+  if (rc) return throw_olap(env, rc);
+  return wrap_new_sharded(env, os, box->comm);
+}
+// drillDown(oldLen, newLen, maps, method, distributions)
+static napi_value ShardedDrillDown(napi_env env, napi_callback_info info) {
+  SHARDED_PROLOGUE(5)
+  if (argc < 1 || !sharded_view(env, s, argv[0])) return nullptr;
+  std::vector<uint32_t> new_len;
+  std::vector<std::vector<uint32_t>> tables;
+  std::vector<const uint32_t *> ptrs;
+  int32_t method = 0;
+  if (argc < 4 || !decode_lens_tables(env, argv[1], argv[2], (size_t)olap_sharded_store_ndim(s), new_len, tables, ptrs) ||
+      napi_get_value_int32(env, argv[3], &method) != napi_ok)
+    return bad_args(env, "drillDown(oldLen, newLen, maps, method, distributions)");
+  const double *dist = nullptr;
+  size_t n_dist = 0;
+  if (argc > 4) {
+    bool is_ta = false;
+    napi_is_typedarray(env, argv[4], &is_ta);
+    if (is_ta) {
+      napi_typedarray_type type;
+      void *data;
+      NAPI_OK(napi_get_typedarray_info(env, argv[4], &type, &n_dist, &data, nullptr, nullptr));
+      static const double none = 0;
+      dist = data ? (const double *)data : &none;
+    }
+  }
+  olap_sharded_store *os = nullptr;
+  int rc = olap_sharded_store_drilldown(s, &os, new_len.data(), ptrs.data(), method, dist, n_dist);
+  if (rc) return throw_olap(env, rc);
+  return wrap_new_sharded(env, os, box->comm);
+}
+// reorder(oldLen, perm)
+static napi_value ShardedReorder(napi_env env, napi_callback_info info) {
+  SHARDED_PROLOGUE(2)
+  if (argc < 1 || !sharded_view(env, s, argv[0])) return nullptr;
+  std::vector<uint32_t> perm;
+  if (argc < 2 || !get_u32_vec(env, argv[1], perm) || perm.size() != (size_t)olap_sharded_store_ndim(s))
+    return bad_args(env, "reorder(oldLen, perm)");
+  olap_sharded_store *os = nullptr;
+  int rc = olap_sharded_store_reorder(s, &os, (const int32_t *)perm.data());
+  if (rc) return throw_olap(env, rc);
+  return wrap_new_sharded(env, os, box->comm);
+}
+
+// shardStore(store: Store, lens: Uint32Array) -> ShardedStore (olap_sharded_store_scatter)
+static napi_value ShardStore(napi_env env, napi_callback_info info) {
+  size_t argc = 2;
+  napi_value argv[2];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+  if (!g_comm) {
+    napi_throw_error(env, nullptr, "sharded: no device list; call setDevices([...]) first");
+    return nullptr;
+  }
+  std::vector<uint32_t> lens;
+  olap_store *whole = argc > 0 ? unwrap(env, argv[0]) : nullptr;
+  if (!whole) return nullptr;
+  if (argc < 2 || !get_u32_vec(env, argv[1], lens)) return bad_args(env, "shardStore(store, lens: Uint32Array)");
+  olap_sharded_store *s = nullptr;
+  int rc = olap_sharded_store_scatter(&s, g_comm->comm, whole, (int)lens.size(), lens.data());
+  if (rc) return throw_olap(env, rc);
+  return wrap_new_sharded(env, s, g_comm);
+}
+
+// setDevices(devices: number[] | null): the devices new sharded measures are split over
+// (olap_comm_init_all: distinct devices talk over RCCL / xGMI; one device repeated exchanges directly)
+static napi_value SetDevices(napi_env env, napi_callback_info info) {
+  size_t argc = 1;
+  napi_value argv[1];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+  bool is_arr = false;
+  if (argc) napi_is_array(env, argv[0], &is_arr);
+  std::vector<int> devices;
+  if (is_arr) {
+    uint32_t n = 0;
+    napi_get_array_length(env, argv[0], &n);
+    for (uint32_t i = 0; i < n; ++i) {
+      napi_value e;
+      int32_t d = 0;
+      NAPI_OK(napi_get_element(env, argv[0], i, &e));
+      NAPI_OK(napi_get_value_int32(env, e, &d));
+      devices.push_back(d);
+    }
+  }
+  CommRef *next = nullptr;
+  if (devices.size() > 1) {
+    olap_comm *c = nullptr;
+    int rc = olap_comm_init_all(&c, devices.data(), (int)devices.size());
+    if (rc) return throw_olap(env, rc);
+    next = new CommRef{c, 1};
+  }
+  comm_release(g_comm);
+  g_comm = next;
+  return num(env, next ? olap_comm_world(next->comm) : 0);
+}
+static napi_value ShardWorld(napi_env env, napi_callback_info) { return num(env, g_comm ? olap_comm_world(g_comm->comm) : 0); }
+static napi_value ShardTransport(napi_env env, napi_callback_info) {
+  napi_value v;
+  napi_create_string_utf8(env, g_comm ? olap_comm_transport(g_comm->comm) : "none", NAPI_AUTO_LENGTH, &v);
+  return v;
+}
+
 // ---- module functions -------------------------------------------------------------------------
 static napi_value MethodFromName(napi_env env, napi_callback_info info) {
   size_t argc = 1;
@@ -652,7 +1050,36 @@ static napi_value Init(napi_env env, napi_value exports) {
   if (napi_define_class(env, "Store", NAPI_AUTO_LENGTH, StoreNew, nullptr, sizeof(props) / sizeof(props[0]), props, &ctor) != napi_ok) return nullptr;
   napi_create_reference(env, ctor, 1, &g_store_ctor);
   napi_set_named_property(env, exports, "Store", ctor);
+  napi_property_descriptor sprops[] = {
+      {"size", nullptr, nullptr, ShardedSize, nullptr, nullptr, napi_default, nullptr},
+      {"byteLength", nullptr, nullptr, ShardedByteLength, nullptr, nullptr, napi_default, nullptr},
+      {"dtype", nullptr, nullptr, ShardedDtype, nullptr, nullptr, napi_default, nullptr},
+      {"defaultKind", nullptr, nullptr, ShardedDefault, nullptr, nullptr, napi_default, nullptr},
+      {"isSharded", nullptr, nullptr, ShardedIsSharded, nullptr, nullptr, napi_default, nullptr},
+      {"bounds", nullptr, nullptr, ShardedBounds, nullptr, nullptr, napi_default, nullptr},
+      {"setData", nullptr, ShardedSetData, nullptr, nullptr, nullptr, napi_default, nullptr},
+      {"getDataF64", nullptr, ShardedGetDataF64, nullptr, nullptr, nullptr, napi_default, nullptr},
+      {"getStatus", nullptr, ShardedGetStatus, nullptr, nullptr, nullptr, napi_default, nullptr},
+      {"getValue", nullptr, ShardedGetValue, nullptr, nullptr, nullptr, napi_default, nullptr},
+      {"setValue", nullptr, ShardedSetValue, nullptr, nullptr, nullptr, napi_default, nullptr},
+      {"fill", nullptr, ShardedFill, nullptr, nullptr, nullptr, napi_default, nullptr},
+      {"total", nullptr, ShardedTotal, nullptr, nullptr, nullptr, napi_default, nullptr},
+      {"clone", nullptr, ShardedClone, nullptr, nullptr, nullptr, napi_default, nullptr},
+      {"gather", nullptr, ShardedGather, nullptr, nullptr, nullptr, napi_default, nullptr},
+      {"drillUp", nullptr, ShardedDrillUp, nullptr, nullptr, nullptr, napi_default, nullptr},
+      {"drillDown", nullptr, ShardedDrillDown, nullptr, nullptr, nullptr, napi_default, nullptr},
+      {"dice", nullptr, ShardedDice, nullptr, nullptr, nullptr, napi_default, nullptr},
+      {"reorder", nullptr, ShardedReorder, nullptr, nullptr, nullptr, napi_default, nullptr},
+  };
+  napi_value sctor;
+  if (napi_define_class(env, "ShardedStore", NAPI_AUTO_LENGTH, ShardedNew, nullptr, sizeof(sprops) / sizeof(sprops[0]), sprops, &sctor) != napi_ok) return nullptr;
+  napi_create_reference(env, sctor, 1, &g_sharded_ctor);
+  napi_set_named_property(env, exports, "ShardedStore", sctor);
   napi_property_descriptor fns[] = {
+      {"setDevices", nullptr, SetDevices, nullptr, nullptr, nullptr, napi_default, nullptr},
+      {"shardWorld", nullptr, ShardWorld, nullptr, nullptr, nullptr, napi_default, nullptr},
+      {"shardTransport", nullptr, ShardTransport, nullptr, nullptr, nullptr, napi_default, nullptr},
+      {"shardStore", nullptr, ShardStore, nullptr, nullptr, nullptr, napi_default, nullptr},
       {"evalFormula", nullptr, EvalFormula, nullptr, nullptr, nullptr, napi_default, nullptr},
       {"storeFromSparse", nullptr, StoreFromSparse, nullptr, nullptr, nullptr, napi_default, nullptr},
       {"methodFromName", nullptr, MethodFromName, nullptr, nullptr, nullptr, napi_default, nullptr},

@@ -15,8 +15,9 @@ NODE = shutil.which("node")
 ADDON = os.path.join(os.path.dirname(HERE), "olap-in-memory_amd", "lib", "olapgpu.node")
 
 
-def run_node(script, *args):
-    r = subprocess.run([NODE, os.path.join(HERE, "js", script), *args], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+def run_node(script, *args, env=None):
+    r = subprocess.run([NODE, os.path.join(HERE, "js", script), *args], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600,
+                       env=dict(os.environ, **(env or {})))
     assert r.returncode == 0, r.stdout[-6000:]
     return r.stdout
 
@@ -50,3 +51,20 @@ def test_reference_suite_on_gpu():
     """All 115 cases of the reference's test/*.js (benchmark file aside), same inputs and literals."""
     out = run_node("reference_cases.js")
     assert "115 passed, 0 failed" in out, out[-6000:]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("devices", ["0,0", "0,0,0"])
+def test_reference_suite_on_gpu_sharded(devices):
+    """The same 115 cases with every stored measure SPLIT along its outermost dimension (OLAP_DEVICES names one
+    device two / three times: the shards exchange by direct reads, RCCL refuses two ranks on one device).
+    Cube.drillUp of the sharded dimension runs as partial + one collective behind the same store call
+    (src/cube.js:1012-1020); what the shards cannot answer in place is gathered first."""
+    out = run_node("reference_cases.js", env={"OLAP_DEVICES": devices})
+    assert "115 passed, 0 failed" in out, out[-6000:]
+
+
+@pytest.mark.gpu
+def test_js_sharded_cube_on_gpu():
+    out = run_node("sharded_test.js")
+    assert "0 failed" in out, out[-6000:]
