@@ -224,6 +224,8 @@ struct olap_plan {
   Brick brick{};
   uint64_t n_bricks = 0;
   GatherReduce gr{};
+  bool xy_ok = false;                      // reorder of 4-byte cells without a mask: two-axis LDS transpose (olap_transpose.hip)
+  TransposeXY xy{};
   DrillUpReduce reduce{};                  // S > 0: reduce regime of the one-axis drillUp
   bool dd_two_pass = false;                // float cells, no distributions: scale + broadcast
   bool dice_pieces = false;                // dice of one dimension, short rows not whole 16-byte groups: dice_pieces_kernel
@@ -915,6 +917,80 @@ extern "C" int olap_reorder_plan(olap_plan **out, int dtype, int default_kind, i
     }
   }
   const bool contiguous_tail = m.empty() || m.back().stride == 1;
+  if (!contiguous_tail && olap_dtype_size(dtype) == 4 && p->out_cells > 0 && !getenv("OLAP_NO_XY")) {
+    // two-axis transpose: X = the source's fastest dimensions, Y = the destination's fastest ones (olap_transpose.hip)
+    const int n = (int)m.size();
+    std::vector<uint64_t> ostr(n);
+    uint64_t st = 1;
+    for (int d = n - 1; d >= 0; --d) {
+      ostr[d] = st;
+      st *= m[d].len;
+    }
+    std::vector<int> by_in(n), by_out(n);
+    for (int d = 0; d < n; ++d) by_in[d] = by_out[d] = d;
+    std::sort(by_in.begin(), by_in.end(), [&](int x, int y) { return m[x].stride < m[y].stride; });
+    std::sort(by_out.begin(), by_out.end(), [&](int x, int y) { return ostr[x] < ostr[y]; });
+    TransposeXY &t = p->xy;
+    std::vector<char> taken(n, 0);
+    t.lx = t.ly = 1;
+    for (int d : by_in) {
+      if (t.lx >= 128 || t.nx == kTransposeMaxAxis || d == by_out[0]) break;  // the destination's fastest dimension is Y's
+      t.len_x[t.nx] = m[d].len;
+      t.out_stride_x[t.nx] = ostr[d];
+      ++t.nx;
+      t.lx *= m[d].len;
+      taken[d] = 1;
+    }
+    for (int d : by_out) {
+      if (t.ly >= 128 || t.ny == kTransposeMaxAxis || taken[d]) break;
+      t.len_y[t.ny] = m[d].len;
+      t.in_stride_y[t.ny] = m[d].stride;
+      ++t.ny;
+      t.ly *= m[d].len;
+      taken[d] = 2;
+    }
+    bool ok = t.lx >= 16 && t.ly >= 16 && t.lx < 0x7FFFFFFFull && t.ly < 0x7FFFFFFFull;
+    t.batch = 1;
+    bool in4 = true, out4 = true;  // every batch / cross stride a multiple of 4 cells: rows start 16-byte aligned
+    for (int d = 0; d < n && ok; ++d) {
+      if (taken[d]) continue;
+      if (t.nb == kTransposeMaxBatch) {
+        ok = false;
+        break;
+      }
+      t.len_b[t.nb] = m[d].len;
+      t.in_stride_b[t.nb] = m[d].stride;
+      t.out_stride_b[t.nb] = ostr[d];
+      ++t.nb;
+      t.batch *= m[d].len;
+      in4 = in4 && m[d].stride % 4 == 0;
+      out4 = out4 && ostr[d] % 4 == 0;
+    }
+    for (int k = 0; k < t.ny; ++k) in4 = in4 && t.in_stride_y[k] % 4 == 0;
+    for (int k = 0; k < t.nx; ++k) out4 = out4 && t.out_stride_x[k] % 4 == 0;
+    if (ok) {
+      // measured (tools/pmc_probe.py): long runs matter more on the write side
+      t.ty = t.ly >= 96 ? 128 : 64;
+      t.tx = 64;
+      if (const char *e = getenv("OLAP_XY_TILE")) {  // developer knob: "64x64" | "128x64" | "64x128"
+        int a = 0, b2 = 0;
+        if (sscanf(e, "%dx%d", &a, &b2) == 2 && (a == 64 || a == 128) && (b2 == 64 || b2 == 128)) {
+          t.tx = a;
+          t.ty = b2;
+        }
+      }
+      t.super = 1;  // walking tiles in 2 x 2 .. 8 x 8 blocks was measured and bought nothing
+      if (const char *e = getenv("OLAP_XY_SUPER")) t.super = std::max(1, atoi(e));
+      t.tiles_x = (t.lx + t.tx - 1) / t.tx;
+      t.tiles_y = (t.ly + t.ty - 1) / t.ty;
+      t.vec_in = in4 && t.lx % 4 == 0;
+      t.vec_out = out4 && t.ly % 4 == 0;
+      const bool is_float = dtype == OLAP_FLOAT32;
+      t.default_test = is_float ? (p->def_nan ? 2 : 1) : (p->def_nan ? 3 : 0);
+      ok = (t.tiles_x + t.super - 1) / t.super * ((t.tiles_y + t.super - 1) / t.super) * t.super * t.super * t.batch < 0x7FFFFFFFull;  // the grid is padded to whole super-tiles
+    }
+    p->xy_ok = ok;
+  }
   if (!contiguous_tail && (int)m.size() <= kMaxDims && p->out_cells > 0) {
     // brick transpose: pick chunk extents so that a brick is long in both orders
     const int n = (int)m.size();
@@ -1107,7 +1183,7 @@ extern "C" int olap_reorder_plan(olap_plan **out, int dtype, int default_kind, i
       b.wr_pos4 = quad ? (const uint2 *)(dev + scalar_words + 2 * (elems / 4)) : nullptr;
       p->kind = PLAN_BRICK;
       p->n_bricks = bricks;
-      p->kernel_name = quad ? "reorder_brick4_kernel" : "reorder_brick_kernel";
+      p->kernel_name = p->xy_ok ? "transpose_xy_kernel" : quad ? "reorder_brick4_kernel" : "reorder_brick_kernel";
       *out = p;
       return OLAP_OK;
     }
@@ -1116,7 +1192,7 @@ extern "C" int olap_reorder_plan(olap_plan **out, int dtype, int default_kind, i
     olap_plan_destroy(p);
     return rc;
   }
-  p->kernel_name = "gather(reorder)";
+  p->kernel_name = p->xy_ok ? "transpose_xy_kernel" : "gather(reorder)";
   *out = p;
   return OLAP_OK;
 }
@@ -1378,6 +1454,11 @@ static int run_typed(olap_plan *p, const void *in_v, const int32_t *in_s, void *
   T *out = (T *)out_v;
   const bool hs = in_s != nullptr;
   hipError_t e = hipSuccess;
+  if (p->xy_ok && !hs) {  // reorder without a mask to honour: pure permutation of 4-byte cells
+    e = launch_transpose_xy(p->xy, in_v, out_v, out_s, aligned16(in_v) && aligned16(out_v) && (!out_s || aligned16(out_s)), stream);
+    if (e != hipSuccess) return hip_fail(e, p->kernel_name.c_str());
+    return OLAP_OK;
+  }
   switch (p->kind) {
     case PLAN_DRILLUP_AXIS: {
       DrillUpAxis a = p->axis;

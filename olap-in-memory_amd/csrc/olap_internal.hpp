@@ -52,3 +52,23 @@ OLAP_INTERNAL const int32_t *mask_needed(const olap_store *s);
 OLAP_INTERNAL int store_alloc(olap_store **out, uint64_t size, int dtype, int default_kind);
 OLAP_INTERNAL int ensure_status(const olap_store *s);
 OLAP_INTERNAL void drop_lazy_status(olap_store *s);
+
+// ---- reorder of 4-byte cells as a two-axis LDS transpose (olap_transpose.hip) ---------------------
+constexpr int kTransposeMaxAxis = 4;    // dimensions merged into the X (source-contiguous) or Y (destination-contiguous) axis
+constexpr int kTransposeMaxBatch = 12;  // remaining dimensions: one coordinate per workgroup
+struct TransposeXY {
+  int nx, ny, nb;
+  uint32_t len_x[kTransposeMaxAxis];         // X chain, fastest source dimension first
+  uint64_t out_stride_x[kTransposeMaxAxis];  // their strides in the destination
+  uint32_t len_y[kTransposeMaxAxis];         // Y chain, fastest destination dimension first
+  uint64_t in_stride_y[kTransposeMaxAxis];   // their strides in the source
+  uint32_t len_b[kTransposeMaxBatch];
+  uint64_t in_stride_b[kTransposeMaxBatch], out_stride_b[kTransposeMaxBatch];
+  uint64_t lx, ly;                           // merged axis lengths
+  uint64_t tiles_x, tiles_y, batch;
+  int tx, ty;                                // tile extents (cells)
+  int super;                                 // tiles are walked in super x super blocks
+  int vec_in, vec_out;                       // every tile row starts 16-byte aligned on that side
+  int default_test;                          // how a generated mask tells the default: 0 int/0, 1 float/0, 2 float/NaN, 3 never
+};
+OLAP_INTERNAL hipError_t launch_transpose_xy(const TransposeXY &t, const void *in, void *out, int32_t *st_out, bool aligned16, hipStream_t stream);

@@ -1,0 +1,245 @@
+// olap_transpose.hip — reorder (axis permutation, /root/reference/src/store/in-memory.js:178-211) of
+// 4-byte cells as a two-axis LDS transpose.
+//
+// A permutation whose fastest dimension changes reads 4 bytes per cache line if it is written as a
+// gather.  Here the dimensions are split into
+//   X  the source's fastest dimensions (a contiguous chain in the SOURCE, merged into one linear axis),
+//   Y  the destination's fastest dimensions (a contiguous chain in the DESTINATION, merged likewise),
+//   B  everything else (batch: one coordinate per workgroup),
+// and a workgroup moves one TX x TY tile of the (X, Y) plane: rows of the tile are read along X (TX
+// contiguous source cells), parked in LDS, and written along Y (TY contiguous destination cells).
+// Offsets are separable — source = base + x + inY[y], destination = base + outX[x] + y — so a tile needs
+// two small tables (TX + TY entries, decoded by the workgroup itself from the tile's origin), not one
+// entry per cell, tiles need not line up with dimension boundaries (512-byte runs on both sides whatever
+// the extents are), and ragged edges are two wave-uniform bounds.
+//
+// LDS layout: cell (x, y) at x * (TY + 1) + y, every access 4 bytes wide.  The pitch TY + 1 = 1 (mod 32)
+// makes the bank of a cell (x + y) mod 32, so
+//   * 16-byte global accesses (lane = 4 adjacent cells) are conflict-free when a 32-lane group covers
+//     8 quads x 4 lines (4q + j + line distinct), on the way in and on the way out alike;
+//   * 4-byte global accesses (lane = one cell, 64 adjacent cells per wave) are conflict-free as they are.
+// The 16-byte form of each side is used when every row of every tile starts 16-byte aligned on that
+// side; otherwise that side moves 4 bytes per lane (cubes with odd extents).
+//
+// HBM-bound: 4 B read + 4 B written per cell.
+#include <hip/hip_runtime.h>
+
+#include "olap_device.hpp"
+#include "olap_internal.hpp"
+
+using namespace olap;
+
+namespace {
+
+template <int TX, int TY, bool VIN, bool VOUT>
+__global__ __launch_bounds__(kBlock) void transpose_xy_kernel(const uint32_t *__restrict__ in, uint32_t *__restrict__ out,
+                                                              int32_t *__restrict__ st_out, const TransposeXY t) {
+  constexpr int P = TY + 1;
+  extern __shared__ __attribute__((aligned(16))) uint32_t tile[];  // TX * P cells
+  __shared__ uint64_t out_x[TX];  // destination offset of tile column x (relative to the tile's base)
+  __shared__ uint64_t in_y[TY];   // source offset of tile row y
+
+  // tile -> (batch coordinate, super-tile, tile inside it).  Workgroups that run at the same time (consecutive
+  // logical ids, one XCD) cover a kSuper x kSuper block of tiles: their row pieces are neighbours in the source
+  // (along X) AND in the destination (along Y), so DRAM pages opened for one tile serve its neighbours
+  const uint32_t kSuper = (uint32_t)t.super;
+  uint64_t c = xcd_contiguous(blockIdx.x, gridDim.x);
+  const uint32_t in_super = (uint32_t)(c % (kSuper * kSuper));
+  c /= kSuper * kSuper;
+  const uint64_t sx_n = (t.tiles_x + kSuper - 1) / kSuper, sy_n = (t.tiles_y + kSuper - 1) / kSuper;
+  const uint32_t tx = (uint32_t)(c % sx_n) * kSuper + in_super % kSuper;
+  c /= sx_n;
+  const uint32_t ty = (uint32_t)(c % sy_n) * kSuper + in_super / kSuper;
+  c /= sy_n;
+  if (tx >= t.tiles_x || ty >= t.tiles_y) return;  // the grid is padded to whole super-tiles
+  uint64_t base_in = 0, base_out = 0;
+#pragma unroll
+  for (int d = 0; d < kTransposeMaxBatch; ++d) {
+    if (d < t.nb) {
+      const uint64_t digit = c % t.len_b[d];
+      c /= t.len_b[d];
+      base_in += digit * t.in_stride_b[d];
+      base_out += digit * t.out_stride_b[d];
+    }
+  }
+  const uint64_t x0 = (uint64_t)tx * TX, y0 = (uint64_t)ty * TY;
+  const uint32_t nx = (uint32_t)((t.lx - x0) < (uint64_t)TX ? (t.lx - x0) : (uint64_t)TX);
+  const uint32_t ny = (uint32_t)((t.ly - y0) < (uint64_t)TY ? (t.ly - y0) : (uint64_t)TY);
+  base_in += x0;   // the X chain is contiguous in the source
+  base_out += y0;  // the Y chain is contiguous in the destination
+
+  // per-tile offset tables: digits of the merged coordinate, fastest dimension first (32-bit arithmetic: the
+  // plan keeps both merged axes below 2^31).  Rows are needed at once; the column table is filled while the
+  // tile's loads are in flight.
+  auto decode_row = [&](uint32_t i) {
+    uint32_t v = (uint32_t)y0 + i;
+    uint64_t off = 0;
+#pragma unroll
+    for (int d = 0; d < kTransposeMaxAxis; ++d)
+      if (d < t.ny) {
+        const uint32_t qd = v / t.len_y[d];
+        off += (uint64_t)(v - qd * t.len_y[d]) * t.in_stride_y[d];
+        v = qd;
+      }
+    in_y[i] = off;
+  };
+  auto decode_col = [&](uint32_t i) {
+    uint32_t v = (uint32_t)x0 + i;
+    uint64_t off = 0;
+#pragma unroll
+    for (int d = 0; d < kTransposeMaxAxis; ++d)
+      if (d < t.nx) {
+        const uint32_t qd = v / t.len_x[d];
+        off += (uint64_t)(v - qd * t.len_x[d]) * t.out_stride_x[d];
+        v = qd;
+      }
+    out_x[i] = off;
+  };
+  for (uint32_t i = threadIdx.x; i < (uint32_t)TY; i += kBlock) decode_row(i);
+  __syncthreads();
+
+  const uint32_t *src = in + base_in;
+  // ---- in: rows along X
+  if constexpr (VIN) {
+    // a 32-lane group = 8 quads x 4 rows; the workgroup's 8 groups tile QX quad-blocks x RY row-blocks
+    constexpr int QX = TX / 32;          // 32-cell blocks across a row
+    constexpr int RY = 8 / QX;           // row blocks per pass
+    constexpr int ROWS = RY * 4;         // rows per pass
+    const uint32_t g = threadIdx.x >> 5, l = threadIdx.x & 31;
+    const uint32_t q = (g % QX) * 8 + (l & 7);          // quad index in the row
+    const uint32_t r0 = (g / QX) * 4 + (l >> 3);        // row within the pass
+    constexpr int PASSES = TY / ROWS;
+    constexpr int UB = PASSES < 8 ? PASSES : 8;
+    for (int p0 = 0; p0 < PASSES; p0 += UB) {
+      Vec<uint32_t, 4> v[UB];
+#pragma unroll
+      for (int u = 0; u < UB; ++u) {
+        const uint32_t y = (p0 + u) * ROWS + r0;
+        if (y < ny && 4 * q < nx) v[u] = load_stream<uint32_t, 4>(src + in_y[y] + 4 * q);
+      }
+      if (p0 == 0)
+        for (uint32_t i = threadIdx.x; i < (uint32_t)TX; i += kBlock) decode_col(i);
+#pragma unroll
+      for (int u = 0; u < UB; ++u) {
+        const uint32_t y = (p0 + u) * ROWS + r0;
+        if (y < ny && 4 * q < nx) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) tile[(4 * q + j) * P + y] = v[u].v[j];
+        }
+      }
+    }
+  } else {
+    constexpr int ROWS = kBlock / TX > 0 ? kBlock / TX : 1;  // rows per pass (TX <= 256)
+    const uint32_t x = threadIdx.x % TX, r0 = threadIdx.x / TX;
+    constexpr int PASSES = TY / ROWS;
+    constexpr int UB = 8;
+    for (int p0 = 0; p0 < PASSES; p0 += UB) {
+      uint32_t v[UB];
+#pragma unroll
+      for (int u = 0; u < UB; ++u) {
+        const uint32_t y = (p0 + u) * ROWS + r0;
+        if (p0 + u < PASSES && y < ny && x < nx) v[u] = __builtin_nontemporal_load(src + in_y[y] + x);
+      }
+      if (p0 == 0)
+        for (uint32_t i = threadIdx.x; i < (uint32_t)TX; i += kBlock) decode_col(i);
+#pragma unroll
+      for (int u = 0; u < UB; ++u) {
+        const uint32_t y = (p0 + u) * ROWS + r0;
+        if (p0 + u < PASSES && y < ny && x < nx) tile[x * P + y] = v[u];
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- out: rows along Y
+  uint32_t *dst = out + base_out;
+  int32_t *sdst = st_out ? st_out + base_out : nullptr;
+  auto status_of = [&](uint32_t bits) -> int32_t {
+    bool is_default;
+    switch (t.default_test) {
+      case 0: is_default = bits == 0u; break;                               // integer cells, 0 default
+      case 1: is_default = (bits << 1) == 0u; break;                        // float cells, 0 default (+0 and -0)
+      case 2: is_default = (bits & 0x7FFFFFFFu) > 0x7F800000u; break;       // float cells, NaN default
+      default: is_default = false; break;
+    }
+    return is_default ? 0 : OLAP_STATUS_SET;
+  };
+  if constexpr (VOUT) {
+    constexpr int QY = TY / 32;
+    constexpr int RX = 8 / QY;
+    constexpr int ROWS = RX * 4;
+    const uint32_t g = threadIdx.x >> 5, l = threadIdx.x & 31;
+    const uint32_t q = (g % QY) * 8 + (l & 7);
+    const uint32_t r0 = (g / QY) * 4 + (l >> 3);
+    constexpr int PASSES = TX / ROWS;
+    for (int p = 0; p < PASSES; ++p) {
+      const uint32_t x = p * ROWS + r0;
+      if (x < nx && 4 * q < ny) {
+        Vec<uint32_t, 4> v;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v.v[j] = tile[x * P + 4 * q + j];
+        store_stream<uint32_t, 4>(dst + out_x[x] + 4 * q, v);
+        if (sdst) {
+          Vec<int32_t, 4> s;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) s.v[j] = status_of(v.v[j]);
+          store_stream<int32_t, 4>(sdst + out_x[x] + 4 * q, s);
+        }
+      }
+    }
+  } else {
+    constexpr int ROWS = kBlock / TY > 0 ? kBlock / TY : 1;
+    const uint32_t y = threadIdx.x % TY, r0 = threadIdx.x / TY;
+    constexpr int PASSES = TX / ROWS;
+    for (int p = 0; p < PASSES; ++p) {
+      const uint32_t x = p * ROWS + r0;
+      if (x < nx && y < ny) {
+        const uint32_t v = tile[x * P + y];
+        __builtin_nontemporal_store(v, dst + out_x[x] + y);
+        if (sdst) __builtin_nontemporal_store(status_of(v), sdst + out_x[x] + y);
+      }
+    }
+  }
+}
+
+template <int TX, int TY, bool VIN, bool VOUT>
+hipError_t launch_one(const TransposeXY &t, const uint32_t *in, uint32_t *out, int32_t *st_out, unsigned grid, hipStream_t stream) {
+  constexpr size_t lds = (size_t)TX * (TY + 1) * sizeof(uint32_t);
+  if (lds > 48 * 1024) {
+    static bool raised = false;  // (per instantiation)
+    if (!raised) {
+      hipError_t e = hipFuncSetAttribute((const void *)transpose_xy_kernel<TX, TY, VIN, VOUT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return e;
+      raised = true;
+    }
+  }
+  hipLaunchKernelGGL((transpose_xy_kernel<TX, TY, VIN, VOUT>), grid, kBlock, lds, stream, in, out, st_out, t);
+  return hipGetLastError();
+}
+
+template <int TX, int TY>
+hipError_t launch_tile(const TransposeXY &t, const uint32_t *in, uint32_t *out, int32_t *st_out, bool vin, bool vout, hipStream_t stream) {
+  const uint64_t kSuper = (uint64_t)t.super;
+  const uint64_t sx = (t.tiles_x + kSuper - 1) / kSuper, sy = (t.tiles_y + kSuper - 1) / kSuper;
+  const uint64_t tiles = sx * sy * kSuper * kSuper * t.batch;
+  if (t.tiles_x * t.tiles_y * t.batch == 0) return hipSuccess;
+  if (tiles > 0x7FFFFFFFull) return hipErrorInvalidValue;
+  const unsigned grid = (unsigned)tiles;
+  if (vin && vout) return launch_one<TX, TY, true, true>(t, in, out, st_out, grid, stream);
+  if (vin) return launch_one<TX, TY, true, false>(t, in, out, st_out, grid, stream);
+  if (vout) return launch_one<TX, TY, false, true>(t, in, out, st_out, grid, stream);
+  return launch_one<TX, TY, false, false>(t, in, out, st_out, grid, stream);
+}
+
+}  // namespace
+
+hipError_t launch_transpose_xy(const TransposeXY &t, const void *in, void *out, int32_t *st_out, bool aligned16, hipStream_t stream) {
+  const bool vin = t.vec_in && aligned16, vout = t.vec_out && aligned16;
+  const uint32_t *src = (const uint32_t *)in;
+  uint32_t *dst = (uint32_t *)out;
+  if (t.tx == 64 && t.ty == 64) return launch_tile<64, 64>(t, src, dst, st_out, vin, vout, stream);
+  if (t.tx == 128 && t.ty == 64) return launch_tile<128, 64>(t, src, dst, st_out, vin, vout, stream);
+  if (t.tx == 64 && t.ty == 128) return launch_tile<64, 128>(t, src, dst, st_out, vin, vout, stream);
+  if (t.tx == 128 && t.ty == 128) return launch_tile<128, 128>(t, src, dst, st_out, vin, vout, stream);
+  return hipErrorInvalidValue;
+}

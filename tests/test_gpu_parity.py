@@ -945,34 +945,40 @@ def test_dice_row_copies_odd_extents(lens, axis, type_name, default, messy):
 
 
 REORDER_CASES = [
-    ([10] * 6, [5, 4, 3, 2, 1, 0], "reorder_brick4_kernel"),          # runs of 100 cells on both sides
-    ([12, 7, 20], [2, 1, 0], "reorder_brick4_kernel"),                # one brick = the whole cube
-    ([64, 48], [1, 0], "reorder_brick4_kernel"),                      # partial dimension on the read side
-    ([1000, 1000], [1, 0], "reorder_brick4_kernel"),                  # 100 x 100 bricks
-    ([50, 100, 1000], [2, 0, 1], None),
-    ([37, 53], [1, 0], "reorder_brick_kernel"),                       # odd extents: ragged scalar bricks
-    ([6, 1, 5, 4], [3, 0, 2, 1], None),
-    ([3, 250, 9, 30], [1, 3, 0, 2], None),
-    ([20, 30, 40], [0, 2, 1], None),                                  # leading dimension untouched
-    ([20, 30, 40], [1, 0, 2], "gather(reorder)"),                     # fastest dimension untouched: 16 B gather
+    # lens, perm, kernel of the masked / 8-byte forms, whether 4-byte cells without a mask take the two-axis transpose
+    ([10] * 6, [5, 4, 3, 2, 1, 0], "reorder_brick4_kernel", True),    # runs of 100 cells on both sides
+    ([12, 7, 20], [2, 1, 0], "reorder_brick4_kernel", False),         # one brick = the whole cube (Y axis of 12 cells: too short)
+    ([64, 48], [1, 0], "reorder_brick4_kernel", True),                # partial dimension on the read side
+    ([1000, 1000], [1, 0], "reorder_brick4_kernel", True),            # 100 x 100 bricks
+    ([50, 100, 1000], [2, 0, 1], None, True),
+    ([37, 53], [1, 0], "reorder_brick_kernel", True),                 # odd extents: ragged scalar bricks / 4-byte tiles
+    ([6, 1, 5, 4], [3, 0, 2, 1], None, False),
+    ([3, 250, 9, 30], [1, 3, 0, 2], None, None),
+    ([20, 30, 40], [0, 2, 1], None, True),                            # leading dimension untouched
+    ([20, 30, 40], [1, 0, 2], "gather(reorder)", False),              # fastest dimension untouched: 16 B gather
+    ([130, 3, 131], [2, 1, 0], None, True),                           # tiles that end inside a dimension, edge tiles on both axes
+    ([5, 300, 7, 260], [3, 1, 2, 0], None, True),                     # batch dimensions on both sides of the axes
 ]
 
 
-@pytest.mark.parametrize("lens,perm,kernel", REORDER_CASES)
-@pytest.mark.parametrize("type_name,default", [("float32", 0.0), ("int32", 0.0), ("uint32", float("nan")), ("float64", float("nan"))])
-def test_reorder_forms(lens, perm, kernel, type_name, default):
-    """reorder (in-memory.js:178-211) against numpy's transpose: the 16-byte brick form, the scalar
-    (ragged) brick form and the gather form, with and without the status mask."""
+@pytest.mark.parametrize("lens,perm,kernel,xy", REORDER_CASES)
+@pytest.mark.parametrize("type_name,default", [("float32", 0.0), ("float32", float("nan")), ("int32", 0.0), ("uint32", float("nan")), ("float64", float("nan"))])
+def test_reorder_forms(lens, perm, kernel, xy, type_name, default):
+    """reorder (in-memory.js:178-211) against numpy's transpose: the two-axis LDS transpose (4-byte cells without a
+    mask), the 16-byte brick form, the scalar (ragged) brick form and the gather form, with and without the mask."""
     rng = np.random.default_rng(29)
     n = int(np.prod(lens))
     vals = rng.integers(1, 1000, size=n).astype(np.float64)
     unset = rng.random(n) < 0.3
     dense = np.where(unset, default, vals)
     plan = pkg.Plan.reorder(type_name, default, lens, perm)
-    if kernel is not None and (type_name != "float64" or "brick4" not in kernel):
+    four_bytes = type_name != "float64"
+    if four_bytes and xy is not None:
+        assert (plan.kernel_name == "transpose_xy_kernel") == xy, plan.kernel_name
+    if kernel is not None and not (four_bytes and xy) and (four_bytes or "brick4" not in kernel):
         assert plan.kernel_name == kernel, plan.kernel_name
-    if type_name == "float64":
-        assert plan.kernel_name != "reorder_brick4_kernel"
+    if not four_bytes:
+        assert plan.kernel_name not in ("reorder_brick4_kernel", "transpose_xy_kernel")
     g = pkg.HipStore(n, type_name, default)
     g.set_data_f64(dense)
     out = g.reorder(lens, perm)
@@ -980,6 +986,12 @@ def test_reorder_forms(lens, perm, kernel, type_name, default):
     assert np.array_equal(out.get_status(), moved(g.get_status()))
     assert same_typed(out.get_data(), moved(g.get_data()))
     assert np.array_equal(out.get_status() == 2, moved(~unset))
+    # raw pointers: the mask generated on the way out (no mask given on the way in), where the values can tell
+    if not (default != default and type_name in ("int32", "uint32")):
+        o2 = pkg.HipStore(n, type_name, default)
+        plan.run(g.values_ptr, None, o2.values_ptr, o2.status_ptr)
+        pkg.capi.check(pkg.lib().olap_device_synchronize())
+        assert same_typed(o2.get_data(), moved(g.get_data())) and np.array_equal(o2.get_status(), moved(g.get_status()))
 
 
 @pytest.mark.parametrize("type_name,default", [("float32", 0.0), ("float32", float("nan")), ("uint32", float("nan")), ("float64", 0.0), ("int32", 0.0)])
