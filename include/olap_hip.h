@@ -259,6 +259,18 @@ int olap_store_to_sparse(const olap_store *store, uint32_t *host_indexes, void *
 int olap_store_from_sparse(olap_store **store, uint64_t size, int dtype, int default_kind,
                            const uint32_t *host_indexes, const void *host_values, uint64_t n);
 
+/* getNestedObject(measure, withTotals = true) (src/cube.js:421-440): every marginal of the measure in ONE
+ * call.  The reference runs, for each of the 2^D subsets of dimensions, the chain drillUp(dim, 'all') over
+ * the subset's dimensions in ascending order; all 2^D results are the cells of one extended cube of shape
+ * (lens[0] + 1) x ... x (lens[D-1] + 1), row-major, index lens[d] of dimension d meaning 'all'.
+ * methods[d] is the measure's rule for dimension d (src/cube.js:1013).  host_values receives that extended
+ * cube as float64 (the default in unset cells), host_status (optional) its mask.  Same operations, order
+ * and per-stage rounding as the chain of olap_store_drillup calls, hence the same values.
+ * When the extended cube fits in LDS (<= 12288 cells) this is one launch that reads the cube from HBM
+ * once; otherwise D + 2 launches instead of 2^D - 1.  *launches / *bytes_read (optional) report what ran. */
+int olap_store_totals(const olap_store *store, int ndim, const uint32_t *lens, const int *methods, double *host_values,
+                      int32_t *host_status, int *launches, uint64_t *bytes_read);
+
 /* olap_eval_formula over stores (all of the same size) into a host float64 array */
 int olap_store_eval_formula(const int32_t *code, int n_code, const double *consts, int n_consts, int n_inputs,
                             const olap_store *const *inputs, const double *scalars, int n_scalars,

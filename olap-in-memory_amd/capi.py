@@ -92,6 +92,7 @@ SIGNATURES = {
     "olap_store_total": (_i32, [_vp, _pdbl]),
     "olap_store_to_sparse": (_i32, [_vp, _pu32, _vp, _u64, _pu64]),
     "olap_store_from_sparse": (_i32, [_pvp, _u64, _i32, _i32, _pu32, _vp, _u64]),
+    "olap_store_totals": (_i32, [_vp, _i32, _pu32, C.POINTER(C.c_int), _pdbl, _pi32, C.POINTER(C.c_int), _pu64]),
     "olap_store_drillup": (_i32, [_vp, _pvp, _i32, _pu32, _pu32, _ppu32, _i32]),
     "olap_store_drilldown": (_i32, [_vp, _pvp, _i32, _pu32, _pu32, _ppu32, _i32, _pdbl, _u64]),
     "olap_store_dice": (_i32, [_vp, _pvp, _i32, _pu32, _pu32, _ppi32]),

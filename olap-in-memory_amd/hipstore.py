@@ -297,6 +297,18 @@ class HipStore:
         check(self._lib.olap_store_clone(self._h, C.byref(h)))
         return HipStore(0, _handle=h)
 
+    def totals(self, lens, methods):
+        """olap_store_totals: the extended cube of shape (len + 1) per dimension — every marginal of
+        getNestedObject(measure, withTotals) — as (float64 values, Int32 mask, launches, bytes read)."""
+        ol = _u32(lens)
+        m = (C.c_int * max(len(ol), 1))(*[_method_code(x) for x in methods])
+        n = int(np.prod([int(l) + 1 for l in ol])) if len(ol) else 1
+        vals, stat = np.zeros(n, np.float64), np.zeros(n, np.int32)
+        launches, nbytes = C.c_int(), C.c_uint64()
+        check(self._lib.olap_store_totals(self._h, len(ol), ol.ctypes.data_as(capi._pu32), m, vals.ctypes.data_as(capi._pdbl),
+                                          stat.ctypes.data_as(capi._pi32), C.byref(launches), C.byref(nbytes)))
+        return vals, stat, launches.value, nbytes.value
+
     # ---- bulk operations (names follow in-memory.js)
     def drill_up(self, old_len, new_len, maps, method="sum"):
         ol, nl = _u32(old_len), _u32(new_len)

@@ -289,25 +289,38 @@ class Cube {
   }
 
   getNestedObjects(measureIds, withTotals = false) {
-    const plain = (cube) => {
+    const plain = (cube, ids) => {
       const out = {};
-      for (const id of measureIds) out[id] = toNestedObject(cube.getData(id), cube.dimensions);
+      for (const id of ids) out[id] = toNestedObject(cube.getData(id), cube.dimensions);
       return out;
     };
     // eslint-disable-next-line eqeqeq
-    if (!withTotals || this.dimensions.length == 0) return plain(this);
-    // The reference rebuilds every marginal from the full cube (2^D chains of drillUps,
-    // src/cube.js:429-437).  The chain of subset s is the chain of (s without its highest
-    // dimension) plus one drillUp, so marginals are memoised: D passes over the full cube instead of
-    // 2^(D-1), same order of operations, same values.
+    if (!withTotals || this.dimensions.length == 0) return plain(this, measureIds);
+    // The reference rebuilds every marginal from the full cube: 2^D chains of drillUp(dim, 'all')
+    // (src/cube.js:429-437), merged into one object whose levels carry an extra 'all' key.  All 2^D
+    // results are the cells of ONE extended cube with an 'all' item appended to every dimension; a stored
+    // measure gets it from a single store call (olap_store_totals: one launch that reads the cube once
+    // when the extended cube fits in LDS, D + 2 launches otherwise) — same chain order, same rounding.
+    const stored = measureIds.filter((id) => this.storedMeasures[id] !== undefined);
+    const others = measureIds.filter((id) => this.storedMeasures[id] === undefined);
+    const extended = this.dimensions.map((d) => ({ getItems: () => d.getItems().concat(['all']) }));
     let result = {};
-    const marginals = [this];
-    for (let subset = 0; subset < 2 ** this.dimensions.length; ++subset) {
-      if (subset > 0) {
-        const top = 31 - Math.clz32(subset);
-        marginals[subset] = marginals[subset & ~(1 << top)].drillUp(this.dimensions[top].id, 'all');
+    for (const id of stored) {
+      const rules = this.storedMeasuresRules[id] || {};
+      result[id] = toNestedObject(this.storedMeasures[id].totals(this.dimensions, this.dimensions.map((d) => rules[d.id])), extended);
+    }
+    if (others.length) {
+      // computed measures are evaluated on each marginal cube (their `__total` parameters are that cube's
+      // totals).  The chain of subset s is the chain of (s without its highest dimension) plus one
+      // drillUp, so marginals are memoised: same order of operations, same values.
+      const marginals = [this];
+      for (let subset = 0; subset < 2 ** this.dimensions.length; ++subset) {
+        if (subset > 0) {
+          const top = 31 - Math.clz32(subset);
+          marginals[subset] = marginals[subset & ~(1 << top)].drillUp(this.dimensions[top].id, 'all');
+        }
+        result = deepMerge(result, plain(marginals[subset], others));
       }
-      result = deepMerge(result, plain(marginals[subset]));
     }
     return result;
   }

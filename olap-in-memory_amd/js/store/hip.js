@@ -233,6 +233,16 @@ class HipStore {
     else this._writable.fill(value);
   }
 
+  /**
+   * Every marginal of this measure (src/cube.js:421-440) as the flat extended cube: one more item, 'all', at
+   * the end of every dimension.  `methods[d]` is the measure's rule for dimension d (default 'sum').
+   */
+  totals(dimensions, methods) {
+    const addon = backend.load();
+    const codes = Int32Array.from(dimensions, (_, d) => addon.methodFromName(methods[d])); // throws 'Unsupported aggregation method: <m>'
+    return this._whole.totals(lengthsOf(dimensions), codes);
+  }
+
   /** in-memory.js:265-334 */
   drillUp(oldDimensions, newDimensions, method = 'sum') {
     const code = backend.load().methodFromName(method); // throws 'Unsupported aggregation method: <m>'

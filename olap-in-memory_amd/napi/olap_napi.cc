@@ -355,6 +355,31 @@ static napi_value StoreClone(napi_env env, napi_callback_info info) {
   return wrap_new_store(env, c);
 }
 
+// totals(lens: Uint32Array, methods: Int32Array) -> Float64Array of the extended cube (olap_store_totals)
+static bool get_u32_vec(napi_env env, napi_value v, std::vector<uint32_t> &out);
+static napi_value StoreTotals(napi_env env, napi_callback_info info) {
+  STORE_METHOD_PROLOGUE(2)
+  std::vector<uint32_t> lens, methods;
+  if (argc < 2 || !get_u32_vec(env, argv[0], lens) || !get_u32_vec(env, argv[1], methods) || lens.size() != methods.size()) {
+    napi_throw_type_error(env, nullptr, "totals(lens: Uint32Array, methods: Int32Array)");
+    return nullptr;
+  }
+  double n = 1;
+  for (uint32_t l : lens) n *= (double)l + 1;
+  if (n > 4.0e9) {
+    napi_throw_range_error(env, nullptr, "totals: extended cube too large");
+    return nullptr;
+  }
+  void *data;
+  napi_value ta = make_ta(env, napi_float64_array, 8, (size_t)n, &data);
+  if (!ta) return nullptr;
+  static const uint32_t none = 0;
+  int rc = olap_store_totals(s, (int)lens.size(), lens.empty() ? &none : lens.data(), lens.empty() ? (const int *)&none : (const int *)methods.data(),
+                             (double *)data, nullptr, nullptr, nullptr);
+  if (rc) return throw_olap(env, rc);
+  return ta;
+}
+
 // toSparse() -> { indexes: Uint32Array, values: TypedArray } of the set cells (ascending)
 static napi_value StoreToSparse(napi_env env, napi_callback_info info) {
   STORE_METHOD_PROLOGUE(0)
@@ -1038,6 +1063,7 @@ static napi_value Init(napi_env env, napi_value exports) {
       {"fill", nullptr, StoreFill, nullptr, nullptr, nullptr, napi_default, nullptr},
       {"total", nullptr, StoreTotal, nullptr, nullptr, nullptr, napi_default, nullptr},
       {"toSparse", nullptr, StoreToSparse, nullptr, nullptr, nullptr, napi_default, nullptr},
+      {"totals", nullptr, StoreTotals, nullptr, nullptr, nullptr, napi_default, nullptr},
       {"clone", nullptr, StoreClone, nullptr, nullptr, nullptr, napi_default, nullptr},
       {"drillUp", nullptr, StoreDrillUp, nullptr, nullptr, nullptr, napi_default, nullptr},
       {"drillDown", nullptr, StoreDrillDown, nullptr, nullptr, nullptr, napi_default, nullptr},
