@@ -72,6 +72,44 @@ def build_lib(force=False, verbose=False):
     return target
 
 
+def asan_lib_path():
+    return os.path.join(HERE, "lib_asan", "libolapgpu.so")
+
+
+def build_lib_asan(force=False):
+    """The same sources with AddressSanitizer + UBSan on the HOST side only (device code is compiled as usual:
+    GPU sanitizers are not available on this pool) -> lib_asan/libolapgpu.so.  Used with OLAP_PLAN_DRY=1 to run the
+    planning code under the sanitizers on a machine without a GPU (tests/test_capi_nogpu.py)."""
+    out_dir, obj_dir = os.path.join(HERE, "lib_asan"), os.path.join(HERE, "build_asan")
+    os.makedirs(out_dir, exist_ok=True)
+    os.makedirs(obj_dir, exist_ok=True)
+    hdrs = [h if os.path.isabs(h) else os.path.join(CSRC, h) for h in HEADERS]
+    flags = ["--offload-arch=" + ARCH, "-O1", "-g", "-std=c++17", "-fPIC", "-Wno-unused-function", "-ffp-contract=off", "-fsanitize=address,undefined",
+             "-fno-gpu-sanitize", "-fno-omit-frame-pointer", "-fno-sanitize-recover=undefined", "-I", os.path.join(ROOT, "include")]
+    jobs, objs = [], []
+    for unit in KERNEL_UNITS:
+        src = os.path.join(CSRC, unit)
+        obj = os.path.join(obj_dir, unit.replace(".hip", ".o"))
+        objs.append(obj)
+        if force or _newer(obj, [src] + hdrs):
+            jobs.append([HIPCC] + flags + ["-c", src, "-o", obj])
+    if jobs:
+        with ThreadPoolExecutor(max_workers=min(len(jobs), 6)) as ex:
+            list(ex.map(_run, jobs))
+    target = asan_lib_path()
+    if force or jobs or _newer(target, objs):
+        _run([HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-fsanitize=address,undefined", "-fno-gpu-sanitize", "-shared-libsan", "-o", target] + objs + ["-ldl"])
+    return target
+
+
+def asan_runtime():
+    """Path of clang's shared ASan runtime (to LD_PRELOAD into python)."""
+    clang = os.path.join(os.path.dirname(os.path.realpath(HIPCC)), "..", "lib", "llvm", "bin", "clang")
+    if not os.path.exists(clang):
+        clang = "/opt/rocm/lib/llvm/bin/clang"
+    return _run([clang, "-print-file-name=libclang_rt.asan-x86_64.so"]).strip()
+
+
 def node_include_dir():
     for d in ("/usr/include/node", "/usr/local/include/node"):
         if os.path.exists(os.path.join(d, "node_api.h")):

@@ -32,7 +32,8 @@ class OlapError(RuntimeError):
 
 
 def lib_path():
-    return os.path.join(HERE, "lib", "libolapgpu.so")
+    # OLAP_LIBOLAPGPU: another build of the same library (the sanitizer build of tests/_plan_dry_worker.py)
+    return os.environ.get("OLAP_LIBOLAPGPU") or os.path.join(HERE, "lib", "libolapgpu.so")
 
 
 _vp, _u64, _i32, _dbl, _sz = C.c_void_p, C.c_uint64, C.c_int, C.c_double, C.c_size_t

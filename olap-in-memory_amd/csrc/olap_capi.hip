@@ -50,6 +50,15 @@ int hip_fail(hipError_t e, const char *what) {
 #include <mutex>
 #include <unordered_map>
 
+// OLAP_PLAN_DRY=1: plans are validated and BUILT without a device — their index tables land in host memory
+// and olap_plan_run refuses to launch.  A diagnostic (which kernel would a query take?) and the way the
+// planning code (CSR, tile cuts, remap and brick tables) runs under AddressSanitizer / UBSan on a machine
+// without a GPU (tests/test_capi_nogpu.py, tools/asan_host.sh).  Never a compute path.
+static bool plan_dry() {
+  static const bool dry = getenv("OLAP_PLAN_DRY") != nullptr;
+  return dry;
+}
+
 namespace {
 struct DevicePool {
   std::mutex mu;
@@ -67,6 +76,12 @@ struct DevicePool {
     return (bytes + step - 1) / step * step;
   }
   hipError_t alloc(void **out, size_t bytes) {
+    if (plan_dry()) {  // host memory standing in for a plan's tables (see plan_dry)
+      if (posix_memalign(out, 256, round_up(bytes)) != 0) return hipErrorOutOfMemory;
+      std::lock_guard<std::mutex> lock(mu);
+      live[*out] = {-1, round_up(bytes)};
+      return hipSuccess;
+    }
     int dev = 0;
     (void)hipGetDevice(&dev);
     const size_t r = round_up(bytes);
@@ -105,6 +120,10 @@ struct DevicePool {
       }
       key = it->second;
       live.erase(it);
+      if (key.first < 0) {  // dry-plan host block
+        free(p);
+        return;
+      }
       if (idle_bytes + key.second <= cap) {
         idle.insert({key, p});
         idle_bytes += key.second;
@@ -186,7 +205,7 @@ extern "C" int olap_device_count(void) {
 
 int require_device() {
   static thread_local int ok = -1;
-  if (ok == 1) return OLAP_OK;
+  if (ok == 1 || plan_dry()) return OLAP_OK;
   if (olap_device_count() <= 0)
     return fail(OLAP_ERR_NO_DEVICE, "no HIP device available: libolapgpu has no CPU fallback");
   ok = 1;
@@ -272,7 +291,8 @@ static int upload(void **dev, const void *host, size_t bytes) {
   *dev = nullptr;
   if (bytes == 0) bytes = 16;
   HIP_TRY(dev_alloc(dev, bytes));
-  if (host) HIP_TRY(hipMemcpy(*dev, host, bytes, hipMemcpyHostToDevice));
+  if (host && plan_dry()) memcpy(*dev, host, bytes);
+  else if (host) HIP_TRY(hipMemcpy(*dev, host, bytes, hipMemcpyHostToDevice));
   return OLAP_OK;
 }
 
@@ -1560,6 +1580,7 @@ static int run_typed(olap_plan *p, const void *in_v, const int32_t *in_s, void *
 extern "C" int olap_plan_run(olap_plan *p, const void *in_values, const int32_t *in_status,
                              void *out_values, int32_t *out_status, void *stream) {
   if (!p) return fail(OLAP_ERR_INVALID_ARGUMENT, "plan is NULL");
+  if (plan_dry()) return fail(OLAP_ERR_NO_DEVICE, "OLAP_PLAN_DRY is set: plans are built for inspection only; libolapgpu has no CPU fallback");
   if ((p->in_cells && !in_values) || (p->out_cells && !out_values))
     return fail(OLAP_ERR_INVALID_ARGUMENT, "values pointers must not be NULL");
   {

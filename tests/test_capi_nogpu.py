@@ -89,3 +89,33 @@ def test_product_does_not_reference_the_oracle():
                 if re.search(r"oracle", text, flags=re.I):
                     bad.append(os.path.join(base, f))
     assert not bad, bad
+
+
+def _run_dry_worker(extra_env):
+    import subprocess
+    import sys
+
+    env = dict(os.environ, OLAP_PLAN_DRY="1", **extra_env)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_plan_dry_worker.py")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                       text=True, timeout=1500, env=env)
+    assert r.returncode == 0 and "dry planning ok" in r.stdout, r.stdout[-6000:]
+
+
+def test_planning_code_without_a_device():
+    """OLAP_PLAN_DRY=1: every planner (drillUp regimes, dice, fused dice->drillUp, load, reorder forms, drillDown) builds
+    its plan with the tables in host memory; running such a plan is refused (no CPU fallback)."""
+    _run_dry_worker({})
+
+
+def test_planning_code_under_asan_and_ubsan():
+    """the host-side planning code (CSR, tile cuts, remap / brick / transpose tables) under
+    AddressSanitizer + UndefinedBehaviorSanitizer — the same worker against the sanitizer build of libolapgpu
+    (host code instrumented, device code as usual; GPU sanitizers are unavailable on this pool)."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("olap_build_for_asan", os.path.join(ROOT, "olap-in-memory_amd", "build.py"))
+    build = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(build)
+    lib = build.build_lib_asan()
+    _run_dry_worker({"OLAP_LIBOLAPGPU": lib, "LD_PRELOAD": build.asan_runtime(), "ASAN_OPTIONS": "detect_leaks=0",
+                     "UBSAN_OPTIONS": "halt_on_error=1:print_stacktrace=1"})
