@@ -205,6 +205,16 @@ struct Pick {
       cur = v;
     }  // OLAP_FIRST keeps cur
   }
+  // the same as `if (set) add(v)` written as selects: no divergent branch per cell in the streaming kernels
+  __device__ __forceinline__ void add_if(bool set, T v) {
+    T next;
+    if constexpr (METHOD == OLAP_HIGHEST) next = select_max<T>(cur, v);
+    else if constexpr (METHOD == OLAP_LOWEST) next = select_min<T>(cur, v);
+    else if constexpr (METHOD == OLAP_LAST) next = v;
+    else next = cur;
+    cur = set ? (has ? next : v) : cur;
+    has = has || set;
+  }
 };
 
 template <int METHOD> struct IsPick { static constexpr bool value = (METHOD == OLAP_HIGHEST || METHOD == OLAP_LOWEST || METHOD == OLAP_FIRST || METHOD == OLAP_LAST); };

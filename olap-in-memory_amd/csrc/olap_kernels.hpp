@@ -65,9 +65,10 @@ struct Lane {
         if constexpr (METHOD == OLAP_AVERAGE || METHOD == OLAP_PARTIAL_AVERAGE) agg[e].count += Cell<T>::is_default(x, false) ? 0u : 1u;
       } else {
         const int32_t sx = HAS_STATUS ? s.v[e] : OLAP_STATUS_SET;
-        if (cell_is_set<T>(x, sx, HAS_STATUS, def_nan)) {
-          if constexpr (kPick) pick[e].add(x);
-          else agg[e].add(Cell<T>::to_f64(x), def_nan);
+        if constexpr (kPick) {
+          pick[e].add_if(cell_is_set<T>(x, sx, HAS_STATUS, def_nan), x);
+        } else if (cell_is_set<T>(x, sx, HAS_STATUS, def_nan)) {
+          agg[e].add(Cell<T>::to_f64(x), def_nan);
         }
       }
     }
@@ -355,13 +356,16 @@ __global__ __launch_bounds__(kBlock) void drillup_tile_kernel(const T *__restric
     lane.init();
     uint32_t j = ALL ? 0u : l_gstart[g];
     const uint32_t jend = ALL ? (uint32_t)a.K : l_gstart[g + 1];
-    constexpr int UJ = 4;  // independent LDS reads in flight
+    constexpr int UJ = MODE == 0 ? 8 : 4;  // independent LDS reads in flight (interleaved groups: member index, then cell — two dependent reads)
     Vec<T, 1> x[UJ];
     Vec<int32_t, 1> sx[UJ];
     for (; j + UJ <= jend; j += UJ) {
+      uint32_t kk[UJ];
+#pragma unroll
+      for (int u = 0; u < UJ; ++u) kk[u] = MODE == 0 ? l_order[j + u] : (j + u);
 #pragma unroll
       for (int u = 0; u < UJ; ++u) {
-        const uint32_t k = MODE == 0 ? l_order[j + u] : (j + u);
+        const uint32_t k = kk[u];
         x[u].v[0] = tile[base + k * tl.inner];
         sx[u].v[0] = HAS_STATUS ? stile[base + k * tl.inner] : OLAP_STATUS_SET;
       }
