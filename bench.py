@@ -115,8 +115,10 @@ def read_traffic():
     pdir = os.path.join(ROOT, "profiles")
     best = None
     if os.path.isdir(pdir):
+        import re
+
         for f in sorted(os.listdir(pdir)):
-            if f.startswith("traffic_r") and f.endswith(".json"):
+            if re.fullmatch(r"traffic_r\d+\.json", f):  # the per-round summary of the headline launch (tools/summarize_profiles.py)
                 best = os.path.join(pdir, f)
     if not best:
         return None
