@@ -231,6 +231,19 @@ uint64_t olap_store_byte_length(const olap_store *store); /* :8-16 */
 void *olap_store_values_ptr(const olap_store *store);       /* device pointer */
 int32_t *olap_store_status_ptr(const olap_store *store);    /* device pointer */
 
+/* Insertion order of the reference's Map (in-memory.js:298 iterates it; `first` / `last`, keys() and serialize()
+ * depend on it).  A dense buffer has none: by default cells are ordered by flat index, which is the reference's
+ * order for a store filled ascending (`data=`, `fill`) and rolled up while dense.  A TRACKED store keeps the order
+ * exactly — through setValue, data=, fill, drillUp (an output cell sits where its first contributing cell sat),
+ * dice, reorder, drillDown and load — at the price of one more uint32 per cell once the order stops being the flat
+ * index, and of a second pass per operation; results of operations on a tracked store are tracked.
+ * olap_store_from_sparse turns tracking on by itself when its index list is not ascending.
+ * Limits: stores below 2^31 cells; sum / average / product still accumulate in index order (a float64 rounding
+ * difference at most); olap_store_totals refuses a tracked store ("ordered: ..."): run the chain of drillUps.
+ * olap_store_order_tracked: 0 = not tracked, 1 = tracked and still ascending, 2 = tracked with an explicit order. */
+int olap_store_track_order(olap_store *store, int on);
+int olap_store_order_tracked(const olap_store *store);
+
 /* `data` setter (:39-46) from a host typed array of the store's dtype (n must equal size,
  * else OLAP_ERR_LENGTH_MISMATCH) or from JS numbers */
 int olap_store_set_data(olap_store *store, const void *host_values, uint64_t n);
@@ -240,8 +253,8 @@ int olap_store_get_data(const olap_store *store, void *host_values);
 int olap_store_get_data_f64(const olap_store *store, double *host_values);
 int olap_store_get_status(const olap_store *store, int32_t *host_status);
 int olap_store_count_set(const olap_store *store, uint64_t *n_set);
-/* ascending indices of the set cells (the reference's _dataMap.keys() for stores filled in
- * ascending order); `cap` entries available, *n_keys receives the full count */
+/* indices of the set cells in the reference's _dataMap.keys() order: ascending, or the tracked insertion order
+ * (olap_store_track_order); `cap` entries available, *n_keys receives the full count */
 int olap_store_get_keys(const olap_store *store, uint64_t *host_keys, uint64_t cap, uint64_t *n_keys);
 int olap_store_get_value(const olap_store *store, uint64_t index, double *value, int *is_set); /* :118-120 */
 int olap_store_set_value(olap_store *store, uint64_t index, double value, int is_null);       /* :122-133 */

@@ -21,7 +21,7 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 
 KERNEL_UNITS = ["olap_kernels_f32.hip", "olap_kernels_f64.hip", "olap_kernels_i32.hip", "olap_kernels_u32.hip",
-                "olap_capi.hip", "olap_sharded.hip", "olap_transpose.hip", "olap_totals.hip"]
+                "olap_capi.hip", "olap_sharded.hip", "olap_transpose.hip", "olap_totals.hip", "olap_order.hip"]
 HEADERS = ["olap_device.hpp", "olap_kernels.hpp", "olap_internal.hpp", os.path.join(ROOT, "include", "olap_hip.h")]
 
 

@@ -80,6 +80,8 @@ SIGNATURES = {
     "olap_store_byte_length": (_u64, [_vp]),
     "olap_store_values_ptr": (_vp, [_vp]),
     "olap_store_status_ptr": (_vp, [_vp]),
+    "olap_store_track_order": (_i32, [_vp, _i32]),
+    "olap_store_order_tracked": (_i32, [_vp]),
     "olap_store_set_data": (_i32, [_vp, _vp, _u64]),
     "olap_store_set_data_f64": (_i32, [_vp, _pdbl, _u64]),
     "olap_store_get_data": (_i32, [_vp, _vp]),

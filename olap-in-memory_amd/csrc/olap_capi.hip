@@ -1852,6 +1852,8 @@ int store_alloc(olap_store **out, uint64_t size, int dtype, int default_kind) {
   s->status = nullptr;
   s->device = 0;
   (void)hipGetDevice(&s->device);
+  s->maybe_nonempty = true;  // results of operations; olap_store_create clears it
+  s->hi_index = size ? size - 1 : 0;
   const size_t vb = (size ? size : 1) * olap_dtype_size(dtype), sb = (size ? size : 1) * sizeof(int32_t);
   hipError_t e = dev_alloc(&s->values, vb);
   if (e == hipSuccess && mask_is_primary(s)) e = dev_alloc((void **)&s->status, sb);
@@ -1905,14 +1907,27 @@ extern "C" int olap_store_create(olap_store **store, uint64_t size, int dtype, i
     olap_store_destroy(s);
     return rc;
   }
+  s->maybe_nonempty = false;  // nothing written yet: cells that arrive in ascending order stay in ascending order
+  s->hi_index = 0;
   *store = s;
   return OLAP_OK;
 }
+
+/* Insertion order of the reference's Map (see olap_order.hip). */
+extern "C" int olap_store_track_order(olap_store *s, int on) {
+  if (!s) return fail(OLAP_ERR_INVALID_ARGUMENT, "store is NULL");
+  if (on && s->size >= 0x7FFFFFFFull) return fail(OLAP_ERR_INVALID_ARGUMENT, "insertion-order tracking supports stores below 2^31 cells");
+  s->track_order = on != 0;
+  if (!on) order_free(s);
+  return OLAP_OK;
+}
+extern "C" int olap_store_order_tracked(const olap_store *s) { return s && s->track_order ? (s->seq ? 2 : 1) : 0; }
 
 extern "C" void olap_store_destroy(olap_store *s) {
   if (!s) return;
   if (s->values) dev_free(s->values);
   if (s->status) dev_free(s->status);
+  order_free(s);
   delete s;
 }
 
@@ -1927,6 +1942,10 @@ extern "C" int olap_store_clone(const olap_store *s, olap_store **out) {
   if (e != hipSuccess) {
     olap_store_destroy(c);
     return hip_fail(e, "store_clone");
+  }
+  if ((rc = order_clone(s, c))) {
+    olap_store_destroy(c);
+    return rc;
   }
   *out = c;
   return OLAP_OK;
@@ -1962,9 +1981,11 @@ extern "C" int olap_store_set_data(olap_store *s, const void *host_values, uint6
   if (rc) return rc;
   if (n && !host_values) return fail(OLAP_ERR_INVALID_ARGUMENT, "values is NULL");
   if (n == 0) return OLAP_OK;
+  if ((rc = order_before_bulk_write(s))) return rc;
   drop_lazy_status(s);
   HIP_TRY(hipMemcpy(s->values, host_values, n * olap_dtype_size(s->dtype), hipMemcpyHostToDevice));
   if ((rc = olap_canonicalize(s->values, s->status, n, s->dtype, s->default_kind, 0, nullptr))) return rc;
+  if ((rc = order_after_bulk_write(s))) return rc;
   HIP_TRY(hipStreamSynchronize(nullptr));
   return OLAP_OK;
 }
@@ -1974,12 +1995,14 @@ extern "C" int olap_store_set_data_f64(olap_store *s, const double *host_values,
   if (rc) return rc;
   if (n && !host_values) return fail(OLAP_ERR_INVALID_ARGUMENT, "values is NULL");
   if (n == 0) return OLAP_OK;
+  if ((rc = order_before_bulk_write(s))) return rc;
   drop_lazy_status(s);
   double *tmp = nullptr;
   HIP_TRY(dev_alloc((void **)&tmp, n * sizeof(double)));
   hipError_t e = hipMemcpy(tmp, host_values, n * sizeof(double), hipMemcpyHostToDevice);
   if (e == hipSuccess) {
     rc = olap_convert_from_f64(tmp, s->values, s->status, n, s->dtype, s->default_kind, nullptr);
+    if (!rc) rc = order_after_bulk_write(s);
     if (!rc) e = hipStreamSynchronize(nullptr);
   }
   dev_free(tmp);
@@ -2031,6 +2054,14 @@ extern "C" int olap_store_count_set(const olap_store *s, uint64_t *n_set) {
 
 extern "C" int olap_store_get_keys(const olap_store *s, uint64_t *host_keys, uint64_t cap, uint64_t *n_keys) {
   if (!s || !n_keys) return fail(OLAP_ERR_INVALID_ARGUMENT, "store is NULL");
+  if (s->seq) {  // a tracked store whose order is not the flat index: the reference's _dataMap.keys()
+    std::vector<uint64_t> keys;
+    int rco = order_sorted_keys(s, keys);
+    if (rco) return rco;
+    for (uint64_t j = 0; j < keys.size() && host_keys && j < cap; ++j) host_keys[j] = keys[j];
+    *n_keys = keys.size();
+    return OLAP_OK;
+  }
   int rc = ensure_status(s);
   if (rc) return rc;
   std::vector<int32_t> st(s->size ? s->size : 1);
@@ -2077,8 +2108,11 @@ extern "C" int olap_store_get_value(const olap_store *s, uint64_t index, double 
 extern "C" int olap_store_set_value(olap_store *s, uint64_t index, double value, int is_null) {
   if (!s) return fail(OLAP_ERR_INVALID_ARGUMENT, "store is NULL");
   if (index >= s->size) return fail(OLAP_ERR_INDEX_RANGE, "cell index %llu out of bounds [0, %llu[", (unsigned long long)index, (unsigned long long)s->size);
+  int rc = order_before_set_value(s, index);
+  if (rc) return rc;
   hipError_t e = hipSuccess;
   DISPATCH_DTYPE(s->dtype, e = Launch<T>::set_cell((T *)s->values, s->status, index, value, is_null, s->default_kind == OLAP_DEFAULT_NAN, nullptr));
+  if (e == hipSuccess && (rc = order_after_set_value(s, index))) return rc;
   if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
   if (e != hipSuccess) return hip_fail(e, "set_value");
   return OLAP_OK;
@@ -2088,6 +2122,8 @@ extern "C" int olap_store_fill(olap_store *s, double value) {
   if (!s) return fail(OLAP_ERR_INVALID_ARGUMENT, "store is NULL");
   if (!s->size) return OLAP_OK;
   // fill = setValue(i, value) for every i (:135-137): one converted cell, broadcast
+  int rc0 = order_before_bulk_write(s);
+  if (rc0) return rc0;
   drop_lazy_status(s);
   std::vector<double> one(1, value);
   double *tmp = nullptr;
@@ -2108,6 +2144,7 @@ extern "C" int olap_store_fill(olap_store *s, double value) {
     if (s->status) HIP_TRY(hipMemcpyAsync(s->status + done, s->status, n * sizeof(int32_t), hipMemcpyDeviceToDevice, nullptr));
     done += n;
   }
+  if ((rc = order_after_bulk_write(s))) return rc;
   HIP_TRY(hipStreamSynchronize(nullptr));
   return OLAP_OK;
 }
@@ -2188,6 +2225,25 @@ extern "C" int olap_store_to_sparse(const olap_store *s, uint32_t *host_indexes,
     if (e == hipSuccess) e = hipMemcpy(host_values, dev_val, total * es, hipMemcpyDeviceToHost);
     if (dev_idx) dev_free(dev_idx);
     if (dev_val) dev_free(dev_val);
+    if (e == hipSuccess && s->seq) {
+      // serialize() writes the Map's entries in insertion order (in-memory.js:94-100): permute the ascending lists
+      std::vector<uint64_t> keys;
+      int rco = order_sorted_keys(s, keys);
+      if (rco) {
+        dev_free(dev_counts);
+        return rco;
+      }
+      if (keys.size() == total) {
+        std::vector<uint32_t> pos(s->size, 0u);  // ascending rank of every set cell
+        for (uint64_t j = 0; j < total; ++j) pos[host_indexes[j]] = (uint32_t)j;
+        std::vector<unsigned char> vals((size_t)total * es);
+        memcpy(vals.data(), host_values, vals.size());
+        for (uint64_t j = 0; j < total; ++j) {
+          host_indexes[j] = (uint32_t)keys[j];
+          memcpy((char *)host_values + j * es, vals.data() + (size_t)pos[keys[j]] * es, es);
+        }
+      }
+    }
   }
   dev_free(dev_counts);
   if (e != hipSuccess) return hip_fail(e, "to_sparse");
@@ -2233,6 +2289,10 @@ extern "C" int olap_store_from_sparse(olap_store **store, uint64_t size, int dty
       return hip_fail(e, "from_sparse");
     }
     // setValue semantics: a listed default value leaves the cell unset (float cells: implied by the value)
+  }
+  if ((rc = order_after_from_sparse(s, host_indexes, n))) {
+    olap_store_destroy(s);
+    return rc;
   }
   *store = s;
   return OLAP_OK;
@@ -2358,6 +2418,12 @@ static bool bad_dims(int ndim, const void *a, const void *b) { return ndim < 0 |
 extern "C" int olap_store_drillup(const olap_store *s, olap_store **out, int ndim, const uint32_t *old_len,
                                   const uint32_t *new_len, const uint32_t *const *maps, int method) {
   if (!s || !out) return fail(OLAP_ERR_INVALID_ARGUMENT, "store is NULL");
+  if (s->track_order && !bad_dims(ndim, old_len, new_len) && (ndim == 0 || maps)) return order_drillup(s, out, ndim, old_len, new_len, maps, method);
+  return store_drillup_plain(s, out, ndim, old_len, new_len, maps, method);
+}
+
+int store_drillup_plain(const olap_store *s, olap_store **out, int ndim, const uint32_t *old_len, const uint32_t *new_len,
+                        const uint32_t *const *maps, int method) {
   *out = nullptr;
   olap_plan *plan = nullptr;
   PlanKey key;
@@ -2390,9 +2456,9 @@ extern "C" int olap_store_drillup(const olap_store *s, olap_store **out, int ndi
   return rc;
 }
 
-extern "C" int olap_store_drilldown(const olap_store *s, olap_store **out, int ndim, const uint32_t *old_len,
-                                    const uint32_t *new_len, const uint32_t *const *maps, int method,
-                                    const double *distributions, uint64_t n_dist) {
+static int store_drilldown_plain(const olap_store *s, olap_store **out, int ndim, const uint32_t *old_len,
+                                 const uint32_t *new_len, const uint32_t *const *maps, int method,
+                                 const double *distributions, uint64_t n_dist) {
   if (!s || !out) return fail(OLAP_ERR_INVALID_ARGUMENT, "store is NULL");
   *out = nullptr;
   // not cached: plans with distributions carry a per-run error word, and drillDown is rare
@@ -2405,8 +2471,16 @@ extern "C" int olap_store_drilldown(const olap_store *s, olap_store **out, int n
   return rc;
 }
 
-extern "C" int olap_store_dice(const olap_store *s, olap_store **out, int ndim, const uint32_t *old_len,
-                               const uint32_t *new_len, const int32_t *const *sel) {
+extern "C" int olap_store_drilldown(const olap_store *s, olap_store **out, int ndim, const uint32_t *old_len,
+                                    const uint32_t *new_len, const uint32_t *const *maps, int method,
+                                    const double *distributions, uint64_t n_dist) {
+  int rc = store_drilldown_plain(s, out, ndim, old_len, new_len, maps, method, distributions, n_dist);
+  if (!rc && s->track_order) rc = order_after_drilldown(s, *out);
+  return rc;
+}
+
+static int store_dice_plain(const olap_store *s, olap_store **out, int ndim, const uint32_t *old_len,
+                            const uint32_t *new_len, const int32_t *const *sel) {
   if (!s || !out) return fail(OLAP_ERR_INVALID_ARGUMENT, "store is NULL");
   *out = nullptr;
   olap_plan *plan = nullptr;
@@ -2439,11 +2513,35 @@ extern "C" int olap_store_dice(const olap_store *s, olap_store **out, int ndim, 
   return rc;
 }
 
+// an operation on a tracked store failed after its result was allocated
+static int drop_result(olap_store **out, int rc) {
+  if (rc && out && *out) {
+    olap_store_destroy(*out);
+    *out = nullptr;
+  }
+  return rc;
+}
+
+extern "C" int olap_store_dice(const olap_store *s, olap_store **out, int ndim, const uint32_t *old_len,
+                               const uint32_t *new_len, const int32_t *const *sel) {
+  int rc = store_dice_plain(s, out, ndim, old_len, new_len, sel);
+  if (!rc && s->track_order) rc = drop_result(out, order_after_dice(s, *out, ndim, old_len, new_len, sel));
+  return rc;
+}
+
 extern "C" int olap_store_dice_drillup(const olap_store *s, olap_store **out, int ndim, const uint32_t *old_len,
                                        const uint32_t *mid_len, const uint32_t *new_len, const int32_t *const *sel,
                                        const uint32_t *const *maps, int method) {
   if (!s || !out) return fail(OLAP_ERR_INVALID_ARGUMENT, "store is NULL");
   *out = nullptr;
+  if (s->track_order) {  // the order of the diced intermediate matters: the two operations, one after the other
+    olap_store *mid = nullptr;
+    int rc = olap_store_dice(s, &mid, ndim, old_len, mid_len, sel);
+    if (rc) return rc;
+    rc = olap_store_drillup(mid, out, ndim, mid_len, new_len, maps, method);
+    olap_store_destroy(mid);
+    return rc;
+  }
   olap_plan *plan = nullptr;
   PlanKey key;
   if (!bad_dims(ndim, old_len, mid_len) && !bad_dims(ndim, mid_len, new_len) && (ndim == 0 || (sel && maps))) {
@@ -2475,8 +2573,7 @@ extern "C" int olap_store_dice_drillup(const olap_store *s, olap_store **out, in
   return rc;
 }
 
-extern "C" int olap_store_reorder(const olap_store *s, olap_store **out, int ndim, const uint32_t *old_len,
-                                  const int32_t *perm) {
+static int store_reorder_plain(const olap_store *s, olap_store **out, int ndim, const uint32_t *old_len, const int32_t *perm) {
   if (!s || !out) return fail(OLAP_ERR_INVALID_ARGUMENT, "store is NULL");
   *out = nullptr;
   olap_plan *plan = nullptr;
@@ -2504,8 +2601,27 @@ extern "C" int olap_store_reorder(const olap_store *s, olap_store **out, int ndi
   return rc;
 }
 
+extern "C" int olap_store_reorder(const olap_store *s, olap_store **out, int ndim, const uint32_t *old_len,
+                                  const int32_t *perm) {
+  int rc = store_reorder_plain(s, out, ndim, old_len, perm);
+  if (!rc && s->track_order) rc = drop_result(out, order_after_reorder(s, *out, ndim, old_len, perm));
+  return rc;
+}
+
+static int store_load_plain(olap_store *s, const olap_store *other, int ndim, const uint32_t *my_len, const uint32_t *his_len,
+                            const int32_t *const *his_to_mine);
+
 extern "C" int olap_store_load(olap_store *s, const olap_store *other, int ndim, const uint32_t *my_len,
                                const uint32_t *his_len, const int32_t *const *his_to_mine) {
+  if (!s || !other) return fail(OLAP_ERR_INVALID_ARGUMENT, "store is NULL");
+  int rc = order_before_load(s);
+  if (!rc) rc = store_load_plain(s, other, ndim, my_len, his_len, his_to_mine);
+  if (!rc) rc = order_after_load(s, other, ndim, my_len, his_len, his_to_mine);
+  return rc;
+}
+
+static int store_load_plain(olap_store *s, const olap_store *other, int ndim, const uint32_t *my_len, const uint32_t *his_len,
+                            const int32_t *const *his_to_mine) {
   if (!s || !other) return fail(OLAP_ERR_INVALID_ARGUMENT, "store is NULL");
   if (s->dtype != other->dtype) return fail(OLAP_ERR_INVALID_TYPE, "load: stores have different cell types");
   olap_plan *plan = nullptr;

@@ -5,6 +5,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <vector>
+
 #include "../../include/olap_hip.h"
 
 #define OLAP_INTERNAL __attribute__((visibility("hidden")))
@@ -45,6 +47,14 @@ struct olap_store {
   int device;               // the HIP device the buffers live on
   void *values;
   mutable int32_t *status;  // nullptr until needed
+  // Insertion order of the reference's Map (in-memory.js:298 iterates it), kept only on request
+  // (olap_store_track_order) and only once it differs from ascending flat index: seq[i] > 0 <=> cell i is set,
+  // and set cells compare by seq as the reference's Map entries compare by age.  olap_order.hip.
+  bool track_order = false;
+  mutable uint32_t *seq = nullptr;   // nullptr: the order is the ascending flat index
+  mutable uint64_t next_seq = 1;     // next value to hand out
+  bool maybe_nonempty = false;       // some cell may be set (false only for a store nothing was written to)
+  uint64_t hi_index = 0;             // no set cell lies above this index (valid while seq == nullptr)
 };
 
 OLAP_INTERNAL bool mask_is_primary(const olap_store *s);
@@ -72,3 +82,26 @@ struct TransposeXY {
   int default_test;                          // how a generated mask tells the default: 0 int/0, 1 float/0, 2 float/NaN, 3 never
 };
 OLAP_INTERNAL hipError_t launch_transpose_xy(const TransposeXY &t, const void *in, void *out, int32_t *st_out, bool aligned16, hipStream_t stream);
+
+// ---- insertion order of tracked stores (olap_order.hip) --------------------------------------------
+OLAP_INTERNAL void order_free(olap_store *s);
+OLAP_INTERNAL int order_clone(const olap_store *from, olap_store *to);
+OLAP_INTERNAL int order_before_bulk_write(olap_store *s);
+OLAP_INTERNAL int order_after_bulk_write(olap_store *s);
+OLAP_INTERNAL int order_before_set_value(olap_store *s, uint64_t index);
+OLAP_INTERNAL int order_after_set_value(olap_store *s, uint64_t index);
+OLAP_INTERNAL int order_after_from_sparse(olap_store *s, const uint32_t *host_indexes, uint64_t n);
+OLAP_INTERNAL int order_drillup(const olap_store *s, olap_store **out, int ndim, const uint32_t *old_len, const uint32_t *new_len,
+                                const uint32_t *const *maps, int method);
+OLAP_INTERNAL int order_after_dice(const olap_store *s, olap_store *out, int ndim, const uint32_t *old_len, const uint32_t *new_len,
+                                   const int32_t *const *sel);
+OLAP_INTERNAL int order_after_reorder(const olap_store *s, olap_store *out, int ndim, const uint32_t *old_len, const int32_t *perm);
+OLAP_INTERNAL int order_after_drilldown(const olap_store *s, olap_store *out);
+OLAP_INTERNAL int order_before_load(olap_store *mine);
+OLAP_INTERNAL int order_after_load(olap_store *mine, const olap_store *his, int ndim, const uint32_t *my_len, const uint32_t *his_len,
+                                   const int32_t *const *his_to_mine);
+// host copy of the set cells' indices in insertion order (ascending when the store has no seq)
+OLAP_INTERNAL int order_sorted_keys(const olap_store *s, std::vector<uint64_t> &keys);
+// the untracked operations of olap_capi.hip (what the public entry points do for a store that is not tracked)
+OLAP_INTERNAL int store_drillup_plain(const olap_store *s, olap_store **out, int ndim, const uint32_t *old_len, const uint32_t *new_len,
+                                      const uint32_t *const *maps, int method);

@@ -245,6 +245,8 @@ extern "C" int olap_store_totals(const olap_store *st, int ndim, const uint32_t 
   if (ndim < 0 || ndim > kTotalsMaxDims) return fail(OLAP_ERR_INVALID_ARGUMENT, "totals: at most %d dimensions", kTotalsMaxDims);
   if (ndim > 0 && (!lens || !methods)) return fail(OLAP_ERR_INVALID_ARGUMENT, "lens/methods is NULL");
   if (!host_values) return fail(OLAP_ERR_INVALID_ARGUMENT, "values is NULL");
+  if (st->track_order)  // every intermediate marginal has an order of its own (first hit), which later `first` / `last` stages follow
+    return fail(OLAP_ERR_INVALID_ARGUMENT, "ordered: this store tracks its insertion order; run the chain of drillUps instead");
   TotalsShape s{};
   s.nd = ndim;
   s.def_nan = st->default_kind == OLAP_DEFAULT_NAN;

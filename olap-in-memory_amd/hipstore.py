@@ -220,6 +220,15 @@ class HipStore:
         check(self._lib.olap_store_total(self._h, C.byref(t)))
         return t.value
 
+    def track_order(self, on=True):
+        """olap_store_track_order: keep the reference Map's insertion order (first / last, keys(), serialize())."""
+        check(self._lib.olap_store_track_order(self._h, 1 if on else 0))
+        return self
+
+    @property
+    def order_tracked(self):
+        return int(self._lib.olap_store_order_tracked(self._h))
+
     def count_set(self):
         n = C.c_uint64()
         check(self._lib.olap_store_count_set(self._h, C.byref(n)))

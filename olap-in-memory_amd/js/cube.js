@@ -93,6 +93,10 @@ class Cube {
     this._checkNewMeasure(measureId);
     this.storedMeasures[measureId] = new HipStore(this.storeSize, type, defaultValue, undefined, this.dimensions.map((d) => d.numItems));
     this.storedMeasuresRules[measureId] = rules;
+    // `first` / `last` follow the Map's insertion order in the reference (in-memory.js:298): such measures keep it
+    // (a measure split over several devices keeps the flat-index order: its shards combine in row order)
+    const store = this.storedMeasures[measureId];
+    if (!store._native.isSharded && Object.values(rules || {}).some((rule) => rule === 'first' || rule === 'last')) store.trackOrder();
   }
 
   /**
@@ -177,6 +181,7 @@ class Cube {
     if (origin === undefined) throw new Error(`This measure does not exists in originCube: ${measureId}`);
     this.storedMeasuresRules[measureId] = Object.assign({}, originCube.storedMeasuresRules[measureId]);
     this.storedMeasures[measureId] = new HipStore(this.storeSize, origin._type, origin._defaultValue, undefined, this.dimensions.map((d) => d.numItems));
+    if (origin.orderTracked && !this.storedMeasures[measureId]._native.isSharded) this.storedMeasures[measureId].trackOrder();
   }
 
   renameMeasure(oldMeasureId, newMeasureId) {
@@ -301,8 +306,10 @@ class Cube {
     // results are the cells of ONE extended cube with an 'all' item appended to every dimension; a stored
     // measure gets it from a single store call (olap_store_totals: one launch that reads the cube once
     // when the extended cube fits in LDS, D + 2 launches otherwise) — same chain order, same rounding.
-    const stored = measureIds.filter((id) => this.storedMeasures[id] !== undefined);
-    const others = measureIds.filter((id) => this.storedMeasures[id] === undefined);
+    // (a measure that tracks its insertion order takes the chain too: every marginal has an order of its own)
+    const direct = (id) => this.storedMeasures[id] !== undefined && !this.storedMeasures[id].orderTracked;
+    const stored = measureIds.filter(direct);
+    const others = measureIds.filter((id) => !direct(id));
     const extended = this.dimensions.map((d) => ({ getItems: () => d.getItems().concat(['all']) }));
     let result = {};
     for (const id of stored) {
@@ -659,6 +666,8 @@ class Cube {
     cube.storedMeasuresRules = data.storedMeasuresRules || {};
     data.storedMeasuresKeys.forEach((id, i) => {
       cube.storedMeasures[id] = HipStore.deserialize(data.storedMeasures[i]);
+      // (a blob whose cells are not listed in ascending order keeps that order by itself, olap_store_from_sparse)
+      if (Object.values(cube.storedMeasuresRules[id] || {}).some((rule) => rule === 'first' || rule === 'last')) cube.storedMeasures[id].trackOrder();
     });
     for (const id of Object.keys(data.computedMeasures || {})) cube.computedMeasures[id] = getParser().parse(data.computedMeasures[id]);
     return cube;

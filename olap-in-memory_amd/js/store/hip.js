@@ -162,6 +162,24 @@ class HipStore {
     return this._nativeStore;
   }
 
+  /**
+   * Keep the reference Map's INSERTION order for this measure (in-memory.js:298): `first` / `last`, `_dataMap.keys()`
+   * and serialize() then answer exactly as the reference does after out-of-order setValue calls, roll-ups of sparse
+   * cubes, permuting dices and reorders.  Costs a second pass per operation once the order leaves the flat index;
+   * Cube turns it on for measures with a `first` / `last` rule.  Results of operations inherit it.  (One device only:
+   * a sharded measure is gathered first.)
+   */
+  trackOrder(on = true) {
+    if (this._native.isSharded) this._nativeStore = this._native.gather();
+    this._writable.trackOrder(on);
+    return this;
+  }
+
+  get orderTracked() {
+    const native = this._pending ? this._pending.source : this._nativeStore;
+    return native && !native.isSharded ? native.orderTracked : 0;
+  }
+
   /** The measure as ONE device store: a sharded measure is gathered (what the shards cannot answer in place). */
   get _whole() {
     const native = this._native;
@@ -298,6 +316,8 @@ class HipStore {
       return new HipStore(size, this._type, this._defaultValue, { source: p.source, oldLen: p.oldLen, midLen: allLen, sel: all });
     }
     const source = this._native; // (materialises a pending selection whose dimensions no longer line up)
+    // a tracked measure: the diced store has an order of its own that the next operation must see
+    if (!source.isSharded && source.orderTracked) return this._wrap(source.dice(lengthsOf(oldDimensions), midLen, composed));
     this._lent = true;
     return new HipStore(size, this._type, this._defaultValue, { source, oldLen: lengthsOf(oldDimensions), midLen, sel: composed });
   }

@@ -347,6 +347,25 @@ static napi_value StoreTotal(napi_env env, napi_callback_info info) {
   return num(env, t);
 }
 
+// trackOrder(on = true): keep the reference Map's insertion order (olap_store_track_order)
+static napi_value StoreTrackOrder(napi_env env, napi_callback_info info) {
+  STORE_METHOD_PROLOGUE(1)
+  bool on = true;
+  if (argc > 0) {
+    napi_valuetype t;
+    NAPI_OK(napi_typeof(env, argv[0], &t));
+    if (t == napi_boolean) NAPI_OK(napi_get_value_bool(env, argv[0], &on));
+  }
+  int rc = olap_store_track_order(s, on ? 1 : 0);
+  if (rc) return throw_olap(env, rc);
+  return nullptr;
+}
+// orderTracked: 0 = not tracked, 1 = tracked and still ascending, 2 = tracked with an explicit order
+static napi_value StoreOrderTracked(napi_env env, napi_callback_info info) {
+  STORE_METHOD_PROLOGUE(0)
+  return num(env, olap_store_order_tracked(s));
+}
+
 static napi_value StoreClone(napi_env env, napi_callback_info info) {
   STORE_METHOD_PROLOGUE(0)
   olap_store *c = nullptr;
@@ -1064,6 +1083,8 @@ static napi_value Init(napi_env env, napi_value exports) {
       {"total", nullptr, StoreTotal, nullptr, nullptr, nullptr, napi_default, nullptr},
       {"toSparse", nullptr, StoreToSparse, nullptr, nullptr, nullptr, napi_default, nullptr},
       {"totals", nullptr, StoreTotals, nullptr, nullptr, nullptr, napi_default, nullptr},
+      {"trackOrder", nullptr, StoreTrackOrder, nullptr, nullptr, nullptr, napi_default, nullptr},
+      {"orderTracked", nullptr, nullptr, StoreOrderTracked, nullptr, nullptr, napi_default, nullptr},
       {"clone", nullptr, StoreClone, nullptr, nullptr, nullptr, napi_default, nullptr},
       {"drillUp", nullptr, StoreDrillUp, nullptr, nullptr, nullptr, napi_default, nullptr},
       {"drillDown", nullptr, StoreDrillDown, nullptr, nullptr, nullptr, napi_default, nullptr},

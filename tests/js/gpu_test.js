@@ -667,4 +667,33 @@ describe('BASELINE config 1 through the Cube API', () => {
   });
 });
 
+describe('insertion order (measures with a first / last rule keep the reference Map order)', () => {
+  const make = (rules) => {
+    const cube = new Cube([new GenericDimension('period', 'season', ['summer', 'winter']), new GenericDimension('location', 'city', ['paris', 'toledo', 'tokyo'])]);
+    cube.createStoredMeasure('mm', rules, 'float32', 0);
+    // object key order = insertion order (src/cube.js:479): cells 5, 3, 1
+    cube.hydrateFromSparseNestedObject('mm', { winter: { tokyo: 5, paris: 6 }, summer: { toledo: 7 } });
+    return cube;
+  };
+  it('keys(), first-hit order of a roll-up, last by insertion order', () => {
+    const cube = make({ period: 'first', location: 'last' });
+    assert.equal(cube.storedMeasures.mm.orderTracked, 2);
+    assert.deepEqual(Array.from(cube.getStatusMap('mm').keys()), [5, 3, 1]);
+    const byCity = cube.drillUp('period', 'all');
+    assert.deepEqual(byCity.getData('mm'), [6, 7, 5]);
+    assert.deepEqual(Array.from(byCity.getStatusMap('mm').keys()), [2, 0, 1]); // tokyo was visited first, then paris, then toledo
+    assert.deepEqual(byCity.drillUp('location', 'all').getData('mm'), [7]); // the LAST inserted: toledo (by index it would be tokyo's 5)
+    assert.deepEqual(cube.collapse().getData('mm'), [7]);
+    assert.deepEqual(cube.getNestedObject('mm', true).all, { paris: 6, toledo: 7, tokyo: 5, all: 7 });
+    const back = Cube.deserialize(cube.serialize());
+    assert.deepEqual(Array.from(back.getStatusMap('mm').keys()), [5, 3, 1]);
+    assert.deepEqual(back.drillUp('period', 'all').drillUp('location', 'all').getData('mm'), [7]);
+  });
+  it('a measure without such a rule is not tracked and answers by flat index', () => {
+    const cube = make({ period: 'sum', location: 'sum' });
+    assert.equal(cube.storedMeasures.mm.orderTracked, 0);
+    assert.deepEqual(Array.from(cube.getStatusMap('mm').keys()), [1, 3, 5]);
+  });
+});
+
 run();
