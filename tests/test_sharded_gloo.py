@@ -161,3 +161,22 @@ def test_sharded_single_process():
     r = subprocess.run([sys.executable, os.path.join(HERE, "_sharded_single_process.py")], stdout=subprocess.PIPE,
                        stderr=subprocess.STDOUT, text=True, timeout=900)
     assert r.returncode == 0 and "sharded single-process ok" in r.stdout, r.stdout[-6000:]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,world", [([10] * 9, 3), ([320, 5, 5, 5, 5, 5, 5, 10, 20], 4)], ids=["literal-3-ranks", "friendly-4-ranks"])
+def test_config4_sharded_on_one_gpu(shape, world):
+    """BASELINE configs[3] at full size (10^9 cells), sharded on dim0 over `world` processes that share the one GPU:
+    rows 4 + 3 + 3 of the literal [10]^9 (400 MB partials), 80 rows per rank of the shard-friendly shape.  The
+    drillUp that collapses the sharded axis runs through the product's sharded store and step; gloo stands in for
+    RCCL.  Every rank checks slices of its block of the scattered result against float64 column sums."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29571 + world), WORLD_SIZE=str(world))
+    procs = []
+    for r in range(world):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "_sharded_big_worker.py"), ",".join(str(x) for x in shape)], env=e,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    logs = [p.communicate(timeout=900)[0] for p in procs]
+    for p, log in zip(procs, logs):
+        assert p.returncode == 0, log[-4000:]
+    assert "sharded 10^9 ok" in logs[0]
