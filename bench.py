@@ -290,6 +290,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="N = 1: only the headline workload")
     ap.add_argument("--serial-steps", action="store_true", help="N > 1: no overlap between consecutive steps")
+    ap.add_argument("--force-sharded", action="store_true",
+                    help="developer aid: run the N > 1 code path (sharded store, RCCL communicator, reduce-scatter) with the ranks given, "
+                         "even one — on a 1-GPU box this drives every line of that path through a one-rank RCCL communicator")
     ap.add_argument("--rehearse", action="store_true",
                     help="developer aid: the N ranks share cuda:0 and gloo carries the payloads (exercises the N > 1 code path on "
                          "a 1-GPU box with a 10x smaller cube; the numbers are meaningless)")
@@ -339,7 +342,8 @@ def main():
         return float(t.item())
 
     extra = {}
-    if world == 1:
+    sharded_path = world > 1 or args.force_sharded
+    if not sharded_path:
         lens = [10] * 8
         workload = "drillUp(sum) dimension0->all, 8-dim 10^8-cell Float32 cube [10]*8, all cells set"
         n = int(np.prod(lens))
@@ -365,7 +369,12 @@ def main():
         lens = list(FRIENDLY_SHAPE)
         if args.rehearse:
             lens[-1] = 2  # 10^8 cells: gloo moves the payloads through host memory
-        comm = Comm.detached(world, rank, 0) if args.rehearse else Comm.from_process_group(dist, local_rank)
+        if args.rehearse:
+            comm = Comm.detached(world, rank, 0)
+        elif world > 1:
+            comm = Comm.from_process_group(dist, local_rank)
+        else:
+            comm = Comm.init_rank(Comm.unique_id(), 1, 0, local_rank)
         transport = comm.transport
         store = ShardedStore(comm, lens, "float32", 0.0).fill_seeded(20240807, 1.0)
         pipelined = not (args.serial_steps or args.rehearse)
@@ -422,7 +431,23 @@ def main():
     alg_bytes = local_cells * 4 + n_out * 4
     achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
 
-    if world > 1 and not args.rehearse:
+    if sharded_path and not args.rehearse and pipelined:
+        # the same steps strictly one after the other (no overlap between the exchange of one query and the local
+        # reduction of the next): what a single query costs end to end
+        sop = store.plan_drillup_dim0(np.zeros(lens[0], np.uint32), 1, "sum", placement=capi.PLACE_SCATTER, depth=1)
+        k_ser = max(2, min(args.steps, 50))
+        for _ in range(3):
+            sop.step(vals, stat, [stream])
+        barrier()
+        ts = time.perf_counter()
+        for _ in range(k_ser):
+            sop.step(vals, stat, [stream])
+        barrier()
+        ser_elapsed = max_over_ranks(time.perf_counter() - ts)
+        extra["serial_steps"] = {"steps": k_ser, "ms_per_step": ser_elapsed / k_ser * 1e3, "cells_per_s": total_cells * k_ser / ser_elapsed,
+                                 "note": "depth 1: local reduction, reduce-scatter and finish of each step before the next one starts"}
+        del sop
+    if sharded_path and not args.rehearse:
         # the literal [10]^9 shape of configs[3] beside the headline: rows split 2,2,1,1,... at N = 8 and every
         # rank ships a 400 MB partial, so the collective dominates; fewer steps, same protocol
         del op, store
@@ -448,7 +473,7 @@ def main():
 
     with_mask = None
     ceiling = None
-    if world == 1:
+    if not sharded_path:
         ceiling = read_ceiling(pkg, engine, torch, values, n * 4)
         if not args.no_extras:
             # the same launch with the Int32 status mask read and written (10 % of the cells unset)
@@ -516,14 +541,14 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
             # N = 1 is the 10^8-cell headline; every N > 1 runs the SAME 10^9 cells (config4_single_gpu is their N = 1 point)
-            "scaling": "weak" if world == 1 else "strong",
+            "scaling": "strong" if sharded_path else "weak",
             "vs_baseline": None,
             "dtype": "f64",  # the arithmetic type: float64 accumulators over Float32 cells (config.cell_type)
             "data": "synthetic (seeded mulberry32, values in [0.5,1.5), generated on device)",
             "config": {"workload": workload, "shape": lens, "cells_per_gpu": local_cells, "cell_type": "float32",
                        "kernel": kernel_name, "collective": collective, "transport": transport, "steps_pipelined": bool(pipelined)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": read_traffic() if world == 1 else None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None if sharded_path else read_traffic(),
                          "kernel_ms": kernel_ms, "algorithmic_bytes": alg_bytes,
                          "hbm_read_frac": local_cells * 4 / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
         }
@@ -533,7 +558,7 @@ def main():
         if with_mask:
             line["with_status_mask"] = with_mask
         line.update(extra)
-        if world == 1 and not args.no_cpu_baseline:
+        if not sharded_path and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
             line["cpu_baseline_flat"] = cpu_baseline_flat()
             line["cpu_baseline_js"] = cpu_baseline_js()

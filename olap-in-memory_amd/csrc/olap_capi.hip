@@ -1001,6 +1001,8 @@ extern "C" int olap_reorder_plan(olap_plan **out, int dtype, int default_kind, i
       }
       t.super = 1;  // walking tiles in 2 x 2 .. 8 x 8 blocks was measured and bought nothing
       if (const char *e = getenv("OLAP_XY_SUPER")) t.super = std::max(1, atoi(e));
+      t.y_first = 0;
+      if (const char *e = getenv("OLAP_XY_ORDER")) t.y_first = e[0] == 'y';
       t.tiles_x = (t.lx + t.tx - 1) / t.tx;
       t.tiles_y = (t.ly + t.ty - 1) / t.ty;
       t.vec_in = in4 && t.lx % 4 == 0;

@@ -47,10 +47,18 @@ __global__ __launch_bounds__(kBlock) void transpose_xy_kernel(const uint32_t *__
   const uint32_t in_super = (uint32_t)(c % (kSuper * kSuper));
   c /= kSuper * kSuper;
   const uint64_t sx_n = (t.tiles_x + kSuper - 1) / kSuper, sy_n = (t.tiles_y + kSuper - 1) / kSuper;
-  const uint32_t tx = (uint32_t)(c % sx_n) * kSuper + in_super % kSuper;
-  c /= sx_n;
-  const uint32_t ty = (uint32_t)(c % sy_n) * kSuper + in_super / kSuper;
-  c /= sy_n;
+  uint32_t tx, ty;
+  if (t.y_first) {  // neighbouring workgroups write neighbouring pieces of the same destination rows
+    ty = (uint32_t)(c % sy_n) * kSuper + in_super / kSuper;
+    c /= sy_n;
+    tx = (uint32_t)(c % sx_n) * kSuper + in_super % kSuper;
+    c /= sx_n;
+  } else {  // ... read neighbouring pieces of the same source rows
+    tx = (uint32_t)(c % sx_n) * kSuper + in_super % kSuper;
+    c /= sx_n;
+    ty = (uint32_t)(c % sy_n) * kSuper + in_super / kSuper;
+    c /= sy_n;
+  }
   if (tx >= t.tiles_x || ty >= t.tiles_y) return;  // the grid is padded to whole super-tiles
   uint64_t base_in = 0, base_out = 0;
 #pragma unroll

@@ -33,3 +33,33 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     # whole-job throughput and the per-step time describe the same run
     cells = d["config"]["cells_per_gpu"]
     assert abs(d["value"] - cells / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
+
+
+@pytest.mark.gpu
+def test_bench_sharded_code_path_on_one_rank():
+    """`--force-sharded` drives every line of bench.py's N > 1 path — sharded store, RCCL communicator made with
+    olap_comm_init_rank, pipelined reduce-scatter steps, the serial-steps figure, the literal [10]^9 shape — with a
+    one-rank communicator, so API misuse shows up on a 1-GPU box and not on the driver's 8-GPU run."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--force-sharded", "--steps", "4", "--warmup", "1"], stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-4000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.strip()][-1])
+    assert d["n_gpus"] == 1 and d["scaling"] == "strong" and d["config"]["transport"] == "rccl" and d["config"]["collective"] == "reduce_scatter"
+    assert d["config"]["shape"] == [320, 5, 5, 5, 5, 5, 5, 10, 20] and d["config"]["cells_per_gpu"] == 10 ** 9
+    assert d["serial_steps"]["ms_per_step"] > 0 and d["literal_shape"]["rows_per_rank"] == [10]
+    assert abs(d["value"] - 1e9 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
+    assert 0.3 < d["roofline"]["frac"] < 1.0
+
+
+@pytest.mark.gpu
+def test_bench_starts_its_own_ranks():
+    """`python3 bench.py --gpus 2 --rehearse` from a bare interpreter: the script launches its two ranks itself (child
+    processes, before this process touches the GPU) and relays rank 0's line (the ranks share the one GPU over gloo)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rehearse", "--steps", "3", "--warmup", "1"], stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["transport"] == "detached" and d["config"]["cells_per_gpu"] == 5 * 10 ** 7
