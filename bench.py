@@ -301,6 +301,15 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         launch_ranks(args)
 
+    # RCCL prints a version banner on standard output when a communicator is created; the contract is ONE JSON line
+    # there.  With more than one rank (or --force-sharded) everything else this process and its libraries print goes to
+    # standard error, and the line is written to the real standard output at the end.
+    real_stdout = None
+    if args.gpus > 1 or args.force_sharded:
+        sys.stdout.flush()
+        real_stdout = os.dup(1)
+        os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
 
@@ -562,7 +571,11 @@ def main():
             line["cpu_baseline"] = cpu_baseline()
             line["cpu_baseline_flat"] = cpu_baseline_flat()
             line["cpu_baseline_js"] = cpu_baseline_js()
-        print(json.dumps(line))
+        if real_stdout is not None:
+            sys.stdout.flush()
+            os.write(real_stdout, (json.dumps(line) + "\n").encode())
+        else:
+            print(json.dumps(line))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

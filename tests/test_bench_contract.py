@@ -43,7 +43,9 @@ def test_bench_sharded_code_path_on_one_rank():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--force-sharded", "--steps", "4", "--warmup", "1"], stdout=subprocess.PIPE,
                        stderr=subprocess.PIPE, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-4000:]
-    d = json.loads([l for l in r.stdout.splitlines() if l.strip()][-1])
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout[:2000]  # RCCL's version banner must not reach standard output
+    d = json.loads(lines[0])
     assert d["n_gpus"] == 1 and d["scaling"] == "strong" and d["config"]["transport"] == "rccl" and d["config"]["collective"] == "reduce_scatter"
     assert d["config"]["shape"] == [320, 5, 5, 5, 5, 5, 5, 10, 20] and d["config"]["cells_per_gpu"] == 10 ** 9
     assert d["serial_steps"]["ms_per_step"] > 0 and d["literal_shape"]["rows_per_rank"] == [10]
@@ -59,7 +61,7 @@ def test_bench_starts_its_own_ranks():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rehearse", "--steps", "3", "--warmup", "1"], stdout=subprocess.PIPE,
                        stderr=subprocess.PIPE, text=True, timeout=900, cwd=ROOT, env=env)
     assert r.returncode == 0, r.stderr[-4000:]
-    lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
     assert len(lines) == 1, r.stdout[-2000:]
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["transport"] == "detached" and d["config"]["cells_per_gpu"] == 5 * 10 ** 7
