@@ -572,7 +572,7 @@ describe('computed measures (formula.js + the device interpreter)', () => {
     assert.deepEqual(c.storedMeasureIds, ['antennas', 'routers', 'router_by_antennas']);
     assert.deepEqual(c.getData('router_by_antennas'), [3, 1, 1, 1.125, 1, 1]);
   });
-  it('device interpreter agrees with the host evaluator on every operator and function', () => {
+  it('device interpreter agrees with the host evaluator AND with plain JavaScript closures on every operator and function', () => {
     const n = 4096;
     const cube = new Cube([new GenericDimension('d', 'root', Array.from({ length: n }, (_x, i) => `i${i}`))]);
     cube.createStoredMeasure('aa', {}, 'float64', NaN_);
@@ -586,6 +586,21 @@ describe('computed measures (formula.js + the device interpreter)', () => {
     const formulas = ['aa + bb * cc - 2', 'aa / bb', 'cc % 3 + 2 ^ bb', '-aa || bb', 'abs aa + sqrt(bb) + floor(aa / 3) + ceil aa + round(aa) + trunc aa',
       'min(aa, bb, cc) + max(aa, 1) * hypot(bb, cc)', 'bb ? aa : cc', 'if(isNaN(aa), bb, aa) + not bb', 'exp(bb / 4) + ln(bb + 1) + log10(bb + 1) + log2(bb + 2) + cbrt aa',
       'sin aa + cos(aa) * tan(bb / 10) + atan2(aa, bb) + asin(bb / 8) + acos(bb / 8) + atan cc', 'sign(aa) * roundTo(aa, 2) + PI * E', 'aa__total + bb__total / cc__total', '(aa + 1) * (bb - 2) / (cc + 0.5) ^ 2'];
+    // An INDEPENDENT restatement of the same formulas as plain JavaScript closures (neither formula.js's parser nor its
+    // evaluator is involved): expr-eval's published operator semantics (^ = Math.pow, % = JS remainder, ?: and if() by
+    // truthiness, `not`, roundTo(x, n) = round at n decimals), with `||` and isNaN exactly as the reference
+    // redefines them in src/parser.js:11-23.
+    const nanAdd = (a, b) => (Number.isNaN(a) && !Number.isNaN(b) ? b : !Number.isNaN(a) && Number.isNaN(b) ? a : a + b);
+    const roundTo = (x, d) => +(`${Math.round(`${x}e+${d}`)}e-${d}`);
+    const plain = [
+      (a, b, c) => a + b * c - 2, (a, b) => a / b, (a, b, c) => (c % 3) + Math.pow(2, b), (a, b) => nanAdd(-a, b),
+      (a, b) => Math.abs(a) + Math.sqrt(b) + Math.floor(a / 3) + Math.ceil(a) + Math.round(a) + Math.trunc(a),
+      (a, b, c) => Math.min(a, b, c) + Math.max(a, 1) * Math.hypot(b, c), (a, b, c) => (b ? a : c), (a, b) => (Number.isNaN(a) ? b : a) + !b,
+      (a, b) => Math.exp(b / 4) + Math.log(b + 1) + Math.log10(b + 1) + Math.log2(b + 2) + Math.cbrt(a),
+      (a, b, c) => Math.sin(a) + Math.cos(a) * Math.tan(b / 10) + Math.atan2(a, b) + Math.asin(b / 8) + Math.acos(b / 8) + Math.atan(c),
+      (a) => Math.sign(a) * roundTo(a, 2) + Math.PI * Math.E, (a, b, c, t) => t.aa__total + t.bb__total / t.cc__total,
+      (a, b, c) => ((a + 1) * (b - 2)) / Math.pow(c + 0.5, 2)];
+    const close = (x, y) => (Number.isNaN(x) && Number.isNaN(y)) || x === y || Math.abs(x - y) <= 1e-12 * Math.max(1, Math.abs(x));
     formulas.forEach((formula, k) => {
       cube.createComputedMeasure(`f_${k}x`, formula);
       const device = cube.getData(`f_${k}x`);
@@ -594,8 +609,9 @@ describe('computed measures (formula.js + the device interpreter)', () => {
       const totals = { aa__total: cube.getTotal('aa'), bb__total: cube.getTotal('bb'), cc__total: cube.getTotal('cc') };
       for (let i = 0; i < n; ++i) {
         const host = expression.evaluate(Object.assign({ aa: A[i], bb: B[i], cc: C[i] }, totals));
-        const ok = (Number.isNaN(host) && Number.isNaN(device[i])) || host === device[i] || Math.abs(host - device[i]) <= 1e-12 * Math.max(1, Math.abs(host));
-        assert.ok(ok, `${formula} @${i}: host ${host} device ${device[i]} (aa=${A[i]} bb=${B[i]} cc=${C[i]})`);
+        assert.ok(close(host, device[i]), `${formula} @${i}: host ${host} device ${device[i]} (aa=${A[i]} bb=${B[i]} cc=${C[i]})`);
+        const independent = plain[k](A[i], B[i], C[i], totals);
+        assert.ok(close(independent, device[i]), `${formula} @${i}: plain JavaScript ${independent} device ${device[i]} (aa=${A[i]} bb=${B[i]} cc=${C[i]})`);
       }
     });
   });
