@@ -1512,6 +1512,7 @@ __global__ __launch_bounds__(1024) void reorder_brick4_kernel(const T *__restric
 // later new item names again) fills the row with the default.
 struct DicePieces {
   uint64_t outer, k_old, k_new, inner;
+  uint32_t strip;      // cells per piece strip in LDS (set by the launcher)
   uint64_t n_in_cells;
   const int32_t *sel;  // device, [k_new], effective selection
   int def_nan;
@@ -1526,11 +1527,16 @@ __global__ __launch_bounds__(kBlock) void dice_pieces_kernel(const T *__restrict
   // P consecutive pieces per wavefront, all their loads issued before any is stored (more bytes in
   // flight per wave: a 1 KiB piece alone leaves the memory pipeline mostly waiting)
   constexpr uint32_t V = 16 / sizeof(T);
-  constexpr uint32_t STRIP = kPieceBytes / sizeof(T) + 2 * V;  // cells per piece strip
   constexpr uint32_t WAVES = kBlock / 64;
-  __shared__ alignas(16) T lv[WAVES][P][STRIP];
-  __shared__ alignas(16) int32_t ls[HAS_STATUS ? WAVES : 1][HAS_STATUS ? P : 1][HAS_STATUS ? STRIP : V];
+  // strips are sized by the ACTUAL piece (dynamic LDS: strip cells = inner rounded up to whole groups + 2 groups), so
+  // short pieces leave room for several per wavefront at full occupancy
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  const uint32_t strip = (uint32_t)a.strip;
+  T *lv_base = reinterpret_cast<T *>(lds_raw);
+  int32_t *ls_base = reinterpret_cast<int32_t *>(lds_raw + (size_t)WAVES * P * strip * sizeof(T));
   const uint32_t w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  auto lvp = [&](int pp) { return lv_base + (size_t)(w * P + pp) * strip; };
+  auto lsp = [&](int pp) { return ls_base + (size_t)(w * P + pp) * strip; };
   const uint64_t n_pieces = a.outer * a.k_new;
   const uint64_t first = ((uint64_t)xcd_contiguous(blockIdx.x, gridDim.x) * WAVES + w) * P;
   const bool def_nan = a.def_nan != 0;
@@ -1564,8 +1570,8 @@ __global__ __launch_bounds__(kBlock) void dice_pieces_kernel(const T *__restrict
             if constexpr (HAS_STATUS) sx.v[e] = at + e < a.n_in_cells ? st_in[at + e] : 0;
           }
         }
-        *reinterpret_cast<Vec<T, (int)V> *>(&lv[w][pp][q * V]) = x;
-        if constexpr (HAS_STATUS) *reinterpret_cast<Vec<int32_t, (int)V> *>(&ls[w][pp][q * V]) = sx;
+        *reinterpret_cast<Vec<T, (int)V> *>(lvp(pp) + q * V) = x;
+        if constexpr (HAS_STATUS) *reinterpret_cast<Vec<int32_t, (int)V> *>(lsp(pp) + q * V) = sx;
       }
     }
   }
@@ -1591,8 +1597,8 @@ __global__ __launch_bounds__(kBlock) void dice_pieces_kernel(const T *__restrict
         T x = Cell<T>::default_value(def_nan);
         bool set = false;
         if (valid && pick[pp] >= 0) {
-          x = lv[w][pp][ms[pp] + ce];
-          set = cell_is_set<T>(x, HAS_STATUS ? ls[w][pp][ms[pp] + ce] : OLAP_STATUS_SET, HAS_STATUS, def_nan);
+          x = lvp(pp)[ms[pp] + ce];
+          set = cell_is_set<T>(x, HAS_STATUS ? lsp(pp)[ms[pp] + ce] : OLAP_STATUS_SET, HAS_STATUS, def_nan);
         }
         ov.v[e] = set ? x : Cell<T>::default_value(def_nan);
         os.v[e] = set ? OLAP_STATUS_SET : 0;
@@ -2603,16 +2609,34 @@ hipError_t Launch<T>::drillup_generic(int method, bool has_status, const T *in, 
 }
 
 template <typename T>
-hipError_t Launch<T>::dice_pieces(bool has_status, const T *in, const int32_t *st_in, T *out, int32_t *st_out, const DicePieces &a,
+hipError_t Launch<T>::dice_pieces(bool has_status, const T *in, const int32_t *st_in, T *out, int32_t *st_out, const DicePieces &a0,
                                   hipStream_t stream) {
-  const uint64_t pieces = a.outer * a.k_new;
-  if (pieces == 0 || a.inner == 0) return hipSuccess;
-  // one piece per wavefront: two per wavefront (loads of both in flight) measured 113 us against 75 us
-  const uint64_t per_block = kBlock / 64;
+  const uint64_t pieces = a0.outer * a0.k_new;
+  if (pieces == 0 || a0.inner == 0) return hipSuccess;
+  // A 1 KiB piece alone leaves the memory pipeline mostly waiting (bytes in flight per CU = waves x piece), so a
+  // wavefront takes P consecutive pieces and issues all their loads first — as many as keep 8 workgroups (32 waves)
+  // per CU with strips sized by the actual piece.  (With strips sized for the longest piece, two per wavefront halved
+  // the occupancy and measured 113 us against 75 us.)
+  DicePieces a = a0;
+  constexpr uint32_t V = 16 / sizeof(T);
+  a.strip = (uint32_t)(((a.inner + V - 1) / V + 2) * V);
+  const size_t strip_bytes = (size_t)a.strip * (sizeof(T) + (has_status ? 4 : 0));
+  const uint64_t waves = kBlock / 64;
+  // measured on 1 084-byte pieces (tools/pmc_probe.py): 70.6 / 70.0 / 71.8 us with 1 / 2 / 4 pieces per wavefront — bytes
+  // in flight are not what bounds this form either
+  int P = waves * 2 * strip_bytes <= 20 * 1024 ? 2 : 1;
+  if (const char *e = getenv("OLAP_DICE_PIECES_PER_WAVE")) P = atoi(e) >= 4 ? 4 : atoi(e) >= 2 ? 2 : 1;
+  const size_t lds = waves * P * strip_bytes;
+  const uint64_t per_block = waves * P;
   const uint64_t blocks = (pieces + per_block - 1) / per_block;
-  if (blocks >= 0x7FFFFFFFull) return hipErrorInvalidValue;
-  if (has_status) hipLaunchKernelGGL((dice_pieces_kernel<T, true, 1>), (unsigned)blocks, kBlock, 0, stream, in, st_in, out, st_out, a);
-  else hipLaunchKernelGGL((dice_pieces_kernel<T, false, 1>), (unsigned)blocks, kBlock, 0, stream, in, st_in, out, st_out, a);
+  if (blocks >= 0x7FFFFFFFull || lds > 64 * 1024) return hipErrorInvalidValue;
+#define OLAP_PIECES(HS, PP) hipLaunchKernelGGL((dice_pieces_kernel<T, HS, PP>), (unsigned)blocks, kBlock, lds, stream, in, st_in, out, st_out, a)
+  if (has_status) {
+    if (P == 4) OLAP_PIECES(true, 4); else if (P == 2) OLAP_PIECES(true, 2); else OLAP_PIECES(true, 1);
+  } else {
+    if (P == 4) OLAP_PIECES(false, 4); else if (P == 2) OLAP_PIECES(false, 2); else OLAP_PIECES(false, 1);
+  }
+#undef OLAP_PIECES
   return hipGetLastError();
 }
 
