@@ -84,11 +84,33 @@ class Comm:
 
     @classmethod
     def from_process_group(cls, dist, device, group=None):
-        """One process per GPU: rank 0 makes the RCCL unique id, torch.distributed carries it."""
+        """One process per GPU: rank 0 makes the RCCL unique id, torch.distributed carries it.  Either every rank
+        returns a communicator or every rank raises (a failure on one rank is agreed on before anybody blocks in RCCL)."""
+        import torch
+
         world, rank = dist.get_world_size(group), dist.get_rank(group)
-        box = [cls.unique_id() if rank == 0 else None]
+        box = [None]
+        if rank == 0:
+            try:
+                box[0] = cls.unique_id()
+            except capi.OlapError as err:
+                box[0] = ("error", err.code, str(err))
         dist.broadcast_object_list(box, src=0, group=group)
-        return cls.init_rank(box[0], world, rank, device)
+        if isinstance(box[0], tuple):
+            raise capi.OlapError(box[0][1], box[0][2])
+        comm, failure = None, None
+        try:
+            comm = cls.init_rank(box[0], world, rank, device)
+        except capi.OlapError as err:
+            failure = err
+        on_gpu = dist.get_backend(group) == "nccl"
+        ok = torch.tensor([0 if failure else 1], dtype=torch.int32, device=torch.device("cuda", int(device)) if on_gpu else "cpu")
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+        if int(ok.item()) == 0:
+            if comm is not None:
+                comm.destroy()
+            raise failure or capi.OlapError(capi.ERR_HIP, "another rank could not create its RCCL communicator")
+        return comm
 
     @property
     def world(self):
