@@ -89,22 +89,28 @@ class Comm:
         import torch
 
         world, rank = dist.get_world_size(group), dist.get_rank(group)
-        box = [None]
-        if rank == 0:
-            try:
-                box[0] = cls.unique_id()
-            except capi.OlapError as err:
-                box[0] = ("error", err.code, str(err))
+        on_gpu = dist.get_backend(group) == "nccl"
+        where = torch.device("cuda", int(device)) if on_gpu else "cpu"
+        # 1. can EVERY rank bind RCCL at all?  (ncclCommInitRank is collective: a rank that cannot even load the
+        #    library must not leave the others waiting inside it)
+        my_id, failure = None, None
+        try:
+            my_id = cls.unique_id()
+        except capi.OlapError as err:
+            failure = err
+        ok = torch.tensor([0 if failure else 1], dtype=torch.int32, device=where)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+        if int(ok.item()) == 0:
+            raise failure or capi.OlapError(capi.ERR_NO_DEVICE, "another rank could not load RCCL")
+        # 2. rank 0's id reaches everybody
+        box = [my_id if rank == 0 else None]
         dist.broadcast_object_list(box, src=0, group=group)
-        if isinstance(box[0], tuple):
-            raise capi.OlapError(box[0][1], box[0][2])
         comm, failure = None, None
         try:
             comm = cls.init_rank(box[0], world, rank, device)
         except capi.OlapError as err:
             failure = err
-        on_gpu = dist.get_backend(group) == "nccl"
-        ok = torch.tensor([0 if failure else 1], dtype=torch.int32, device=torch.device("cuda", int(device)) if on_gpu else "cpu")
+        ok = torch.tensor([0 if failure else 1], dtype=torch.int32, device=where)
         dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
         if int(ok.item()) == 0:
             if comm is not None:
