@@ -180,3 +180,10 @@ def test_config4_sharded_on_one_gpu(shape, world):
     for p, log in zip(procs, logs):
         assert p.returncode == 0, log[-4000:]
     assert "sharded 10^9 ok" in logs[0]
+
+
+@pytest.mark.gpu
+def test_comm_from_torch_process_group():
+    """bench.py's way to its RCCL communicator at N > 1 (Comm.from_process_group over a torch "nccl" group), one rank."""
+    r = subprocess.run([sys.executable, os.path.join(HERE, "_comm_from_group.py")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert r.returncode == 0 and "comm from group ok" in r.stdout, r.stdout[-4000:]
