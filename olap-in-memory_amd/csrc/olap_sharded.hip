@@ -19,6 +19,7 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "olap_device.hpp"
@@ -248,8 +249,11 @@ extern "C" int olap_comm_init_detached(olap_comm **comm, int world, int rank, in
   return OLAP_OK;
 }
 
+static void drop_cached_steps(const olap_comm *comm);
+
 extern "C" void olap_comm_destroy(olap_comm *c) {
   if (!c) return;
+  drop_cached_steps(c);  // steps the store handles keep for this communicator
   DeviceGuard guard;
   Rccl *r = c->transport == TRANSPORT_RCCL ? rccl() : nullptr;
   for (auto &l : c->local) {
@@ -868,6 +872,81 @@ extern "C" int olap_shard_drillup_result(const olap_shard_drillup *op, int local
   return OLAP_OK;
 }
 
+// ------------------------------------------------------------------ cache of drillUp steps for the store handles
+// Building a step costs plans, table uploads, buffers and events on every device (320 us for two shards of one GPU,
+// against a 25 us query); a dashboard repeats the same few roll-ups.  The handle layer therefore keeps its steps in
+// an LRU keyed by everything that defines them; olap_comm_destroy drops the entries of its communicator.  Like the
+// handles themselves this is for one thread at a time.
+namespace {
+struct OpCache {
+  struct Entry {
+    olap_shard_drillup *op;
+    uint64_t tick;
+    size_t bytes;
+  };
+  std::mutex mu;
+  std::unordered_map<std::string, Entry> map;
+  uint64_t tick = 0;
+  size_t bytes = 0;
+  static constexpr size_t kMaxEntries = 32;
+  static constexpr size_t kMaxBytes = (size_t)2 << 30;
+
+  olap_shard_drillup *find(const std::string &key) {
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = map.find(key);
+    if (it == map.end()) return nullptr;
+    it->second.tick = ++tick;
+    return it->second.op;
+  }
+  void insert(const std::string &key, olap_shard_drillup *op, size_t op_bytes) {
+    std::vector<olap_shard_drillup *> evicted;
+    {
+      std::lock_guard<std::mutex> lock(mu);
+      while (!map.empty() && (map.size() >= kMaxEntries || bytes + op_bytes > kMaxBytes)) {
+        auto oldest = map.begin();
+        for (auto it = map.begin(); it != map.end(); ++it)
+          if (it->second.tick < oldest->second.tick) oldest = it;
+        evicted.push_back(oldest->second.op);
+        bytes -= oldest->second.bytes;
+        map.erase(oldest);
+      }
+      map[key] = Entry{op, ++tick, op_bytes};
+      bytes += op_bytes;
+    }
+    for (olap_shard_drillup *o : evicted) olap_shard_drillup_destroy(o);
+  }
+  void drop_comm(const olap_comm *comm) {
+    std::vector<olap_shard_drillup *> gone;
+    {
+      std::lock_guard<std::mutex> lock(mu);
+      for (auto it = map.begin(); it != map.end();) {
+        if (it->second.op->comm == comm) {
+          gone.push_back(it->second.op);
+          bytes -= it->second.bytes;
+          it = map.erase(it);
+        } else {
+          ++it;
+        }
+      }
+    }
+    for (olap_shard_drillup *o : gone) olap_shard_drillup_destroy(o);
+  }
+};
+OpCache &op_cache() {
+  static OpCache *c = new OpCache();  // leaked on purpose, like the pool
+  return *c;
+}
+
+size_t op_bytes(const olap_shard_drillup *op) {
+  size_t total = 0;
+  for (int p = 0; p < op->recipe.n_payloads; ++p) total += (size_t)(op->n_send + recv_cells(op, p)) * payload_size(op, p);
+  if (op->recipe.finish == OLAP_FINISH_COMBINE) total += (size_t)op->n_out * (olap_dtype_size(op->dtype) + 4);
+  return total * op->depth * op->ranks.size();
+}
+}  // namespace
+
+static void drop_cached_steps(const olap_comm *comm) { op_cache().drop_comm(comm); }
+
 // ------------------------------------------------------------------ sharded store handle
 struct olap_sharded_store {
   olap_comm *comm = nullptr;
@@ -1235,10 +1314,25 @@ extern "C" int olap_sharded_store_drillup(const olap_sharded_store *s, olap_shar
   // arrives whole on the device of local rank 0
   olap_comm *c = s->comm;
   const bool one_process = (int)c->local.size() == c->world;
-  olap_shard_drillup *op = nullptr;
-  int rc = olap_shard_drillup_create(&op, c, s->dtype, s->default_kind, method, ndim, s->lens.data(), new_len, s->bounds.data(), maps,
-                                     one_process ? OLAP_PLACE_ROOT : OLAP_PLACE_ALL, 1);
-  if (rc) return rc;
+  const int placement = one_process ? OLAP_PLACE_ROOT : OLAP_PLACE_ALL;
+  std::string key;
+  {
+    auto raw = [&](const void *ptr, size_t n) { key.append((const char *)ptr, n); };
+    const int head[5] = {s->dtype, s->default_kind, method, ndim, placement};
+    raw(&c, sizeof c);
+    raw(head, sizeof head);
+    raw(s->lens.data(), s->lens.size() * sizeof(uint32_t));
+    raw(new_len, (size_t)ndim * sizeof(uint32_t));
+    raw(s->bounds.data(), s->bounds.size() * sizeof(uint32_t));
+    for (int d = 0; d < ndim; ++d) raw(maps[d], (size_t)s->lens[d] * sizeof(uint32_t));
+  }
+  olap_shard_drillup *op = op_cache().find(key);
+  int rc = OLAP_OK;
+  if (!op) {
+    rc = olap_shard_drillup_create(&op, c, s->dtype, s->default_kind, method, ndim, s->lens.data(), new_len, s->bounds.data(), maps, placement, 1);
+    if (rc) return rc;
+    op_cache().insert(key, op, op_bytes(op));
+  }
   std::vector<const void *> vals(s->shard.size());
   std::vector<const int32_t *> stat(s->shard.size());
   for (size_t i = 0; i < s->shard.size(); ++i) {
@@ -1265,12 +1359,11 @@ extern "C" int olap_sharded_store_drillup(const olap_sharded_store *s, olap_shar
           if (rs) e = hipMemcpyAsync(w->status, rs, count * sizeof(int32_t), hipMemcpyDeviceToDevice, nullptr);
           else rc = olap_canonicalize(w->values, w->status, count, s->dtype, s->default_kind, 0, nullptr);
         }
-        if (e == hipSuccess) e = hipStreamSynchronize(nullptr);  // the op's buffers are released below
+        // (the cached step keeps its buffers; its next run is enqueued on this same stream, behind the copy)
         if (e != hipSuccess) rc = hip_fail(e, "sharded drillUp result");
       }
     }
   }
-  olap_shard_drillup_destroy(op);
   if (rc) {
     olap_store_destroy(w);
     return rc;
