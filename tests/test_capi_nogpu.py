@@ -119,3 +119,26 @@ def test_planning_code_under_asan_and_ubsan():
     lib = build.build_lib_asan()
     _run_dry_worker({"OLAP_LIBOLAPGPU": lib, "LD_PRELOAD": build.asan_runtime(), "ASAN_OPTIONS": "detect_leaks=0",
                      "UBSAN_OPTIONS": "halt_on_error=1:print_stacktrace=1"})
+
+
+def test_sharded_entry_points_validate_before_the_device():
+    """The multi-GPU entry points: host-only arithmetic works without a device, argument errors come first, and
+    without a device nothing falls back (OLAP_ERR_NO_DEVICE)."""
+    import ctypes as C
+
+    from olap_in_memory_amd import sharded
+
+    L = capi.lib()
+    assert sharded.partition_rows(10, 3) == [0, 4, 7, 10]
+    expect(capi.ERR_INVALID_ARGUMENT, "world must be >= 1", sharded.partition_rows, 10, 0)
+    expect(capi.ERR_INVALID_ARGUMENT, "sharded:", sharded.dice_bounds, [0, 5, 10], [3, 3])
+    expect(capi.ERR_UNSUPPORTED_METHOD, "Unsupported aggregation method", sharded.recipe, "float32", 0.0, 7)
+    expect(capi.ERR_INVALID_TYPE, "Invalid type", lambda: capi.check(L.olap_shard_recipe_get(9, 0, 0, C.byref(capi.ShardRecipe()))))
+    h = C.c_void_p()
+    assert L.olap_sharded_store_create(C.byref(h), None, 1, (C.c_uint32 * 1)(4), 2, 0, None) == capi.ERR_INVALID_ARGUMENT
+    assert L.olap_shard_drillup_create(C.byref(h), None, 2, 0, 0, 1, None, None, None, None, 0, 1) == capi.ERR_INVALID_ARGUMENT
+    assert L.olap_comm_init_all(C.byref(h), (C.c_int * 2)(0, 0), 0) == capi.ERR_INVALID_ARGUMENT
+    assert L.olap_comm_init_detached(C.byref(h), 2, 5, 0) == capi.ERR_INVALID_ARGUMENT
+    if L.olap_device_count() == 0:
+        expect(capi.ERR_NO_DEVICE, "no CPU fallback", sharded.Comm.init_all, [0, 0])
+        expect(capi.ERR_NO_DEVICE, "no CPU fallback", sharded.Comm.detached, 2, 0, 0)
