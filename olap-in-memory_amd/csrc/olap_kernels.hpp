@@ -817,12 +817,12 @@ __global__ __launch_bounds__(kBlock) void drillup_reduce4_kernel(const T *__rest
       if (d > 32) {  // partner lane l + d may sit in another wavefront (only for rd.unit == kBlock): fold through LDS
 #pragma unroll
         for (int e = 0; e < 4; ++e)
-          if ((uint32_t)e < ne) lds[threadIdx.x * 4 + e] = p[e];
+          if ((uint32_t)e < ne) lds[e * kBlock + threadIdx.x] = p[e];  // 16 B per lane, lanes adjacent: no bank conflicts
         __syncthreads();
         if (threadIdx.x < d) {
 #pragma unroll
           for (int e = 0; e < 4; ++e)
-            if ((uint32_t)e < ne) partial_merge_fast<METHOD, FAST>(p[e], lds[(threadIdx.x + d) * 4 + e], def_nan);
+            if ((uint32_t)e < ne) partial_merge_fast<METHOD, FAST>(p[e], lds[e * kBlock + threadIdx.x + d], def_nan);
         }
         __syncthreads();
       } else {
