@@ -361,7 +361,9 @@ typedef enum {
 typedef enum {
   OLAP_PLACE_SCATTER = 0,   /* additive methods: rank r keeps flat cells [r*per, (r+1)*per), per = ceil(n_out/world) */
   OLAP_PLACE_ALL = 1,       /* every rank holds the whole result */
-  OLAP_PLACE_ROOT = 2       /* rank 0 holds the whole result */
+  OLAP_PLACE_ROOT = 2,      /* rank 0 holds the whole result */
+  OLAP_PLACE_SCATTER_ROWS = 3 /* like SCATTER in blocks of whole rows of the new leading dimension: rank r keeps rows
+                               * [r*p, (r+1)*p) of it, p = ceil(new_len[0] / world) (what a sharded store needs) */
 } olap_shard_placement;
 typedef struct {
   int local_method;     /* olap_method run by each rank over its own rows */
@@ -444,8 +446,10 @@ int olap_sharded_store_scatter(olap_sharded_store **store, olap_comm *comm, cons
                                const uint32_t *lens);
 /* The bulk operations.  Dimension 0 untouched (identity map / selection / perm[0] == 0): per shard,
  * no communication, *out_sharded keeps the partition.  drillUp that changes dimension 0: partial +
- * ONE collective, the (K0 / G0 times smaller) result arrives as an ordinary store in *out_whole on
- * the device of local rank 0 (every process gets it when there is one process per GPU).  dice of
+ * ONE collective; when the new leading dimension still has a row per rank (day -> month on a sharded time
+ * axis) the result stays sharded along it (reduce-scatter of whole rows, rank r keeps rows [r*p, (r+1)*p),
+ * p = ceil(G0 / world)), otherwise ('all') the (K0 / G0 times smaller) result arrives as an ordinary store
+ * in *out_whole on the device of local rank 0 (every process gets it when there is one process per GPU).  dice of
  * dimension 0 by a strictly ascending list of existing rows: per shard, the partition becomes
  * uneven.  Anything else that touches dimension 0 (reordering it, refining it, selections that
  * repeat, permute or invent rows): OLAP_ERR_INVALID_ARGUMENT with a message starting "sharded:" —

@@ -166,7 +166,7 @@ class ShardRecipe(C.Structure):
 
 XCHG_SUM, XCHG_MAX, XCHG_GATHER = 0, 1, 2
 FINISH_NONE, FINISH_RESTORE, FINISH_AVERAGE, FINISH_COMBINE = 0, 1, 2, 3
-PLACE_SCATTER, PLACE_ALL, PLACE_ROOT = 0, 1, 2
+PLACE_SCATTER, PLACE_ALL, PLACE_ROOT, PLACE_SCATTER_ROWS = 0, 1, 2, 3
 UNIQUE_ID_BYTES = 128
 
 _lib = None

@@ -434,12 +434,14 @@ struct olap_shard_drillup {
   std::vector<RankState> ranks;
 };
 
+static bool is_scatter(int placement) { return placement == OLAP_PLACE_SCATTER || placement == OLAP_PLACE_SCATTER_ROWS; }
+
 static size_t payload_size(const olap_shard_drillup *op, int p) { return olap_dtype_size(op->recipe.payload_dtype[p]); }
 
 // cells of recv[p] on a rank
 static uint64_t recv_cells(const olap_shard_drillup *op, int p) {
   if (op->recipe.payload_op[p] == OLAP_XCHG_GATHER) return op->n_out * (uint64_t)op->comm->world;
-  return op->placement == OLAP_PLACE_SCATTER ? op->per : op->n_out;
+  return is_scatter(op->placement) ? op->per : op->n_out;
 }
 
 extern "C" void olap_shard_drillup_destroy(olap_shard_drillup *op) {
@@ -475,7 +477,7 @@ extern "C" int olap_shard_drillup_create(olap_shard_drillup **out, olap_comm *co
   if (!comm) return fail(OLAP_ERR_INVALID_ARGUMENT, "comm is NULL");
   if (ndim < 1 || ndim > OLAP_MAX_DIMS || !lens || !new_len || !bounds || !maps)
     return fail(OLAP_ERR_INVALID_ARGUMENT, "a sharded drillUp needs at least one dimension, its lengths, bounds and maps");
-  if (placement < OLAP_PLACE_SCATTER || placement > OLAP_PLACE_ROOT) return fail(OLAP_ERR_INVALID_ARGUMENT, "placement %d", placement);
+  if (placement < OLAP_PLACE_SCATTER || placement > OLAP_PLACE_SCATTER_ROWS) return fail(OLAP_ERR_INVALID_ARGUMENT, "placement %d", placement);
   if (depth != 1 && depth != 2) return fail(OLAP_ERR_INVALID_ARGUMENT, "depth must be 1 or 2");
   olap_shard_recipe recipe;
   int rc = olap_shard_recipe_get(dtype, default_kind, method, &recipe);
@@ -507,7 +509,11 @@ extern "C" int olap_shard_drillup_create(olap_shard_drillup **out, olap_comm *co
   for (int d = 0; d < ndim; ++d) n_out *= new_len[d];
   op->n_out = n_out;
   op->per = (n_out + (uint64_t)world - 1) / (uint64_t)world;
-  op->n_send = op->placement == OLAP_PLACE_SCATTER ? op->per * (uint64_t)world : n_out;  // padded so that it divides
+  if (op->placement == OLAP_PLACE_SCATTER_ROWS) {  // blocks of whole rows of the new leading dimension
+    const uint64_t row = new_len[0] ? n_out / new_len[0] : 0;
+    op->per = ((uint64_t)new_len[0] + (uint64_t)world - 1) / (uint64_t)world * row;
+  }
+  op->n_send = is_scatter(op->placement) ? op->per * (uint64_t)world : n_out;  // padded so that it divides
   op->ranks.resize(comm->local.size());
 
   DeviceGuard guard;
@@ -699,7 +705,7 @@ static int shard_exchange(olap_shard_drillup *op, int k, const std::vector<hipSt
           continue;
         }
         const ncclRedOp_t red = rp.payload_op[p] == OLAP_XCHG_SUM ? ncclSum : ncclMax;
-        if (op->placement == OLAP_PLACE_SCATTER) res = r->ReduceScatter(b.send[p], b.recv[p], op->per, ty, red, l.nccl, xs[i]);
+        if (is_scatter(op->placement)) res = r->ReduceScatter(b.send[p], b.recv[p], op->per, ty, red, l.nccl, xs[i]);
         else if (op->placement == OLAP_PLACE_ALL) res = r->AllReduce(b.send[p], b.recv[p], op->n_out, ty, red, l.nccl, xs[i]);
         else res = r->Reduce(b.send[p], b.recv[p] ? b.recv[p] : b.send[p], op->n_out, ty, red, 0, l.nccl, xs[i]);
       }
@@ -723,8 +729,8 @@ static int shard_exchange(olap_shard_drillup *op, int k, const std::vector<hipSt
         continue;
       }
       if (op->placement == OLAP_PLACE_ROOT && l.rank != 0) continue;
-      const uint64_t first = op->placement == OLAP_PLACE_SCATTER ? (uint64_t)l.rank * op->per : 0;
-      const uint64_t n = op->placement == OLAP_PLACE_SCATTER ? op->per : op->n_out;
+      const uint64_t first = is_scatter(op->placement) ? (uint64_t)l.rank * op->per : 0;
+      const uint64_t n = is_scatter(op->placement) ? op->per : op->n_out;
       const bool sum = rp.payload_op[p] == OLAP_XCHG_SUM;
 #define DIRECT_LAUNCH(T)                                                                                                     \
   do {                                                                                                                       \
@@ -849,7 +855,7 @@ extern "C" int olap_shard_drillup_result(const olap_shard_drillup *op, int local
   const BufSet &b = op->ranks[local].set[op->cur];
   const int rank = op->comm->local[local].rank;
   uint64_t f = 0, n = op->n_out;
-  if (op->placement == OLAP_PLACE_SCATTER) {
+  if (is_scatter(op->placement)) {
     f = std::min<uint64_t>((uint64_t)rank * op->per, op->n_out);
     n = std::min<uint64_t>(op->per, op->n_out - f);
   } else if (op->placement == OLAP_PLACE_ROOT && rank != 0) {
@@ -1310,11 +1316,13 @@ extern "C" int olap_sharded_store_drillup(const olap_sharded_store *s, olap_shar
     *out_sharded = o;
     return OLAP_OK;
   }
-  // the sharded axis is rolled up: partial + one collective; the result is K0/G0 times smaller and
-  // arrives whole on the device of local rank 0
+  // the sharded axis is rolled up: partial + one collective.  With at least one new row per rank the result STAYS
+  // sharded along the new leading dimension (reduce-scatter of whole rows: rank r keeps rows [r*p, (r+1)*p), p =
+  // ceil(G0 / world)); otherwise it is K0/G0 times smaller and arrives whole on the device of local rank 0.
   olap_comm *c = s->comm;
   const bool one_process = (int)c->local.size() == c->world;
-  const int placement = one_process ? OLAP_PLACE_ROOT : OLAP_PLACE_ALL;
+  const bool keep_sharded = new_len[0] >= (uint32_t)c->world;
+  const int placement = keep_sharded ? OLAP_PLACE_SCATTER_ROWS : one_process ? OLAP_PLACE_ROOT : OLAP_PLACE_ALL;
   std::string key;
   {
     auto raw = [&](const void *ptr, size_t n) { key.append((const char *)ptr, n); };
@@ -1339,36 +1347,56 @@ extern "C" int olap_sharded_store_drillup(const olap_sharded_store *s, olap_shar
     vals[i] = s->shard[i]->values;
     stat[i] = mask_needed(s->shard[i]);
   }
-  rc = olap_shard_drillup_step(op, vals.data(), stat.data(), nullptr);
-  olap_store *w = nullptr;
-  if (!rc) {
+  if ((rc = olap_shard_drillup_step(op, vals.data(), stat.data(), nullptr))) return rc;
+  const size_t es = olap_dtype_size(s->dtype);
+  // copies `count` cells of local rank i's result, starting at global output cell `from`, into a new store on its device
+  auto take = [&](int i, uint64_t from, uint64_t count, olap_store **dst) -> int {
     DeviceGuard guard;
-    hipError_t e = hipSetDevice(c->local[0].device);
-    if (e != hipSuccess) rc = hip_fail(e, "hipSetDevice");
-    if (!rc) rc = store_alloc(&w, op->n_out, s->dtype, s->default_kind);
-    if (!rc) {
-      void *rv = nullptr;
-      int32_t *rs = nullptr;
-      uint64_t first = 0, count = 0;
-      rc = olap_shard_drillup_result(op, 0, &rv, &rs, &first, &count);
-      if (!rc && count != op->n_out) rc = fail(OLAP_ERR_INVALID_ARGUMENT, "sharded: local rank 0 does not hold the whole result");
-      if (!rc && count) {
-        // (the null stream is already ordered behind the step)
-        e = hipMemcpyAsync(w->values, rv, count * olap_dtype_size(s->dtype), hipMemcpyDeviceToDevice, nullptr);
-        if (e == hipSuccess && w->status) {
-          if (rs) e = hipMemcpyAsync(w->status, rs, count * sizeof(int32_t), hipMemcpyDeviceToDevice, nullptr);
-          else rc = olap_canonicalize(w->values, w->status, count, s->dtype, s->default_kind, 0, nullptr);
-        }
-        // (the cached step keeps its buffers; its next run is enqueued on this same stream, behind the copy)
-        if (e != hipSuccess) rc = hip_fail(e, "sharded drillUp result");
+    HIP_TRY(hipSetDevice(c->local[i].device));
+    olap_store *w = nullptr;
+    int r2 = store_alloc(&w, count, s->dtype, s->default_kind);
+    if (r2) return r2;
+    void *rv = nullptr;
+    int32_t *rs = nullptr;
+    uint64_t first = 0, have = 0;
+    r2 = olap_shard_drillup_result(op, i, &rv, &rs, &first, &have);
+    if (!r2 && count && (from < first || from + count > first + have)) r2 = fail(OLAP_ERR_INVALID_ARGUMENT, "sharded: the result block of a rank is not where it was expected");
+    if (!r2 && count) {
+      // (the null stream is already ordered behind the step; the cached step's next run is enqueued behind these copies)
+      hipError_t e = hipMemcpyAsync(w->values, (const char *)rv + (from - first) * es, count * es, hipMemcpyDeviceToDevice, nullptr);
+      if (e == hipSuccess && w->status) {
+        if (rs) e = hipMemcpyAsync(w->status, rs + (from - first), count * sizeof(int32_t), hipMemcpyDeviceToDevice, nullptr);
+        else r2 = olap_canonicalize(w->values, w->status, count, s->dtype, s->default_kind, 0, nullptr);
       }
+      if (e != hipSuccess) r2 = hip_fail(e, "sharded drillUp result");
     }
+    if (r2) {
+      olap_store_destroy(w);
+      return r2;
+    }
+    *dst = w;
+    return OLAP_OK;
+  };
+  if (!keep_sharded) {
+    olap_store *w = nullptr;
+    if ((rc = take(0, 0, op->n_out, &w))) return rc;
+    *out_whole = w;
+    return OLAP_OK;
+  }
+  const uint64_t row = op->n_out / new_len[0], per_rows = ((uint64_t)new_len[0] + (uint64_t)c->world - 1) / (uint64_t)c->world;
+  std::vector<uint32_t> nb(c->world + 1);
+  for (int r = 0; r <= c->world; ++r) nb[r] = (uint32_t)std::min<uint64_t>((uint64_t)r * per_rows, new_len[0]);
+  olap_sharded_store *o = nullptr;
+  if ((rc = sharded_frame(&o, c, ndim, new_len, s->dtype, s->default_kind, nb.data()))) return rc;
+  for (size_t i = 0; i < s->shard.size() && !rc; ++i) {
+    const int r = c->local[i].rank;
+    rc = take((int)i, (uint64_t)nb[r] * row, (uint64_t)(nb[r + 1] - nb[r]) * row, &o->shard[i]);
   }
   if (rc) {
-    olap_store_destroy(w);
+    olap_sharded_store_destroy(o);
     return rc;
   }
-  *out_whole = w;
+  *out_sharded = o;
   return OLAP_OK;
 }
 

@@ -252,7 +252,7 @@ def exchange_over_process_group(op, dist, group=None):
         else:
             dist.all_reduce(t, op=dist.ReduceOp.SUM if xop == capi.XCHG_SUM else dist.ReduceOp.MAX, group=group)
             full = t.numpy()
-            if op.placement == capi.PLACE_SCATTER:  # this rank keeps its own block of the padded payload
+            if op.placement in (capi.PLACE_SCATTER, capi.PLACE_SCATTER_ROWS):  # this rank keeps its own block of the padded payload
                 per = n // world
                 full = full[rank * per:(rank + 1) * per]
         if recv:
@@ -379,7 +379,8 @@ class ShardedStore:
 
     # ---- bulk operations (names follow in-memory.js)
     def drill_up(self, new_len, maps, method="sum"):
-        """-> ShardedStore (dimension 0 untouched) or HipStore (dimension 0 rolled up: one collective)."""
+        """-> ShardedStore (dimension 0 untouched, or rolled up to at least one row per rank: the result stays sharded
+        along the new leading dimension) or HipStore (dimension 0 rolled up to fewer rows than ranks, e.g. 'all')."""
         nl = _u32(new_len)
         keep, arr = _tables(maps, np.uint32, C.c_uint32)
         hs, hw = C.c_void_p(), C.c_void_p()

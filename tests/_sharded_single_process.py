@@ -77,11 +77,27 @@ def run_steps(comm, what):
                     if op.placement == capi.PLACE_ROOT and world > 1:
                         assert op.result(1)[3] == 0, tag
                     op.destroy()
-            # the store-level operation the Node host binds: the result arrives whole as an ordinary store
-            whole = s.drill_up(new_len, maps, method)
-            assert isinstance(whole, pkg.HipStore) and whole.size == n_out
-            assert np.array_equal(whole.get_status(), es), "%s %s %s store" % (what, name, method)
-            assert close(method, dtype, whole.get_data(), ev), "%s %s %s store" % (what, name, method)
+            # the store-level operation the Node host binds: with a new row per rank the result stays sharded along the
+            # new leading dimension (rank r keeps rows [r*p, (r+1)*p), p = ceil(G / world)), otherwise it arrives whole
+            res = s.drill_up(new_len, maps, method)
+            if case["groups"] >= world:
+                assert isinstance(res, ShardedStore) and res.size == n_out
+                p_rows = -(-case["groups"] // world)
+                assert res.bounds == [min(r * p_rows, case["groups"]) for r in range(world + 1)], res.bounds
+                got_v, got_s = res.get_data_f64(), res.get_status()
+                if default != default and dtype in ("int32", "uint32"):
+                    got_v = np.where(got_s == 2, got_v, 0.0)
+                # and it is a sharded store like any other: roll the rest of dimension 0 up from there
+                if method == "sum" and name == "f32_zero":
+                    again = res.drill_up([1] + new_len[1:], [np.zeros(case["groups"], np.uint32)] + maps[1:], "sum")
+                    e2, _ = expected_typed(o.drill_up(lens, [1] + new_len[1:], [np.zeros(lens[0], np.uint32)] + maps[1:], "sum"))
+                    assert isinstance(again, ShardedStore if world == 1 else pkg.HipStore)  # one row left: whole, unless there is one rank
+                    assert np.allclose(again.get_data_f64() if world == 1 else again.get_data(), e2, rtol=1e-5, atol=0)
+            else:
+                assert isinstance(res, pkg.HipStore) and res.size == n_out
+                got_v, got_s = res.get_data().astype(np.float64), res.get_status()
+            assert np.array_equal(got_s, es), "%s %s %s store" % (what, name, method)
+            assert close(method, dtype, got_v, ev), "%s %s %s store" % (what, name, method)
         del s
 
 
@@ -114,6 +130,9 @@ def run_store_api(comm, what):
     assert picked.bounds == [int(np.searchsorted([1, 2, 4, 6], b)) for b in s.bounds]
     m = [np.zeros(4, np.uint32), ident(6), ident(10)]
     same(picked.drill_up([1, 6, 10], m, "last"), o.dice(lens, [4, 6, 10], rows).drill_up([4, 6, 10], [1, 6, 10], m, "last"), "rows then dim0 last")
+    pairs = [(np.arange(7) // 2).astype(np.uint32), ident(6), ident(10)]  # 7 rows -> 4 groups: stays sharded, uneven blocks
+    for method in ("sum", "average", "highest", "last"):
+        same(s.drill_up([4, 6, 10], pairs, method), o.drill_up(lens, [4, 6, 10], pairs, method), "dim0 -> 4 groups " + method)
     dm = [ident(7), ident(6), np.repeat(np.arange(10), 3).astype(np.uint32)]
     same(s.drill_down([7, 6, 30], dm, "sum"), o.drill_down(lens, [7, 6, 30], dm, "sum"), "drillDown axis 2")
     same(s.reorder([0, 2, 1]), o.reorder(lens, [0, 2, 1]), "reorder")
