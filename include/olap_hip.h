@@ -437,7 +437,9 @@ int olap_sharded_store_get_status(const olap_sharded_store *store, int32_t *host
 int olap_sharded_store_get_value(const olap_sharded_store *store, uint64_t index, double *value, int *is_set);
 int olap_sharded_store_set_value(olap_sharded_store *store, uint64_t index, double value, int is_null);
 int olap_sharded_store_fill(olap_sharded_store *store, double value);
-int olap_sharded_store_total(const olap_sharded_store *store, double *total);  /* local ranks only */
+/* sum of the set cells of the WHOLE measure: with one process per GPU over RCCL every rank must call it (a
+ * collective); on a detached communicator it is the sum of this process' slabs only */
+int olap_sharded_store_total(const olap_sharded_store *store, double *total);
 int olap_sharded_store_clone(const olap_sharded_store *store, olap_sharded_store **out);
 /* whole measure on the device of local rank 0 as an ordinary store, and back (one-process
  * communicators: device-to-device copies; one process per GPU: RCCL broadcasts of the slabs) */

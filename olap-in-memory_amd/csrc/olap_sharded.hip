@@ -1161,8 +1161,26 @@ extern "C" int olap_sharded_store_total(const olap_sharded_store *s, double *tot
     acc += t;  // ranks own ascending index ranges: the reference's order of addition between slabs
     return e;
   });
+  if (rc) return rc;
+  olap_comm *c = s->comm;
+  if ((int)c->local.size() != c->world && c->transport == TRANSPORT_RCCL) {
+    // one process per GPU: the other ranks' slabs are added over RCCL (every rank calls this, like any collective)
+    const auto &l = c->local[0];
+    DeviceGuard guard;
+    HIP_TRY(hipSetDevice(l.device));
+    double *dev = nullptr;
+    HIP_TRY(dev_alloc((void **)&dev, sizeof(double)));
+    hipError_t e = hipMemcpyAsync(dev, &acc, sizeof(double), hipMemcpyHostToDevice, l.xstream);
+    ncclResult_t res = ncclSuccess;
+    if (e == hipSuccess) res = rccl()->AllReduce(dev, dev, 1, ncclFloat64, ncclSum, l.nccl, l.xstream);
+    if (e == hipSuccess && res == ncclSuccess) e = hipMemcpyAsync(&acc, dev, sizeof(double), hipMemcpyDeviceToHost, l.xstream);
+    if (e == hipSuccess && res == ncclSuccess) e = hipStreamSynchronize(l.xstream);
+    dev_free(dev);
+    if (res != ncclSuccess) return rccl_fail(res, "ncclAllReduce(total)");
+    if (e != hipSuccess) return hip_fail(e, "sharded total");
+  }
   *total = acc;
-  return rc;
+  return OLAP_OK;
 }
 
 extern "C" int olap_sharded_store_clone(const olap_sharded_store *s, olap_sharded_store **out) {
