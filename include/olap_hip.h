@@ -441,6 +441,11 @@ int olap_sharded_store_fill(olap_sharded_store *store, double value);
  * collective); on a detached communicator it is the sum of this process' slabs only */
 int olap_sharded_store_total(const olap_sharded_store *store, double *total);
 int olap_sharded_store_clone(const olap_sharded_store *store, olap_sharded_store **out);
+/* olap_store_eval_formula over sharded inputs that are partitioned alike: evaluated per shard, every local slab of
+ * host_out (full size) is filled */
+int olap_sharded_store_eval_formula(const int32_t *code, int n_code, const double *consts, int n_consts, int n_inputs,
+                                    const olap_sharded_store *const *inputs, const double *scalars, int n_scalars,
+                                    double *host_out);
 /* whole measure on the device of local rank 0 as an ordinary store, and back (one-process
  * communicators: device-to-device copies; one process per GPU: RCCL broadcasts of the slabs) */
 int olap_sharded_store_gather(const olap_sharded_store *store, olap_store **out);

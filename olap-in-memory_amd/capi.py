@@ -148,6 +148,7 @@ SIGNATURES = {
     "olap_sharded_store_set_value": (_i32, [_vp, _u64, _dbl, _i32]),
     "olap_sharded_store_fill": (_i32, [_vp, _dbl]),
     "olap_sharded_store_total": (_i32, [_vp, _pdbl]),
+    "olap_sharded_store_eval_formula": (_i32, [_pi32, _i32, _pdbl, _i32, _i32, _pvp, _pdbl, _i32, _pdbl]),
     "olap_sharded_store_clone": (_i32, [_vp, _pvp]),
     "olap_sharded_store_gather": (_i32, [_vp, _pvp]),
     "olap_sharded_store_scatter": (_i32, [_pvp, _vp, _vp, _i32, _pu32]),

@@ -1292,6 +1292,27 @@ extern "C" int olap_sharded_store_scatter(olap_sharded_store **out, olap_comm *c
   return OLAP_OK;
 }
 
+// computed measures over sharded inputs: the element-wise interpreter runs per shard, each into its slab of host_out
+extern "C" int olap_sharded_store_eval_formula(const int32_t *code, int n_code, const double *consts, int n_consts, int n_inputs,
+                                               const olap_sharded_store *const *inputs, const double *scalars, int n_scalars,
+                                               double *host_out) {
+  if (n_inputs <= 0 || !inputs || !inputs[0]) return fail(OLAP_ERR_INVALID_ARGUMENT, "a formula needs at least one stored measure to size its result");
+  if (n_inputs > OLAP_FORMULA_MAX_INPUTS) return fail(OLAP_ERR_INVALID_ARGUMENT, "formula: too many inputs");
+  const olap_sharded_store *s0 = inputs[0];
+  for (int k = 1; k < n_inputs; ++k) {
+    if (!inputs[k]) return fail(OLAP_ERR_INVALID_ARGUMENT, "formula input %d is NULL", k);
+    if (inputs[k]->comm != s0->comm || inputs[k]->size != s0->size || inputs[k]->bounds != s0->bounds || inputs[k]->inner0 != s0->inner0)
+      return fail(OLAP_ERR_INVALID_ARGUMENT, "sharded: the formula's inputs are not partitioned alike; gather first");
+  }
+  if (s0->size && !host_out) return fail(OLAP_ERR_INVALID_ARGUMENT, "out is NULL");
+  return for_each_shard(s0, [&](int i, olap_store *sh) -> int {
+    if (!sh->size) return OLAP_OK;
+    const olap_store *shards[OLAP_FORMULA_MAX_INPUTS];
+    for (int k = 0; k < n_inputs; ++k) shards[k] = inputs[k]->shard[i];
+    return olap_store_eval_formula(code, n_code, consts, n_consts, n_inputs, shards, scalars, n_scalars, host_out + slab_first(s0, i));
+  });
+}
+
 static bool identity_map(const uint32_t *m, uint32_t old_len, uint32_t new_len) {
   if (old_len != new_len) return false;
   for (uint32_t k = 0; k < old_len; ++k)

@@ -152,7 +152,7 @@ class Cube {
       if (name.includes('__total')) {
         scalars[name] = totals.push(this.storedMeasures[name.replace('__total', '')].total) - 1;
       } else {
-        inputs[name] = stores.push(this.storedMeasures[name]._whole) - 1;
+        inputs[name] = stores.push(this.storedMeasures[name]) - 1;
       }
     }
     if (stores.length === 0) {
@@ -164,7 +164,17 @@ class Cube {
       return new Array(this.storeSize).fill(expression.evaluate(params));
     }
     const program = expression.compile(inputs, scalars);
-    return HipStore.toPlainArray(backend.load().evalFormula(program.code, program.consts, stores, Float64Array.from(totals)));
+    const addon = backend.load();
+    const natives = stores.map((store) => store._native);
+    // measures split over several devices alike: evaluated per shard; otherwise on one device (gathered if need be)
+    if (natives.every((native) => native.isSharded)) {
+      try {
+        return HipStore.toPlainArray(addon.evalFormulaSharded(program.code, program.consts, natives, Float64Array.from(totals)));
+      } catch (e) {
+        if (!/^sharded:/.test(e.message)) throw e;
+      }
+    }
+    return HipStore.toPlainArray(addon.evalFormula(program.code, program.consts, stores.map((store) => store._whole), Float64Array.from(totals)));
   }
 
   copyStoredMeasure(measureId, copyMeasureId) {

@@ -989,6 +989,42 @@ static napi_value ShardStore(napi_env env, napi_callback_info info) {
   return wrap_new_sharded(env, s, g_comm);
 }
 
+// evalFormulaSharded(code, consts, stores: ShardedStore[], scalars) -> Float64Array: per shard, no gather
+static napi_value EvalFormulaSharded(napi_env env, napi_callback_info info) {
+  size_t argc = 4;
+  napi_value argv[4];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+  if (argc < 4) return bad_args(env, "evalFormulaSharded(code, consts, stores, scalars)");
+  napi_typedarray_type t;
+  size_t n_code = 0, n_consts = 0, n_scalars = 0;
+  void *code = nullptr, *consts = nullptr, *scalars = nullptr;
+  if (napi_get_typedarray_info(env, argv[0], &t, &n_code, &code, nullptr, nullptr) != napi_ok || t != napi_int32_array ||
+      napi_get_typedarray_info(env, argv[1], &t, &n_consts, &consts, nullptr, nullptr) != napi_ok || t != napi_float64_array ||
+      napi_get_typedarray_info(env, argv[3], &t, &n_scalars, &scalars, nullptr, nullptr) != napi_ok || t != napi_float64_array)
+    return bad_args(env, "evalFormulaSharded(code: Int32Array, consts: Float64Array, stores: ShardedStore[], scalars: Float64Array)");
+  bool is_arr = false;
+  napi_is_array(env, argv[2], &is_arr);
+  uint32_t n_inputs = 0;
+  if (is_arr) napi_get_array_length(env, argv[2], &n_inputs);
+  if (!is_arr || n_inputs == 0) return bad_args(env, "evalFormulaSharded: stores must be a non-empty array of ShardedStore");
+  std::vector<const olap_sharded_store *> stores(n_inputs);
+  for (uint32_t i = 0; i < n_inputs; ++i) {
+    napi_value e;
+    NAPI_OK(napi_get_element(env, argv[2], i, &e));
+    ShardedBox *box = unwrap_sharded(env, e);
+    if (!box) return nullptr;
+    stores[i] = box->store;
+  }
+  void *out;
+  napi_value ta = make_ta(env, napi_float64_array, 8, olap_sharded_store_size(stores[0]), &out);
+  if (!ta) return nullptr;
+  static const double zero = 0;
+  int rc = olap_sharded_store_eval_formula((const int32_t *)code, (int)n_code, consts ? (const double *)consts : &zero, (int)n_consts, (int)n_inputs,
+                                           stores.data(), scalars ? (const double *)scalars : &zero, (int)n_scalars, (double *)out);
+  if (rc) return throw_olap(env, rc);
+  return ta;
+}
+
 // setDevices(devices: number[] | null): the devices new sharded measures are split over
 // (olap_comm_init_all: distinct devices talk over RCCL / xGMI; one device repeated exchanges directly)
 static napi_value SetDevices(napi_env env, napi_callback_info info) {
@@ -1127,6 +1163,7 @@ static napi_value Init(napi_env env, napi_value exports) {
       {"shardWorld", nullptr, ShardWorld, nullptr, nullptr, nullptr, napi_default, nullptr},
       {"shardTransport", nullptr, ShardTransport, nullptr, nullptr, nullptr, napi_default, nullptr},
       {"shardStore", nullptr, ShardStore, nullptr, nullptr, nullptr, napi_default, nullptr},
+      {"evalFormulaSharded", nullptr, EvalFormulaSharded, nullptr, nullptr, nullptr, napi_default, nullptr},
       {"evalFormula", nullptr, EvalFormula, nullptr, nullptr, nullptr, napi_default, nullptr},
       {"storeFromSparse", nullptr, StoreFromSparse, nullptr, nullptr, nullptr, napi_default, nullptr},
       {"methodFromName", nullptr, MethodFromName, nullptr, nullptr, nullptr, napi_default, nullptr},
