@@ -1917,6 +1917,7 @@ extern "C" int olap_store_create(olap_store **store, uint64_t size, int dtype, i
 
 /* Insertion order of the reference's Map (see olap_order.hip). */
 extern "C" int olap_store_track_order(olap_store *s, int on) {
+  OnStoreDevice on_device__(s);
   if (!s) return fail(OLAP_ERR_INVALID_ARGUMENT, "store is NULL");
   if (on && s->size >= 0x7FFFFFFFull) return fail(OLAP_ERR_INVALID_ARGUMENT, "insertion-order tracking supports stores below 2^31 cells");
   s->track_order = on != 0;
@@ -1926,6 +1927,7 @@ extern "C" int olap_store_track_order(olap_store *s, int on) {
 extern "C" int olap_store_order_tracked(const olap_store *s) { return s && s->track_order ? (s->seq ? 2 : 1) : 0; }
 
 extern "C" void olap_store_destroy(olap_store *s) {
+  OnStoreDevice on_device__(s);
   if (!s) return;
   if (s->values) dev_free(s->values);
   if (s->status) dev_free(s->status);
@@ -1934,6 +1936,7 @@ extern "C" void olap_store_destroy(olap_store *s) {
 }
 
 extern "C" int olap_store_clone(const olap_store *s, olap_store **out) {
+  OnStoreDevice on_device__(s);
   if (!s || !out) return fail(OLAP_ERR_INVALID_ARGUMENT, "store is NULL");
   *out = nullptr;
   olap_store *c = nullptr;
@@ -1959,6 +1962,7 @@ extern "C" int olap_store_default(const olap_store *s) { return s ? s->default_k
 extern "C" uint64_t olap_store_byte_length(const olap_store *s) { return s ? s->size * olap_dtype_size(s->dtype) : 0; }
 extern "C" void *olap_store_values_ptr(const olap_store *s) { return s ? s->values : nullptr; }
 extern "C" int32_t *olap_store_status_ptr(const olap_store *s) {
+  OnStoreDevice on_device__(s);
   if (!s || ensure_status(s)) return nullptr;
   return s->status;
 }
@@ -1979,6 +1983,7 @@ void drop_lazy_status(olap_store *s) {
 }
 
 extern "C" int olap_store_set_data(olap_store *s, const void *host_values, uint64_t n) {
+  OnStoreDevice on_device__(s);
   int rc = check_length(s, n);
   if (rc) return rc;
   if (n && !host_values) return fail(OLAP_ERR_INVALID_ARGUMENT, "values is NULL");
@@ -1993,6 +1998,7 @@ extern "C" int olap_store_set_data(olap_store *s, const void *host_values, uint6
 }
 
 extern "C" int olap_store_set_data_f64(olap_store *s, const double *host_values, uint64_t n) {
+  OnStoreDevice on_device__(s);
   int rc = check_length(s, n);
   if (rc) return rc;
   if (n && !host_values) return fail(OLAP_ERR_INVALID_ARGUMENT, "values is NULL");
@@ -2014,12 +2020,14 @@ extern "C" int olap_store_set_data_f64(olap_store *s, const double *host_values,
 }
 
 extern "C" int olap_store_get_data(const olap_store *s, void *host_values) {
+  OnStoreDevice on_device__(s);
   if (!s || (s->size && !host_values)) return fail(OLAP_ERR_INVALID_ARGUMENT, "store/values is NULL");
   if (s->size) HIP_TRY(hipMemcpy(host_values, s->values, s->size * olap_dtype_size(s->dtype), hipMemcpyDeviceToHost));
   return OLAP_OK;
 }
 
 extern "C" int olap_store_get_data_f64(const olap_store *s, double *host_values) {
+  OnStoreDevice on_device__(s);
   if (!s || (s->size && !host_values)) return fail(OLAP_ERR_INVALID_ARGUMENT, "store/values is NULL");
   if (!s->size) return OLAP_OK;
   if (s->dtype == OLAP_FLOAT64) return olap_store_get_data(s, host_values);
@@ -2042,6 +2050,7 @@ extern "C" int olap_store_get_data_f64(const olap_store *s, double *host_values)
 }
 
 extern "C" int olap_store_get_status(const olap_store *s, int32_t *host_status) {
+  OnStoreDevice on_device__(s);
   if (!s || (s->size && !host_status)) return fail(OLAP_ERR_INVALID_ARGUMENT, "store/status is NULL");
   int rc = ensure_status(s);
   if (rc) return rc;
@@ -2050,11 +2059,13 @@ extern "C" int olap_store_get_status(const olap_store *s, int32_t *host_status) 
 }
 
 extern "C" int olap_store_count_set(const olap_store *s, uint64_t *n_set) {
+  OnStoreDevice on_device__(s);
   if (!s || !n_set) return fail(OLAP_ERR_INVALID_ARGUMENT, "store is NULL");
   return olap_total(s->values, s->status, s->size, s->dtype, s->default_kind, nullptr, n_set, nullptr);
 }
 
 extern "C" int olap_store_get_keys(const olap_store *s, uint64_t *host_keys, uint64_t cap, uint64_t *n_keys) {
+  OnStoreDevice on_device__(s);
   if (!s || !n_keys) return fail(OLAP_ERR_INVALID_ARGUMENT, "store is NULL");
   if (s->seq) {  // a tracked store whose order is not the flat index: the reference's _dataMap.keys()
     std::vector<uint64_t> keys;
@@ -2079,6 +2090,7 @@ extern "C" int olap_store_get_keys(const olap_store *s, uint64_t *host_keys, uin
 }
 
 extern "C" int olap_store_get_value(const olap_store *s, uint64_t index, double *value, int *is_set) {
+  OnStoreDevice on_device__(s);
   if (!s) return fail(OLAP_ERR_INVALID_ARGUMENT, "store is NULL");
   if (index >= s->size) {  // Map.get of an absent key: the default (:118-120)
     if (value) *value = s->default_kind == OLAP_DEFAULT_NAN ? NAN : 0.0;
@@ -2108,6 +2120,7 @@ extern "C" int olap_store_get_value(const olap_store *s, uint64_t index, double 
 }
 
 extern "C" int olap_store_set_value(olap_store *s, uint64_t index, double value, int is_null) {
+  OnStoreDevice on_device__(s);
   if (!s) return fail(OLAP_ERR_INVALID_ARGUMENT, "store is NULL");
   if (index >= s->size) return fail(OLAP_ERR_INDEX_RANGE, "cell index %llu out of bounds [0, %llu[", (unsigned long long)index, (unsigned long long)s->size);
   int rc = order_before_set_value(s, index);
@@ -2121,6 +2134,7 @@ extern "C" int olap_store_set_value(olap_store *s, uint64_t index, double value,
 }
 
 extern "C" int olap_store_fill(olap_store *s, double value) {
+  OnStoreDevice on_device__(s);
   if (!s) return fail(OLAP_ERR_INVALID_ARGUMENT, "store is NULL");
   if (!s->size) return OLAP_OK;
   // fill = setValue(i, value) for every i (:135-137): one converted cell, broadcast
@@ -2152,6 +2166,7 @@ extern "C" int olap_store_fill(olap_store *s, double value) {
 }
 
 extern "C" int olap_store_total(const olap_store *s, double *total) {
+  OnStoreDevice on_device__(s);
   if (!s || !total) return fail(OLAP_ERR_INVALID_ARGUMENT, "store is NULL");
   return olap_total(s->values, s->status, s->size, s->dtype, s->default_kind, total, nullptr, nullptr);
 }
@@ -2190,6 +2205,7 @@ extern "C" int olap_store_eval_formula(const int32_t *code, int n_code, const do
 // ---- sparse form (the reference's serialised layout, in-memory.js:75-116) ------------------------
 extern "C" int olap_store_to_sparse(const olap_store *s, uint32_t *host_indexes, void *host_values, uint64_t cap,
                                     uint64_t *n_set) {
+  OnStoreDevice on_device__(s);
   if (!s || !n_set) return fail(OLAP_ERR_INVALID_ARGUMENT, "store is NULL");
   if (s->size > 0xFFFFFFFFull) return fail(OLAP_ERR_INVALID_ARGUMENT, "sparse form uses 32-bit indexes: store too large");
   *n_set = 0;
@@ -2389,11 +2405,6 @@ PlanCache &plan_cache() {
 // data-dependent error (in-memory.js:397-398) must surface from this call.
 static int run_to_new_store(olap_plan *plan, const olap_store *in, olap_store **out) {
   olap_store *o = nullptr;
-  {
-    int cur = -1;
-    if (hipGetDevice(&cur) == hipSuccess && cur != in->device)
-      return fail(OLAP_ERR_INVALID_ARGUMENT, "store lives on device %d but the current device is %d", in->device, cur);
-  }
   int rc = store_alloc(&o, olap_plan_out_cells(plan), in->dtype, in->default_kind);
   if (!rc) rc = olap_plan_run(plan, in->values, mask_needed(in), o->values, o->status, nullptr);
   if (!rc && plan->kind == PLAN_DRILLDOWN && plan->dd.dist) {
@@ -2419,6 +2430,7 @@ static bool bad_dims(int ndim, const void *a, const void *b) { return ndim < 0 |
 
 extern "C" int olap_store_drillup(const olap_store *s, olap_store **out, int ndim, const uint32_t *old_len,
                                   const uint32_t *new_len, const uint32_t *const *maps, int method) {
+  OnStoreDevice on_device__(s);
   if (!s || !out) return fail(OLAP_ERR_INVALID_ARGUMENT, "store is NULL");
   if (s->track_order && !bad_dims(ndim, old_len, new_len) && (ndim == 0 || maps)) return order_drillup(s, out, ndim, old_len, new_len, maps, method);
   return store_drillup_plain(s, out, ndim, old_len, new_len, maps, method);
@@ -2476,6 +2488,7 @@ static int store_drilldown_plain(const olap_store *s, olap_store **out, int ndim
 extern "C" int olap_store_drilldown(const olap_store *s, olap_store **out, int ndim, const uint32_t *old_len,
                                     const uint32_t *new_len, const uint32_t *const *maps, int method,
                                     const double *distributions, uint64_t n_dist) {
+  OnStoreDevice on_device__(s);
   int rc = store_drilldown_plain(s, out, ndim, old_len, new_len, maps, method, distributions, n_dist);
   if (!rc && s->track_order) rc = order_after_drilldown(s, *out);
   return rc;
@@ -2526,6 +2539,7 @@ static int drop_result(olap_store **out, int rc) {
 
 extern "C" int olap_store_dice(const olap_store *s, olap_store **out, int ndim, const uint32_t *old_len,
                                const uint32_t *new_len, const int32_t *const *sel) {
+  OnStoreDevice on_device__(s);
   int rc = store_dice_plain(s, out, ndim, old_len, new_len, sel);
   if (!rc && s->track_order) rc = drop_result(out, order_after_dice(s, *out, ndim, old_len, new_len, sel));
   return rc;
@@ -2534,6 +2548,7 @@ extern "C" int olap_store_dice(const olap_store *s, olap_store **out, int ndim, 
 extern "C" int olap_store_dice_drillup(const olap_store *s, olap_store **out, int ndim, const uint32_t *old_len,
                                        const uint32_t *mid_len, const uint32_t *new_len, const int32_t *const *sel,
                                        const uint32_t *const *maps, int method) {
+  OnStoreDevice on_device__(s);
   if (!s || !out) return fail(OLAP_ERR_INVALID_ARGUMENT, "store is NULL");
   *out = nullptr;
   if (s->track_order) {  // the order of the diced intermediate matters: the two operations, one after the other
@@ -2605,6 +2620,7 @@ static int store_reorder_plain(const olap_store *s, olap_store **out, int ndim, 
 
 extern "C" int olap_store_reorder(const olap_store *s, olap_store **out, int ndim, const uint32_t *old_len,
                                   const int32_t *perm) {
+  OnStoreDevice on_device__(s);
   int rc = store_reorder_plain(s, out, ndim, old_len, perm);
   if (!rc && s->track_order) rc = drop_result(out, order_after_reorder(s, *out, ndim, old_len, perm));
   return rc;
@@ -2615,7 +2631,10 @@ static int store_load_plain(olap_store *s, const olap_store *other, int ndim, co
 
 extern "C" int olap_store_load(olap_store *s, const olap_store *other, int ndim, const uint32_t *my_len,
                                const uint32_t *his_len, const int32_t *const *his_to_mine) {
+  OnStoreDevice on_device__(s);
   if (!s || !other) return fail(OLAP_ERR_INVALID_ARGUMENT, "store is NULL");
+  if (s->device != other->device)
+    return fail(OLAP_ERR_INVALID_ARGUMENT, "load: the stores live on different devices (%d and %d)", s->device, other->device);
   int rc = order_before_load(s);
   if (!rc) rc = store_load_plain(s, other, ndim, my_len, his_len, his_to_mine);
   if (!rc) rc = order_after_load(s, other, ndim, my_len, his_len, his_to_mine);

@@ -11,6 +11,19 @@
 
 #include "../../include/olap_hip.h"
 
+// hipFuncSetAttribute is per device: "already raised" flags are kept per device (one process may drive several)
+struct PerDeviceFlag {
+  bool done[64] = {};
+  bool test_and_set() {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 64) return false;  // unknown device: raise again (harmless)
+    const bool was = done[dev];
+    done[dev] = true;
+    return was;
+  }
+};
+
 namespace olap {
 
 constexpr int kBlock = 256;  // 4 wavefronts of 64 lanes

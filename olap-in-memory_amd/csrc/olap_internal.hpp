@@ -57,6 +57,15 @@ struct olap_store {
   uint64_t hi_index = 0;             // no set cell lies above this index (valid while seq == nullptr)
 };
 
+// The handle layer runs every operation on the device its store lives on, whatever device the
+// calling thread had current (one process may drive several GPUs: the sharded stores hand whole
+// results back as plain stores on their first device), and puts the caller's device back on exit.
+struct OnStoreDevice : DeviceGuard {
+  explicit OnStoreDevice(const olap_store *s) {
+    if (s && saved >= 0 && s->device != saved) (void)hipSetDevice(s->device);
+  }
+};
+
 OLAP_INTERNAL bool mask_is_primary(const olap_store *s);
 OLAP_INTERNAL const int32_t *mask_needed(const olap_store *s);
 OLAP_INTERNAL int store_alloc(olap_store **out, uint64_t size, int dtype, int default_kind);

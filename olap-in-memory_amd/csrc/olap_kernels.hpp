@@ -2711,13 +2711,12 @@ hipError_t Launch<T>::reorder_brick(bool has_status, const T *in, const int32_t 
       const size_t padded = (size_t)(b.elems + ((b.elems >> 5) << 2)) * 4;
       const size_t lds4 = padded * (has_status ? 2 : 1);
       // above 64 KiB of dynamic LDS the kernel has to be told once (bricks of 10^4 cells with the mask: 90 KiB)
-      static bool raised = false;
-      if (!raised) {
+      static PerDeviceFlag raised;
+      if (!raised.test_and_set()) {
         hipError_t e1 = hipFuncSetAttribute((const void *)reorder_brick4_kernel<T, true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
         hipError_t e2 = hipFuncSetAttribute((const void *)reorder_brick4_kernel<T, false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
         if (e1 != hipSuccess) return e1;
         if (e2 != hipSuccess) return e2;
-        raised = true;
       }
       unsigned threads4 = kBlock;  // measured: 512 and 1024 lanes lose on the [10]^8 reversal, 512 gains 7 % on a 2-D transpose
       if (const char *e = getenv("OLAP_BRICK_THREADS")) threads4 = (unsigned)atoi(e);
@@ -2732,13 +2731,12 @@ hipError_t Launch<T>::reorder_brick(bool has_status, const T *in, const int32_t 
   unsigned threads = kBlock;  // larger workgroups for larger bricks bought nothing (tools/sweep.py)
   if (const char *e = getenv("OLAP_BRICK_THREADS")) threads = (unsigned)atoi(e);
   if (lds > 48 * 1024) {  // bricks sized for the 16-byte form, run here because a buffer is not 16 B aligned
-    static bool raised_scalar = false;
-    if (!raised_scalar) {
+    static PerDeviceFlag raised_scalar;
+    if (!raised_scalar.test_and_set()) {
       hipError_t e1 = hipFuncSetAttribute((const void *)reorder_brick_kernel<T, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
       hipError_t e2 = hipFuncSetAttribute((const void *)reorder_brick_kernel<T, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
       if (e1 != hipSuccess) return e1;
       if (e2 != hipSuccess) return e2;
-      raised_scalar = true;
     }
   }
   if (has_status) hipLaunchKernelGGL((reorder_brick_kernel<T, true>), (unsigned)n_bricks, threads, lds, stream, in, st_in, out, st_out, b);

@@ -194,11 +194,9 @@ int totals_typed(const olap_store *st, const TotalsShape &s, double *dev_out, in
   const uint64_t mask_bytes = st_in ? 4 : 0;
   if (s.ext <= kLdsCells) {
     const size_t lds = (size_t)((s.ext * sizeof(T) + 15) & ~(uint64_t)15) + (size_t)s.ext;
-    static bool raised = false;  // (per cell type)
-    if (!raised && lds > 48 * 1024) {
+    static PerDeviceFlag raised;  // (per cell type, per device)
+    if (lds > 48 * 1024 && !raised.test_and_set())
       HIP_TRY(hipFuncSetAttribute((const void *)totals_lds_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kLdsCells * (sizeof(T) + 1) + 16)));
-      raised = true;
-    }
     const unsigned threads = s.ext >= 4096 ? 1024 : 256;
     hipLaunchKernelGGL((totals_lds_kernel<T>), 1, threads, lds, nullptr, in, st_in, dev_out, dev_status, s);
     HIP_TRY(hipGetLastError());
@@ -241,6 +239,7 @@ int totals_typed(const olap_store *st, const TotalsShape &s, double *dev_out, in
 
 extern "C" int olap_store_totals(const olap_store *st, int ndim, const uint32_t *lens, const int *methods, double *host_values,
                                  int32_t *host_status, int *launches, uint64_t *bytes_read) {
+  OnStoreDevice on_device__(st);
   if (!st) return fail(OLAP_ERR_INVALID_ARGUMENT, "store is NULL");
   if (ndim < 0 || ndim > kTotalsMaxDims) return fail(OLAP_ERR_INVALID_ARGUMENT, "totals: at most %d dimensions", kTotalsMaxDims);
   if (ndim > 0 && (!lens || !methods)) return fail(OLAP_ERR_INVALID_ARGUMENT, "lens/methods is NULL");

@@ -214,11 +214,10 @@ template <int TX, int TY, bool VIN, bool VOUT>
 hipError_t launch_one(const TransposeXY &t, const uint32_t *in, uint32_t *out, int32_t *st_out, unsigned grid, hipStream_t stream) {
   constexpr size_t lds = (size_t)TX * (TY + 1) * sizeof(uint32_t);
   if (lds > 48 * 1024) {
-    static bool raised = false;  // (per instantiation)
-    if (!raised) {
+    static PerDeviceFlag raised;  // (per instantiation, per device)
+    if (!raised.test_and_set()) {
       hipError_t e = hipFuncSetAttribute((const void *)transpose_xy_kernel<TX, TY, VIN, VOUT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) return e;
-      raised = true;
     }
   }
   hipLaunchKernelGGL((transpose_xy_kernel<TX, TY, VIN, VOUT>), grid, kBlock, lds, stream, in, out, st_out, t);
