@@ -247,10 +247,8 @@ struct olap_plan {
   TransposeXY xy{};
   DrillUpReduce reduce{};                  // S > 0: reduce regime of the one-axis drillUp
   bool dd_two_pass = false;                // float cells, no distributions: scale + broadcast
-  bool dice_pieces = false;                // dice of one dimension, short rows not whole 16-byte groups: dice_pieces_kernel
-  DicePieces pieces{};
-  bool dice_lines = false;                 // dice of one dimension, rows not whole 16-byte groups: row copies through
-                                           // drilldown_rows_lines_kernel (uses `axis`, `dd_longest`)
+  bool dice_direct = false;                // dice of one dimension, rows not whole 16-byte groups: dice_direct_kernel
+  DiceRows dice_rows{};
   bool dd_rows = false;                    // one refined axis, wide rows: drilldown_rows_kernel (uses `axis`)
   uint32_t dd_longest = 0;                 // children of the largest parent
   void *dev_tab2 = nullptr;                // second table set (two-pass drillDown)
@@ -665,11 +663,10 @@ extern "C" int olap_dice_plan(olap_plan **out, int dtype, int default_kind, int 
     return rc;
   }
   p->kernel_name = "gather(dice)";
-  // One diced dimension, every new item names a distinct old item, rows that are not whole 16-byte
-  // groups (cubes with odd extents): the gather would move 4 bytes per lane; instead every selected
-  // source row is copied to its destination row through the line-aligned windows of
-  // drilldown_rows_lines_kernel (a "drillDown" in which each parent has at most one child and
-  // nothing is divided).
+  // One diced dimension over rows that are not whole 16-byte groups (cubes with odd extents): the gather would move
+  // 4 bytes per lane; dice_direct_kernel writes aligned 16-byte groups of the (contiguous) result and fetches each
+  // with one cell-aligned 16-byte load.  An unknown item, or an old item that a later new item names again, fills
+  // its row with the default (the effective selection below).
   {
     int axis = -1, touched = 0;
     for (int d = 0; d < ndim; ++d)
@@ -678,14 +675,19 @@ extern "C" int olap_dice_plan(olap_plan **out, int dtype, int default_kind, int 
         ++touched;
       }
     const uint64_t vf = 16 / olap_dtype_size(dtype);
-    if (touched == 1 && p->out_cells > 0 && !getenv("OLAP_DICE_NO_LINES")) {
+    if (touched == 1 && p->out_cells > 0 && !getenv("OLAP_DICE_NO_DIRECT")) {
       uint64_t outer = 1, inner = 1;
       for (int d = 0; d < axis; ++d) outer *= old_len[d];
       for (int d = axis + 1; d < ndim; ++d) inner *= old_len[d];
       const uint32_t G = old_len[axis], K = new_len[axis];
-      // short rows: one wavefront per (outer, new item) piece, any selection (dice_pieces_kernel)
-      if (inner % vf != 0 && inner * olap_dtype_size(dtype) >= 256 && inner * olap_dtype_size(dtype) <= kPieceBytes && K > 0 &&
-          outer * K < 0x1FFFFFFFFull && !getenv("OLAP_DICE_NO_PIECES")) {
+      DiceRows rows{};
+      rows.outer = outer;
+      rows.k_old = G;
+      rows.k_new = K;
+      rows.inner = inner;
+      rows.def_nan = p->def_nan;
+      const bool fits = olap_dtype_size(dtype) == 8 ? dice_direct_fits<double>(rows, nullptr) : dice_direct_fits<float>(rows, nullptr);
+      if (inner % vf != 0 && K > 0 && fits) {
         std::vector<int32_t> eff(K, -1);
         std::vector<int64_t> last(G ? G : 1, -1);
         for (uint32_t j = 0; j < K; ++j)
@@ -698,44 +700,10 @@ extern "C" int olap_dice_plan(olap_plan **out, int dtype, int default_kind, int 
           return rc;
         }
         p->owned.push_back(dev);
-        p->pieces.outer = outer;
-        p->pieces.k_old = G;
-        p->pieces.k_new = K;
-        p->pieces.inner = inner;
-        p->pieces.n_in_cells = p->in_cells;
-        p->pieces.sel = (const int32_t *)dev;
-        p->pieces.def_nan = p->def_nan;
-        p->dice_pieces = true;
-        p->kernel_name = "dice_pieces_kernel";
-      }
-      bool plain = !p->dice_pieces && inner % vf != 0 && inner * olap_dtype_size(dtype) >= 2048 && K > 0;
-      std::vector<uint32_t> count(G + 1, 0);
-      for (uint32_t j = 0; plain && j < K; ++j) {
-        if (sel[axis][j] < 0 || count[sel[axis][j] + 1] != 0) plain = false;  // unknown item, or an old item named twice
-        else count[sel[axis][j] + 1] = 1;
-      }
-      const uint64_t bpr = (inner + 128 / olap_dtype_size(dtype) + (uint64_t)kBlock * vf - 1) / ((uint64_t)kBlock * vf);
-      if (plain && outer * G * bpr < 0x7FFFFFFFull) {
-        std::vector<uint32_t> tab(G + 1 + K);
-        for (uint32_t g = 0; g < G; ++g) tab[g + 1] = tab[g] + count[g + 1];
-        for (uint32_t j = 0; j < K; ++j) tab[G + 1 + tab[sel[axis][j]]] = j;  // one child at most per source row
-        void *dev = nullptr;
-        if ((rc = upload(&dev, tab.data(), tab.size() * sizeof(uint32_t)))) {
-          olap_plan_destroy(p);
-          return rc;
-        }
-        p->owned.push_back(dev);
-        DrillUpAxis &ax = p->axis;
-        ax.outer = outer;
-        ax.K = K;
-        ax.inner = inner;
-        ax.G = G;
-        ax.gstart = (const uint32_t *)dev;
-        ax.order = (const uint32_t *)dev + G + 1;
-        ax.def_nan = p->def_nan;
-        p->dd_longest = 1;
-        p->dice_lines = true;
-        p->kernel_name = "drilldown_rows_lines_kernel(dice)";
+        rows.sel = (const int32_t *)dev;
+        p->dice_rows = rows;
+        p->dice_direct = true;
+        p->kernel_name = "dice_direct_kernel";
       }
     }
   }
@@ -1502,14 +1470,8 @@ static int run_typed(olap_plan *p, const void *in_v, const int32_t *in_s, void *
       e = Launch<T>::drillup_generic(p->method, hs, in, in_s, out, out_s, p->gen, stream);
       break;
     case PLAN_GATHER: {
-      if (p->dice_pieces && aligned16(in) && aligned16(out) && (!in_s || aligned16(in_s)) && (!out_s || aligned16(out_s))) {
-        e = Launch<T>::dice_pieces(hs, in, in_s, out, out_s, p->pieces, stream);
-        break;
-      }
-      if (p->dice_lines && aligned16(in) && aligned16(out) && (!in_s || aligned16(in_s)) && (!out_s || aligned16(out_s))) {
-        DrillUpAxis a = p->axis;
-        a.aligned16 = 1;
-        e = Launch<T>::drilldown_rows_lines(hs, true, in, in_s, out, out_s, a, 2, p->dd_longest, stream);
+      if (p->dice_direct && aligned16(out) && (!out_s || aligned16(out_s))) {
+        e = Launch<T>::dice_direct(hs, in, in_s, out, out_s, p->dice_rows, stream);
         break;
       }
       Remap r = p->remap;

@@ -131,6 +131,33 @@ __device__ __forceinline__ void store_stream(T *p, const Vec<T, N> &x) {
   }
 }
 
+// The same 16-byte streaming load from an address that is only CELL-aligned.  gfx950 takes global
+// dwordx4 accesses at any 4-byte boundary (the compiler keeps one `global_load_dwordx4 … nt` for an
+// under-aligned vector type), and tools/unaligned_probe.hip measures no cost on the load side (a
+// 10^8-cell copy: 125 us with the source shifted by 1-3 cells against 123 us aligned; shifted
+// STORES cost 7 %), so paths over rows that are not whole 16-byte groups need neither 4-byte lanes
+// nor an LDS staging pass to realign.
+template <int BYTES, int ALIGN> struct RawVecAt;
+template <> struct RawVecAt<16, 4> { typedef uint32_t type __attribute__((ext_vector_type(4), aligned(4))); };
+template <> struct RawVecAt<16, 8> { typedef uint32_t type __attribute__((ext_vector_type(4), aligned(8))); };
+template <> struct RawVecAt<8, 4> { typedef uint32_t type __attribute__((ext_vector_type(2), aligned(4))); };  // the status words of two 8-byte cells
+
+template <typename T, int N>
+__device__ __forceinline__ Vec<T, N> load_stream_cell_aligned(const T *p) {
+  typedef typename RawVecAt<sizeof(T) * N, sizeof(T)>::type R;
+  union U { typename RawVec<sizeof(T) * N>::type r; Vec<T, N> v; __device__ U() {} } u;
+  u.r = __builtin_nontemporal_load(reinterpret_cast<const R *>(p));
+  return u.v;
+}
+
+template <typename T, int N>
+__device__ __forceinline__ void store_stream_cell_aligned(T *p, const Vec<T, N> &x) {
+  typedef typename RawVecAt<sizeof(T) * N, sizeof(T)>::type R;
+  union U { typename RawVec<sizeof(T) * N>::type r; Vec<T, N> v; __device__ U() {} } u;
+  u.v = x;
+  __builtin_nontemporal_store(u.r, reinterpret_cast<R *>(p));
+}
+
 // ---------------------------------------------------------------- the per-output-cell aggregate
 // Restates the body of the drillUp loop, in-memory.js:311-320: the first contribution stores the
 // value, later ones store agg(current, value); setValue drops the key when the running value

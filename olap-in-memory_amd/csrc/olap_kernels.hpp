@@ -9,6 +9,8 @@
 
 #include <cstdlib>
 
+#include <type_traits>
+
 #include "olap_device.hpp"
 
 namespace olap {
@@ -114,7 +116,11 @@ struct Lane {
 // loads and branches) and each wave-instruction reads VEC*sizeof(T)*64 contiguous bytes.  A lane
 // walks its group's rows in ascending order — the reference's accumulation order, so the float64
 // running sums are bit-identical — with U independent row loads in flight.
-template <typename T, int METHOD, bool HAS_STATUS, int VEC, int U, bool CONTIG, bool FAST, bool NT = true>
+// RAGGED (rows that are not whole 16-byte groups — odd extents): slots are still VEC = 16 bytes wide, counted from
+// the row's first cell; a slot is loaded and stored with ONE access at a cell-aligned address (free on the load
+// side, +7 % on stores: tools/unaligned_probe.hip) and only the row's last, partial slot goes cell by cell —
+// instead of 4-byte lanes (four times the load instructions and waves for the same bytes).
+template <typename T, int METHOD, bool HAS_STATUS, int VEC, int U, bool CONTIG, bool FAST, bool NT = true, bool RAGGED = false>
 __global__ __launch_bounds__(kBlock) void drillup_rows_kernel(const T *__restrict__ in,
                                                               const int32_t *__restrict__ st_in,
                                                               T *__restrict__ out,
@@ -140,33 +146,85 @@ __global__ __launch_bounds__(kBlock) void drillup_rows_kernel(const T *__restric
   Lane<T, METHOD, HAS_STATUS, VEC, FAST> lane;
   lane.init();
 
+  // RAGGED: cells of this slot inside the row.  A row's last slot may be partial; it is loaded as the row's LAST
+  // whole group (`shift` cells earlier) and rotated into place, so that no lane reads past its row and the loop
+  // has no divergent branch around its loads (a divergent cell-by-cell tail made the compiler wait for every
+  // row's load before issuing the next: 145 us against 95 us for the 4-byte lanes).  Only wavefronts that hold
+  // such a slot run the rotating form of the loop.
+  const uint32_t valid = RAGGED && i0 + VEC > a.inner ? (uint32_t)(a.inner - i0) : (uint32_t)VEC;
+  const uint32_t shift = (uint32_t)VEC - valid;
   Vec<T, VEC> v[U];
   Vec<int32_t, VEC> s[U];
-  for (; j + U <= jend; j += U) {
+  auto accumulate = [&](auto rotating) {
+    constexpr bool ROT = decltype(rotating)::value;
+    auto fetch = [&](uint64_t k, Vec<T, VEC> &vv, Vec<int32_t, VEC> &ss) {
+      const T *p = base + k * a.inner;
+      const int32_t *sp = HAS_STATUS ? sbase + k * a.inner : nullptr;
+      if constexpr (!RAGGED) {
+        vv = NT ? load_stream<T, VEC>(p) : load_vec<T, VEC>(p);
+        if constexpr (HAS_STATUS) ss = NT ? load_stream<int32_t, VEC>(sp) : load_vec<int32_t, VEC>(sp);
+      } else if constexpr (!ROT) {
+        vv = load_stream_cell_aligned<T, VEC>(p);
+        if constexpr (HAS_STATUS) ss = load_stream_cell_aligned<int32_t, VEC>(sp);
+      } else {
+        const Vec<T, VEC> lv = load_stream_cell_aligned<T, VEC>(p - shift);
+        Vec<int32_t, VEC> ls;
+        if constexpr (HAS_STATUS) ls = load_stream_cell_aligned<int32_t, VEC>(sp - shift);
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const uint64_t k = CONTIG ? (uint64_t)(j + u) : (uint64_t)a.order[j + u];
-      v[u] = NT ? load_stream<T, VEC>(base + k * a.inner) : load_vec<T, VEC>(base + k * a.inner);
-      if constexpr (HAS_STATUS) s[u] = NT ? load_stream<int32_t, VEC>(sbase + k * a.inner) : load_vec<int32_t, VEC>(sbase + k * a.inner);
-    }
+        for (int e = 0; e < VEC; ++e) {
+          T x = Cell<T>::default_value(def_nan);
+          int32_t sx = 0;
 #pragma unroll
-    for (int u = 0; u < U; ++u) lane.add_row(v[u], s[u], def_nan);
-  }
-  const uint32_t rest = jend - j;  // < U, wave-uniform
-  if (rest) {
-#pragma unroll
-    for (int u = 0; u < U - 1; ++u) {
-      if ((uint32_t)u < rest) {
-        const uint64_t k = CONTIG ? (uint64_t)(j + u) : (uint64_t)a.order[j + u];
-        v[u] = NT ? load_stream<T, VEC>(base + k * a.inner) : load_vec<T, VEC>(base + k * a.inner);
-        if constexpr (HAS_STATUS) s[u] = NT ? load_stream<int32_t, VEC>(sbase + k * a.inner) : load_vec<int32_t, VEC>(sbase + k * a.inner);
+          for (int sh = 0; sh + e < VEC; ++sh) {
+            x = shift == (uint32_t)sh ? lv.v[e + sh] : x;
+            if constexpr (HAS_STATUS) sx = shift == (uint32_t)sh ? ls.v[e + sh] : sx;
+          }
+          vv.v[e] = x;
+          if constexpr (HAS_STATUS) ss.v[e] = sx;
+        }
       }
-    }
+    };
+    for (; j + U <= jend; j += U) {
 #pragma unroll
-    for (int u = 0; u < U - 1; ++u)
-      if ((uint32_t)u < rest) lane.add_row(v[u], s[u], def_nan);
+      for (int u = 0; u < U; ++u) fetch(CONTIG ? (uint64_t)(j + u) : (uint64_t)a.order[j + u], v[u], s[u]);
+#pragma unroll
+      for (int u = 0; u < U; ++u) lane.add_row(v[u], s[u], def_nan);
+    }
+    const uint32_t rest = jend - j;  // < U, wave-uniform
+    if (rest) {
+#pragma unroll
+      for (int u = 0; u < U - 1; ++u)
+        if ((uint32_t)u < rest) fetch(CONTIG ? (uint64_t)(j + u) : (uint64_t)a.order[j + u], v[u], s[u]);
+#pragma unroll
+      for (int u = 0; u < U - 1; ++u)
+        if ((uint32_t)u < rest) lane.add_row(v[u], s[u], def_nan);
+    }
+  };
+  if constexpr (RAGGED) {
+    if (__any(shift != 0)) accumulate(std::true_type{});  // wave-uniform
+    else accumulate(std::false_type{});
+  } else {
+    accumulate(std::false_type{});
   }
-  lane.template finish_and_store<NT>(def_nan, out, st_out, (o * a.G + g) * a.inner + i0);
+  const uint64_t oidx = (o * a.G + g) * a.inner + i0;
+  if constexpr (!RAGGED) {
+    lane.template finish_and_store<NT>(def_nan, out, st_out, oidx);
+  } else {
+    Vec<T, VEC> ov;
+    Vec<int32_t, VEC> os;
+    lane.finish(def_nan, ov, os);
+    if (valid == (uint32_t)VEC) {
+      store_stream_cell_aligned<T, VEC>(out + oidx, ov);
+      if (st_out) store_stream_cell_aligned<int32_t, VEC>(st_out + oidx, os);
+    } else {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e)
+        if ((uint32_t)e < valid) {
+          out[oidx + e] = ov.v[e];
+          if (st_out) st_out[oidx + e] = os.v[e];
+        }
+    }
+  }
 }
 
 // Flat regime (inner small): one lane per VEC output cells, (outer, group) decoded per lane.
@@ -1502,121 +1560,199 @@ __global__ __launch_bounds__(1024) void reorder_brick4_kernel(const T *__restric
   }
 }
 
-// dice of ONE dimension whose rows (the `inner` cells below it) are short and not whole 16-byte
-// groups — filtering a middle dimension of a cube with odd extents.  The operation is a list of
-// piece copies: destination row (o, j) <- source row (o, sel[j]), `inner` cells each, source and
-// destination misaligned by different amounts.  One WAVEFRONT per piece: the aligned 16-byte groups
-// covering the source piece go to the wave's LDS strip, and the aligned groups of the destination
-// piece are assembled from it (4 LDS reads per group) and stored whole; only the groups straddling
-// the piece's two ends are stored cell by cell.  sel[j] < 0 (unknown item, or an old item that a
-// later new item names again) fills the row with the default.
-struct DicePieces {
-  uint64_t outer, k_old, k_new, inner;
-  uint32_t strip;      // cells per piece strip in LDS (set by the launcher)
-  uint64_t n_in_cells;
-  const int32_t *sel;  // device, [k_new], effective selection
+// dice of ONE dimension over rows that are not whole 16-byte groups, any row length of at least one
+// group (cubes with odd extents).  The destination [outer, k_new, inner] is one contiguous run, so a
+// lane owns ALIGNED 16-byte groups of it and fetches each from wherever its cells lie in the source
+// with ONE 16-byte load at a cell-aligned address (load_stream_cell_aligned: gfx950 takes it at no
+// measurable cost) — no staging of cells through LDS, U groups in flight per lane, every store a
+// whole aligned group.  Integer work is what this form has to watch (v_mul_lo/hi_u32 are quarter rate:
+// a first version that decoded (outer, item) and formed the 64-bit source offset per group, four
+// times over for a straddling one, measured 89 us where the bytes take 45): the workgroup decodes its
+// first cell once with 64-bit divisions, its first threads put the source offset of each of the few
+// destination rows it touches into LDS, and a lane gets its row from SmallDiv (a compare or one
+// mul-hi) and its source cell with one LDS read and an add.
+struct DiceRows {
+  uint64_t outer, k_old, k_new, inner;  // source [outer, k_old, inner] -> destination [outer, k_new, inner]
+  const int32_t *sel;                   // device, [k_new]: the old item of each new item, -1: a row of defaults
   int def_nan;
 };
 
-constexpr uint32_t kPieceBytes = 4096;  // longest piece this form takes
+struct SmallDiv {
+  uint32_t d, magic;
+  int how;  // 0: mul-hi by magic; 1: x < 2 d, one compare; 2: d == 1
+};
+__device__ __forceinline__ uint32_t small_div(uint32_t x, const SmallDiv &s) {
+  return s.how == 0 ? __umulhi(x, s.magic) : s.how == 1 ? (x >= s.d ? 1u : 0u) : x;
+}
+// exact for every x <= x_max, or false (m = floor(2^32 / d) + 1 is exact while x d < 2^32)
+inline bool small_div_for(uint64_t d, uint64_t x_max, SmallDiv *out) {
+  if (d == 0 || d > 0xFFFFFFFFull || x_max > 0xFFFFFFFFull) return false;
+  out->d = (uint32_t)d;
+  out->magic = 0;
+  if (d == 1) {
+    out->how = 2;
+    return x_max <= 0xFFFFFFFFull;
+  }
+  if (x_max < 2 * d) {
+    out->how = 1;
+    return true;
+  }
+  if (x_max * d >= (1ull << 32)) return false;
+  out->how = 0;
+  out->magic = (uint32_t)((1ull << 32) / d + 1);
+  return true;
+}
 
-template <typename T, bool HAS_STATUS, int P>
-__global__ __launch_bounds__(kBlock) void dice_pieces_kernel(const T *__restrict__ in, const int32_t *__restrict__ st_in,
+struct DiceDirect {
+  DiceRows p;
+  SmallDiv by_inner, by_k;
+  uint32_t rows;  // destination rows a workgroup can touch, plus the one a last group runs into
+};
+
+constexpr int kDiceDirectGroups = 4;  // 16-byte groups in flight per lane
+
+// whether dice_direct_kernel takes this shape (the plan asks before choosing it)
+inline int dice_direct_groups() {
+  static const int u = [] {
+    const char *e = getenv("OLAP_DICE_DIRECT_GROUPS");
+    const int v = e ? atoi(e) : kDiceDirectGroups;
+    return v == 1 || v == 2 || v == 8 ? v : 4;
+  }();
+  return u;
+}
+
+template <typename T>
+inline bool dice_direct_fits(const DiceRows &p, DiceDirect *out) {
+  constexpr uint64_t V = 16 / sizeof(T);
+  const uint64_t SPAN = (uint64_t)dice_direct_groups() * kBlock * V;
+  if (p.inner < V || p.inner >= (1ull << 31) || p.k_new == 0 || p.k_new > 0xFFFFFFFFull || p.k_old > 0xFFFFFFFFull) return false;
+  DiceDirect d;
+  d.p = p;
+  const uint64_t rel_max = p.inner - 1 + SPAN;  // first cell of a lane's group, counted from the workgroup's first row
+  const uint64_t rows_max = rel_max / p.inner;
+  d.rows = (uint32_t)(rows_max + 2);
+  if (!small_div_for(p.inner, rel_max, &d.by_inner) || !small_div_for(p.k_new, p.k_new - 1 + d.rows, &d.by_k)) return false;
+  const long double cells = (long double)p.outer * (long double)p.k_new * (long double)p.inner;
+  if (cells / (long double)SPAN >= 2147483000.0L) return false;
+  if (out) *out = d;
+  return true;
+}
+
+template <typename T, bool HAS_STATUS, int U>
+__global__ __launch_bounds__(kBlock) void dice_direct_kernel(const T *__restrict__ in, const int32_t *__restrict__ st_in,
                                                              T *__restrict__ out, int32_t *__restrict__ st_out,
-                                                             const DicePieces a) {
-  // P consecutive pieces per wavefront, all their loads issued before any is stored (more bytes in
-  // flight per wave: a 1 KiB piece alone leaves the memory pipeline mostly waiting)
+                                                             const DiceDirect a) {
   constexpr uint32_t V = 16 / sizeof(T);
-  constexpr uint32_t WAVES = kBlock / 64;
-  // strips are sized by the ACTUAL piece (dynamic LDS: strip cells = inner rounded up to whole groups + 2 groups), so
-  // short pieces leave room for several per wavefront at full occupancy
+  constexpr uint32_t SPAN = U * kBlock * V;  // destination cells per workgroup
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-  const uint32_t strip = (uint32_t)a.strip;
-  T *lv_base = reinterpret_cast<T *>(lds_raw);
-  int32_t *ls_base = reinterpret_cast<int32_t *>(lds_raw + (size_t)WAVES * P * strip * sizeof(T));
-  const uint32_t w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  auto lvp = [&](int pp) { return lv_base + (size_t)(w * P + pp) * strip; };
-  auto lsp = [&](int pp) { return ls_base + (size_t)(w * P + pp) * strip; };
-  const uint64_t n_pieces = a.outer * a.k_new;
-  const uint64_t first = ((uint64_t)xcd_contiguous(blockIdx.x, gridDim.x) * WAVES + w) * P;
-  const bool def_nan = a.def_nan != 0;
-  const uint32_t inner = (uint32_t)a.inner;
-  int32_t pick[P];
-  uint32_t ms[P];
+  int64_t *row_src = reinterpret_cast<int64_t *>(lds_raw);  // [a.rows]: first source cell of the workgroup's t-th destination row, -1: default
+  const uint32_t inner = (uint32_t)a.p.inner, k_new = (uint32_t)a.p.k_new;
+  const uint64_t n_out = a.p.outer * a.p.k_new * a.p.inner;
+  const uint64_t c_base = (uint64_t)xcd_contiguous(blockIdx.x, gridDim.x) * SPAN;
+  const uint64_t p_base = c_base / a.p.inner;
+  const uint32_t i_base = (uint32_t)(c_base - p_base * a.p.inner);
+  const uint64_t o_base = p_base / a.p.k_new;
+  const uint32_t j_base = (uint32_t)(p_base - o_base * a.p.k_new);
+  for (uint32_t t = threadIdx.x; t < a.rows; t += kBlock) {
+    const uint32_t jr = j_base + t;
+    const uint32_t dq = small_div(jr, a.by_k);
+    const uint32_t j = jr - dq * k_new;
+    const uint64_t o = o_base + dq;
+    int64_t src = -1;
+    if (o < a.p.outer) {
+      const int32_t sj = a.p.sel[j];
+      if (sj >= 0) src = (int64_t)((o * a.p.k_old + (uint64_t)sj) * a.p.inner);
+    }
+    row_src[t] = src;
+  }
+  __syncthreads();
+  const bool def_nan = a.p.def_nan != 0;
+  const T dflt = Cell<T>::default_value(def_nan);
+  // A group that runs over the end of its destination row (inner >= V: into the next row at most) takes its first
+  // m cells from the LAST whole group of its source row and the others from the FIRST whole group of the next
+  // row's source: two whole-group loads into registers of their own, rotated into place once everything has
+  // arrived.  (Fetching those cells one by one in a divergent branch made the compiler wait for each group's load
+  // before issuing the next — the same registers were written on both paths — and left ONE load in flight per lane.)
+  Vec<T, (int)V> xv[U], yv[U];
+  Vec<int32_t, (int)V> xs[U], ys[U];
+  uint32_t mm[U];  // cells of group u that belong to its first row (>= V: all of them)
+  bool live_x[U], live_y[U];  // that row / the next one has a source (else: a row of defaults)
 #pragma unroll
-  for (int pp = 0; pp < P; ++pp) {
-    const uint64_t piece = first + pp;
-    const bool live = piece < n_pieces;
-    const uint64_t o = live ? piece / a.k_new : 0;
-    const uint32_t j = live ? (uint32_t)(piece - o * a.k_new) : 0;
-    pick[pp] = live ? a.sel[j] : -1;
-    ms[pp] = 0;
-    if (pick[pp] >= 0) {
-      const uint64_t src0 = (o * a.k_old + (uint64_t)pick[pp]) * a.inner;
-      const uint64_t as = src0 & ~(uint64_t)(V - 1);
-      ms[pp] = (uint32_t)(src0 - as);
-      const uint32_t groups = (ms[pp] + inner + V - 1) / V;
-      for (uint32_t q = lane; q < groups; q += 64) {
-        const uint64_t at = as + (uint64_t)q * V;
-        Vec<T, (int)V> x;
-        Vec<int32_t, (int)V> sx;
-        if (at + V <= a.n_in_cells) {
-          x = load_stream<T, (int)V>(in + at);
-          if constexpr (HAS_STATUS) sx = load_stream<int32_t, (int)V>(st_in + at);
-        } else {
+  for (int u = 0; u < U; ++u) {
+    const uint32_t off = ((uint32_t)u * kBlock + threadIdx.x) * V;
+    const uint64_t c0 = c_base + off;
 #pragma unroll
-          for (uint32_t e = 0; e < V; ++e) {
-            x.v[e] = at + e < a.n_in_cells ? in[at + e] : T(0);
-            if constexpr (HAS_STATUS) sx.v[e] = at + e < a.n_in_cells ? st_in[at + e] : 0;
-          }
-        }
-        *reinterpret_cast<Vec<T, (int)V> *>(lvp(pp) + q * V) = x;
-        if constexpr (HAS_STATUS) *reinterpret_cast<Vec<int32_t, (int)V> *>(lsp(pp) + q * V) = sx;
+    for (uint32_t e = 0; e < V; ++e) {
+      xv[u].v[e] = dflt;
+      yv[u].v[e] = dflt;
+      xs[u].v[e] = 0;
+      ys[u].v[e] = 0;
+    }
+    mm[u] = V;
+    live_x[u] = live_y[u] = false;
+    if (c0 >= n_out) continue;
+    const uint32_t rel = i_base + off;
+    const uint32_t t = small_div(rel, a.by_inner);
+    const uint32_t i0 = rel - t * inner;
+    const uint32_t m = inner - i0;  // cells left in this destination row
+    mm[u] = m < V ? m : V;
+    const int64_t src = row_src[t];
+    if (src >= 0) {
+      live_x[u] = true;
+      const int64_t at = src + (m >= V ? i0 : inner - V);
+      xv[u] = load_stream_cell_aligned<T, (int)V>(in + at);
+      if constexpr (HAS_STATUS) xs[u] = load_stream_cell_aligned<int32_t, (int)V>(st_in + at);
+    }
+    if (m < V) {
+      const int64_t next = row_src[t + 1];  // -1 past the end of the cube
+      if (next >= 0) {
+        live_y[u] = true;
+        yv[u] = load_stream_cell_aligned<T, (int)V>(in + next);
+        if constexpr (HAS_STATUS) ys[u] = load_stream_cell_aligned<int32_t, (int)V>(st_in + next);
       }
     }
   }
-  __syncthreads();  // (every wavefront reaches it; strips are private to their wavefront)
 #pragma unroll
-  for (int pp = 0; pp < P; ++pp) {
-    const uint64_t piece = first + pp;
-    if (piece >= n_pieces) break;
-    const uint64_t dst0 = piece * a.inner;
-    const uint64_t ad = dst0 & ~(uint64_t)(V - 1);
-    const uint32_t md = (uint32_t)(dst0 - ad);
-    const uint32_t groups = (md + inner + V - 1) / V;
-    for (uint32_t q = lane; q < groups; q += 64) {
-      const int32_t c = (int32_t)(q * V) - (int32_t)md;  // piece-relative cell of the group's first slot
-      Vec<T, (int)V> ov;
-      Vec<int32_t, (int)V> os;
-      bool whole = true;
+  for (int u = 0; u < U; ++u) {
+    const uint64_t c0 = c_base + ((uint64_t)u * kBlock + threadIdx.x) * V;
+    if (c0 >= n_out) continue;
+    Vec<T, (int)V> ov;
+    Vec<int32_t, (int)V> os;
 #pragma unroll
-      for (uint32_t e = 0; e < V; ++e) {
-        const int32_t ce = c + (int32_t)e;
-        const bool valid = ce >= 0 && ce < (int32_t)inner;
-        whole = whole && valid;
-        T x = Cell<T>::default_value(def_nan);
-        bool set = false;
-        if (valid && pick[pp] >= 0) {
-          x = lvp(pp)[ms[pp] + ce];
-          set = cell_is_set<T>(x, HAS_STATUS ? lsp(pp)[ms[pp] + ce] : OLAP_STATUS_SET, HAS_STATUS, def_nan);
-        }
-        ov.v[e] = set ? x : Cell<T>::default_value(def_nan);
-        os.v[e] = set ? OLAP_STATUS_SET : 0;
-      }
-      const uint64_t at = ad + (uint64_t)q * V;
-      if (whole) {
-        store_stream<T, (int)V>(out + at, ov);
-        if (st_out) store_stream<int32_t, (int)V>(st_out + at, os);
-      } else {
+    for (uint32_t e = 0; e < V; ++e) {
+      T x = xv[u].v[e];
+      int32_t sx = HAS_STATUS ? xs[u].v[e] : OLAP_STATUS_SET;
 #pragma unroll
-        for (uint32_t e = 0; e < V; ++e) {
-          const int32_t ce = c + (int32_t)e;
-          if (ce >= 0 && ce < (int32_t)inner) {
-            out[at + e] = ov.v[e];
-            if (st_out) st_out[at + e] = os.v[e];
-          }
+      for (uint32_t m = 1; m < V; ++m) {  // the group holds m cells of its first row
+        const bool is = mm[u] == m;
+        if (e < m) {
+          x = is ? xv[u].v[V - m + e] : x;
+          if constexpr (HAS_STATUS) sx = is ? xs[u].v[V - m + e] : sx;
+        } else {
+          x = is ? yv[u].v[e - m] : x;
+          if constexpr (HAS_STATUS) sx = is ? ys[u].v[e - m] : sx;
         }
       }
+      if (e == V - 1) {
+        // (never taken: mm >= 1.  It keeps the last cell of the second load alive — with that register free the
+        // allocator reuses it for the next group's scalars and the compiler waits for the load right after issuing it)
+        x = mm[u] == 0 ? yv[u].v[V - 1] : x;
+        if constexpr (HAS_STATUS) sx = mm[u] == 0 ? ys[u].v[V - 1] : sx;
+      }
+      const bool set = (e < mm[u] ? live_x[u] : live_y[u]) && cell_is_set<T>(x, sx, HAS_STATUS, def_nan);
+      ov.v[e] = set ? x : dflt;
+      os.v[e] = set ? OLAP_STATUS_SET : 0;
+    }
+    if (c0 + V <= n_out) {
+      store_stream<T, (int)V>(out + c0, ov);
+      if (st_out) store_stream<int32_t, (int)V>(st_out + c0, os);
+    } else {
+#pragma unroll
+      for (uint32_t e = 0; e < V; ++e)
+        if (c0 + e < n_out) {
+          out[c0 + e] = ov.v[e];
+          if (st_out) st_out[c0 + e] = os.v[e];
+        }
     }
   }
 }
@@ -1822,26 +1958,35 @@ __global__ __launch_bounds__(kBlock) void drilldown_rows_lines_kernel(const T *_
   const T *prow = in + (o * a.G + g) * a.inner;
   const int32_t *psrow = HAS_STATUS ? st_in + (o * a.G + g) * a.inner : nullptr;
   if constexpr (ANY) {
-    for (uint32_t c = threadIdx.x; c < CH + LINE; c += kBlock) {
+    // every lane's cells are fetched before any is used (unconditional loads, from the row's first cell where the
+    // window has none: a load inside the range test is waited for before the next one is issued)
+    constexpr uint32_t NC = (CH + LINE + kBlock - 1) / kBlock;
+    T pv[NC];
+    int32_t ps[NC];
+#pragma unroll
+    for (uint32_t q = 0; q < NC; ++q) {
+      const uint32_t c = threadIdx.x + q * kBlock;
+      const int64_t i = w0 + (int64_t)c;
+      const int64_t at = c < CH + LINE && i >= 0 && i < (int64_t)a.inner ? i : 0;
+      pv[q] = prow[at];
+      ps[q] = HAS_STATUS ? psrow[at] : OLAP_STATUS_SET;
+    }
+#pragma unroll
+    for (uint32_t q = 0; q < NC; ++q) {
+      const uint32_t c = threadIdx.x + q * kBlock;
       const int64_t i = w0 + (int64_t)c;
       T ov = T(0);
       int32_t os = 0;
       if (i >= 0 && i < (int64_t)a.inner) {
-        const T pv = prow[i];
-        if (divide == 2) {  // dice: the selected source row is copied as it is (set cells keep their value)
-          const bool set = cell_is_set<T>(pv, HAS_STATUS ? psrow[i] : OLAP_STATUS_SET, HAS_STATUS, def_nan);
-          ov = set ? pv : Cell<T>::default_value(def_nan);
-          os = set ? OLAP_STATUS_SET : 0;
-        } else {
-          const double old_value = Cell<T>::to_f64(pv);
-          const bool has = cell_is_set<T>(pv, HAS_STATUS ? psrow[i] : OLAP_STATUS_SET, HAS_STATUS, def_nan) &&
-                           old_value == old_value && old_value != 0.0;  // in-memory.js:386-387
-          const double r = divide ? old_value / n : old_value;           // :419, :422
-          emit_cell<T>(r, has && !is_default_f64(r, def_nan), def_nan, ov, os);
-        }
+        const double old_value = Cell<T>::to_f64(pv[q]);
+        const bool has = cell_is_set<T>(pv[q], ps[q], HAS_STATUS, def_nan) && old_value == old_value && old_value != 0.0;  // in-memory.js:386-387
+        const double r = divide ? old_value / n : old_value;  // :419, :422
+        emit_cell<T>(r, has && !is_default_f64(r, def_nan), def_nan, ov, os);
       }
-      lv[c] = ov;
-      ls[c] = os;
+      if (c < CH + LINE) {
+        lv[c] = ov;
+        ls[c] = os;
+      }
     }
   }
   for (uint32_t slot = threadIdx.x; !ANY && slot < SLOTS; slot += kBlock) {
@@ -2339,7 +2484,7 @@ struct Launch {
                               const DrillDown &a, hipStream_t stream);
   static hipError_t drilldown_rows(bool has_status, int vec, const T *in, const int32_t *st_in, T *out, int32_t *st_out,
                                    const DrillUpAxis &a, int divide, int use_rounding, uint32_t longest_group, hipStream_t stream);
-  static hipError_t dice_pieces(bool has_status, const T *in, const int32_t *st_in, T *out, int32_t *st_out, const DicePieces &a,
+  static hipError_t dice_direct(bool has_status, const T *in, const int32_t *st_in, T *out, int32_t *st_out, const DiceRows &a,
                                 hipStream_t stream);
   static hipError_t drilldown_rows_lines(bool has_status, bool any_shift, const T *in, const int32_t *st_in, T *out, int32_t *st_out,
                                          const DrillUpAxis &a, int divide, uint32_t longest_group, hipStream_t stream);
@@ -2466,6 +2611,37 @@ static hipError_t drillup_axis_launch(const T *in, const int32_t *st_in, T *out,
   } while (0)
   DrillUpAxis ar = a;  // the row regime's own workgroup width
   ar.blocks_per_row = (a.n_vec + row_lanes - 1) / row_lanes;
+  if constexpr (VEC == 1) {
+    // rows that are not whole 16-byte groups (or buffers that are not 16-byte aligned): 16-byte slots at
+    // cell-aligned addresses instead of 4-byte lanes
+    constexpr int RV = 16 / sizeof(T);
+    static const bool no_ragged = getenv("OLAP_NO_RAGGED_ROWS") != nullptr;
+    if (rows && !no_ragged) {
+      DrillUpAxis rg = a;
+      rg.n_vec = (a.inner + RV - 1) / RV;
+      unsigned lanes = kBlock;
+      double best = 0.0;
+      for (unsigned cand : {256u, 128u, 64u}) {
+        const double fill = (double)rg.n_vec / (double)(((rg.n_vec + cand - 1) / cand) * cand);
+        if (fill >= 0.85) { lanes = cand; break; }
+        if (fill > best) { best = fill; lanes = cand; }
+      }
+      rg.blocks_per_row = (rg.n_vec + lanes - 1) / lanes;
+      const uint64_t blocks = a.outer * a.G * rg.blocks_per_row;
+      if (blocks < 0x7FFFFFFFull) {
+#define OLAP_RAGGED(C, F) hipLaunchKernelGGL((drillup_rows_kernel<T, METHOD, HS, RV, U, C, F, true, true>), (unsigned)blocks, lanes, 0, stream, in, st_in, out, st_out, rg)
+        if constexpr (kAdditive && !HS) {
+          if (fast) {
+            if (contig) OLAP_RAGGED(true, true); else OLAP_RAGGED(false, true);
+            return hipGetLastError();
+          }
+        }
+        if (contig) OLAP_RAGGED(true, false); else OLAP_RAGGED(false, false);
+#undef OLAP_RAGGED
+        return hipGetLastError();
+      }
+    }
+  }
   if (rows) {
     if constexpr (kAdditive && !HS) {
       if (fast) {
@@ -2609,34 +2785,23 @@ hipError_t Launch<T>::drillup_generic(int method, bool has_status, const T *in, 
 }
 
 template <typename T>
-hipError_t Launch<T>::dice_pieces(bool has_status, const T *in, const int32_t *st_in, T *out, int32_t *st_out, const DicePieces &a0,
+hipError_t Launch<T>::dice_direct(bool has_status, const T *in, const int32_t *st_in, T *out, int32_t *st_out, const DiceRows &p,
                                   hipStream_t stream) {
-  const uint64_t pieces = a0.outer * a0.k_new;
-  if (pieces == 0 || a0.inner == 0) return hipSuccess;
-  // A 1 KiB piece alone leaves the memory pipeline mostly waiting (bytes in flight per CU = waves x piece), so a
-  // wavefront takes P consecutive pieces and issues all their loads first — as many as keep 8 workgroups (32 waves)
-  // per CU with strips sized by the actual piece.  (With strips sized for the longest piece, two per wavefront halved
-  // the occupancy and measured 113 us against 75 us.)
-  DicePieces a = a0;
-  constexpr uint32_t V = 16 / sizeof(T);
-  a.strip = (uint32_t)(((a.inner + V - 1) / V + 2) * V);
-  const size_t strip_bytes = (size_t)a.strip * (sizeof(T) + (has_status ? 4 : 0));
-  const uint64_t waves = kBlock / 64;
-  // measured on 1 084-byte pieces (tools/pmc_probe.py): 70.6 / 70.0 / 71.8 us with 1 / 2 / 4 pieces per wavefront — bytes
-  // in flight are not what bounds this form either
-  int P = waves * 2 * strip_bytes <= 20 * 1024 ? 2 : 1;
-  if (const char *e = getenv("OLAP_DICE_PIECES_PER_WAVE")) P = atoi(e) >= 4 ? 4 : atoi(e) >= 2 ? 2 : 1;
-  const size_t lds = waves * P * strip_bytes;
-  const uint64_t per_block = waves * P;
-  const uint64_t blocks = (pieces + per_block - 1) / per_block;
-  if (blocks >= 0x7FFFFFFFull || lds > 64 * 1024) return hipErrorInvalidValue;
-#define OLAP_PIECES(HS, PP) hipLaunchKernelGGL((dice_pieces_kernel<T, HS, PP>), (unsigned)blocks, kBlock, lds, stream, in, st_in, out, st_out, a)
+  DiceDirect a;
+  if (!dice_direct_fits<T>(p, &a)) return hipErrorInvalidValue;
+  const int groups = dice_direct_groups();
+  const uint64_t SPAN = (uint64_t)groups * kBlock * (16 / sizeof(T));
+  const uint64_t n_out = p.outer * p.k_new * p.inner;
+  if (n_out == 0) return hipSuccess;
+  const unsigned blocks = (unsigned)((n_out + SPAN - 1) / SPAN);
+  const size_t lds = (size_t)a.rows * sizeof(int64_t);  // <= (SPAN / V + 3) entries
+#define OLAP_DD(HS, UU) hipLaunchKernelGGL((dice_direct_kernel<T, HS, UU>), blocks, kBlock, lds, stream, in, st_in, out, st_out, a)
   if (has_status) {
-    if (P == 4) OLAP_PIECES(true, 4); else if (P == 2) OLAP_PIECES(true, 2); else OLAP_PIECES(true, 1);
+    if (groups == 1) OLAP_DD(true, 1); else if (groups == 2) OLAP_DD(true, 2); else if (groups == 8) OLAP_DD(true, 8); else OLAP_DD(true, 4);
   } else {
-    if (P == 4) OLAP_PIECES(false, 4); else if (P == 2) OLAP_PIECES(false, 2); else OLAP_PIECES(false, 1);
+    if (groups == 1) OLAP_DD(false, 1); else if (groups == 2) OLAP_DD(false, 2); else if (groups == 8) OLAP_DD(false, 8); else OLAP_DD(false, 4);
   }
-#undef OLAP_PIECES
+#undef OLAP_DD
   return hipGetLastError();
 }
 

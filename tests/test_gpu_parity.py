@@ -907,7 +907,8 @@ def test_tile_regime_long_last_dimension(K, type_name, method):
 @pytest.mark.parametrize("messy", [False, True])
 def test_dice_row_copies_odd_extents(lens, axis, type_name, default, messy):
     """dice of one dimension of a cube with odd extents, every new item naming a distinct old item
-    (subset, reordered): row copies through line-aligned windows instead of the 4-byte gather."""
+    (subset, reordered), with and without an unknown item and an old item named twice: dice_direct_kernel
+    instead of the 4-byte gather."""
     rng = np.random.default_rng(53)
     n = int(np.prod(lens))
     vals = rng.integers(1, 500, size=n).astype(np.float64)
@@ -924,10 +925,8 @@ def test_dice_row_copies_odd_extents(lens, axis, type_name, default, messy):
     inner = int(np.prod(lens[axis + 1:]))
     isz = np.dtype(type_name).itemsize
     odd = inner % (16 // isz) != 0
-    if odd and 256 <= inner * isz <= 4096:
-        expected = "dice_pieces_kernel"            # one wavefront per row piece
-    elif odd and inner * isz >= 2048 and not messy:
-        expected = "drilldown_rows_lines_kernel(dice)"  # row copies through line-aligned windows
+    if odd and inner >= 16 // isz:
+        expected = "dice_direct_kernel"  # aligned destination groups, one cell-aligned 16-byte load each
     else:
         expected = "gather(dice)"
     assert plan.kernel_name == expected, plan.kernel_name

@@ -29,6 +29,8 @@ def bench(plan_fn, n_in, n_out, elem=4, with_mask=False, iters=30):
     ost = eng.empty(n_out, "int32")
     plan = plan_fn()
     args = (vals.data_ptr(), st.data_ptr() if with_mask else None, out.data_ptr(), ost.data_ptr() if with_mask else None, eng.stream())
+    if os.environ.get("OLAP_SWEEP_PTRS"):  # where the buffers of this case lie (placement experiments)
+        print("    in %#x  mask %#x  out %#x  out mask %#x" % (vals.data_ptr(), st.data_ptr(), out.data_ptr(), ost.data_ptr()), flush=True)
     for _ in range(3):
         plan.run(*args)
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
