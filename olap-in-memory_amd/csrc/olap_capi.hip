@@ -404,6 +404,28 @@ extern "C" int olap_drillup_plan(olap_plan **out, int dtype, int default_kind, i
     }
     a.gstart = (const uint32_t *)p->dev_tab;
     a.order = contiguous ? nullptr : (const uint32_t *)p->dev_tab + order_off;
+    // row-tile regime with interleaved groups (drillup_tile_kernel MODE 3): where every cell of a row goes in
+    // the permuted tile
+    a.perm_cell = a.perm_grp = nullptr;
+    a.perm_pitch = 0;
+    {
+      const uint64_t budget = kTileBytes / olap_dtype_size(dtype);
+      if (!contiguous && a.inner > 0 && a.inner < 4096 && a.K * a.inner <= budget) {
+        TilePerm tp;
+        tile_perm_build(gstart.data(), order.data(), (uint32_t)a.K, (uint32_t)a.G, (uint32_t)a.inner, budget, 16 / olap_dtype_size(dtype), &tp);
+        std::vector<uint32_t> both(tp.cell);
+        both.insert(both.end(), tp.grp.begin(), tp.grp.end());
+        void *dev_perm = nullptr;
+        if ((rc = upload(&dev_perm, both.data(), both.size() * sizeof(uint32_t)))) {
+          olap_plan_destroy(p);
+          return rc;
+        }
+        p->owned.push_back(dev_perm);
+        a.perm_cell = (const uint32_t *)dev_perm;
+        a.perm_grp = (const uint32_t *)dev_perm + tp.cell.size();
+        a.perm_pitch = tp.pitch;
+      }
+    }
     // group-tile regime (drillup_gtile_kernel): contiguous groups, short row pieces, rows too long for
     // the row-tile regime; the group list is cut into tiles of whole groups that fit kTileBytes
     bool gtile_ok = false;
@@ -507,7 +529,7 @@ extern "C" int olap_drillup_plan(olap_plan **out, int dtype, int default_kind, i
     else if (a.inner / (uint64_t)p->vec >= 128) p->kernel_name = "drillup_rows_kernel";
     else if (gtile_ok) p->kernel_name = "drillup_gtile_kernel";
     else if (a.inner < 128 && a.K * a.inner <= (16 * 1024) / olap_dtype_size(dtype) && a.K * a.inner > 0 &&
-             (a.G + 1 + (contiguous ? 0 : a.K)) * 4 <= 16 * 1024)
+             (a.perm_cell && !getenv("OLAP_TILE_NO_PERMUTE") ? 2 * a.G : a.G + 1 + (contiguous ? 0 : a.K)) * 4 <= 16 * 1024)
       p->kernel_name = "drillup_tile_kernel";  // (the launcher re-checks alignment; may still pick the flat form)
     else p->kernel_name = "drillup_flat_kernel";
   } else {
@@ -1563,6 +1585,74 @@ extern "C" int olap_plan_run(olap_plan *p, const void *in_values, const int32_t 
   }
 }
 
+// One launch for several measures (Batch<T>): drillUp plans of one axis outside the cooperative reduce regime (whose
+// workspace belongs to the plan); everything else runs pair by pair — still one call for the host.
+template <typename T>
+static int run_batch_typed(olap_plan *p, int n, const void *const *in_v, const int32_t *const *in_s, void *const *out_v,
+                           int32_t *const *out_s, hipStream_t stream) {
+  const bool hs = in_s && in_s[0];
+  for (int first = 0; first < n; first += kMaxBatch) {
+    const int nb = std::min(n - first, (int)kMaxBatch);
+    Batch<T> b{};
+    bool al = true;
+    for (int i = 0; i < nb; ++i) {
+      b.in[i] = (const T *)in_v[first + i];
+      b.st_in[i] = hs ? in_s[first + i] : nullptr;
+      b.out[i] = (T *)out_v[first + i];
+      b.st_out[i] = out_s ? out_s[first + i] : nullptr;
+      al = al && aligned16(b.in[i]) && aligned16(b.out[i]) && (!b.st_in[i] || aligned16(b.st_in[i])) && (!b.st_out[i] || aligned16(b.st_out[i]));
+    }
+    DrillUpAxis a = p->axis;
+    int vec = p->vec;
+    a.aligned16 = al;
+    if (!al) vec = 1;
+    a.n_vec = a.inner / (uint64_t)vec;
+    a.total = a.outer * a.G * a.n_vec;
+    a.blocks_per_row = (a.n_vec + kBlock - 1) / kBlock;
+    { const char *x = getenv("OLAP_XCD_ORDER"); a.xcd_order = x ? atoi(x) : 1; }
+    hipError_t e = Launch<T>::drillup_axis_batch(p->method, hs, vec, b, (unsigned)nb, a, stream);
+    if (e != hipSuccess) return hip_fail(e, p->kernel_name.c_str());
+  }
+  return OLAP_OK;
+}
+
+extern "C" int olap_plan_run_batch(olap_plan *p, int n, const void *const *in_values, const int32_t *const *in_status,
+                                   void *const *out_values, int32_t *const *out_status, void *stream) {
+  if (!p) return fail(OLAP_ERR_INVALID_ARGUMENT, "plan is NULL");
+  if (n < 0 || (n > 0 && (!in_values || !out_values))) return fail(OLAP_ERR_INVALID_ARGUMENT, "batch of %d: values pointer lists must not be NULL", n);
+  if (plan_dry()) return fail(OLAP_ERR_NO_DEVICE, "OLAP_PLAN_DRY is set: plans are built for inspection only; libolapgpu has no CPU fallback");
+  bool masks_in = false, masks_out = false, mixed = false;
+  for (int i = 0; i < n; ++i) {
+    if ((p->in_cells && !in_values[i]) || (p->out_cells && !out_values[i]))
+      return fail(OLAP_ERR_INVALID_ARGUMENT, "values pointers must not be NULL (pair %d of the batch)", i);
+    const bool mi = in_status && in_status[i], mo = out_status && out_status[i];
+    if (i == 0) masks_in = mi, masks_out = mo;
+    else if (mi != masks_in || mo != masks_out) mixed = true;
+  }
+  const bool one_launch = p->kind == PLAN_DRILLUP_AXIS && p->reduce.S == 0 && !mixed && n > 1;
+  if (!one_launch) {
+    for (int i = 0; i < n; ++i) {
+      const int rc = olap_plan_run(p, in_values[i], in_status ? in_status[i] : nullptr, out_values[i], out_status ? out_status[i] : nullptr, stream);
+      if (rc) return rc;
+    }
+    return OLAP_OK;
+  }
+  {
+    int cur = -1;
+    if (hipGetDevice(&cur) == hipSuccess && cur != p->device)
+      return fail(OLAP_ERR_INVALID_ARGUMENT, "plan was built on device %d but the current device is %d", p->device, cur);
+  }
+  hipStream_t s = (hipStream_t)stream;
+  p->last_stream = s;
+  p->ran = true;
+  switch (p->dtype) {
+    case OLAP_INT32: return run_batch_typed<int32_t>(p, n, in_values, in_status, out_values, out_status, s);
+    case OLAP_UINT32: return run_batch_typed<uint32_t>(p, n, in_values, in_status, out_values, out_status, s);
+    case OLAP_FLOAT32: return run_batch_typed<float>(p, n, in_values, in_status, out_values, out_status, s);
+    default: return run_batch_typed<double>(p, n, in_values, in_status, out_values, out_status, s);
+  }
+}
+
 extern "C" int olap_plan_status(olap_plan *p) {
   if (!p) return fail(OLAP_ERR_INVALID_ARGUMENT, "plan is NULL");
   if (p->kind != PLAN_DRILLDOWN || !p->dd.dist || !p->ran) return OLAP_OK;
@@ -2430,6 +2520,74 @@ int store_drillup_plain(const olap_store *s, olap_store **out, int ndim, const u
   if (!rc) rc = run_to_new_store(plan, s, out);
   plan_cache().release(plan);
   return rc;
+}
+
+// Cube.drillUp over several stored measures that share cell type, default and rule (src/cube.js:1012-1020 calls the
+// store once per measure): one plan, one launch (olap_plan_run_batch).  Stores that differ in type or default, or that
+// track their insertion order, take the single-store path one by one — same results, n launches.
+extern "C" int olap_store_drillup_batch(int n, const olap_store *const *stores, olap_store **out, int ndim, const uint32_t *old_len,
+                                        const uint32_t *new_len, const uint32_t *const *maps, int method) {
+  if (n < 0 || (n > 0 && (!stores || !out))) return fail(OLAP_ERR_INVALID_ARGUMENT, "store list is NULL");
+  for (int i = 0; i < n; ++i) out[i] = nullptr;
+  for (int i = 0; i < n; ++i)
+    if (!stores[i]) return fail(OLAP_ERR_INVALID_ARGUMENT, "store %d of the batch is NULL", i);
+  bool same = n > 1;
+  for (int i = 0; i < n && same; ++i)
+    same = stores[i]->dtype == stores[0]->dtype && stores[i]->default_kind == stores[0]->default_kind && stores[i]->size == stores[0]->size &&
+           stores[i]->device == stores[0]->device && !stores[i]->track_order;
+  auto undo = [&](int rc) {
+    for (int i = 0; i < n; ++i) {
+      if (out[i]) olap_store_destroy(out[i]);
+      out[i] = nullptr;
+    }
+    return rc;
+  };
+  if (!same || bad_dims(ndim, old_len, new_len) || (ndim > 0 && !maps)) {
+    for (int i = 0; i < n; ++i) {
+      const int rc = olap_store_drillup(stores[i], &out[i], ndim, old_len, new_len, maps, method);
+      if (rc) return undo(rc);
+    }
+    return OLAP_OK;
+  }
+  const olap_store *s0 = stores[0];
+  OnStoreDevice on_device__(s0);
+  olap_plan *plan = nullptr;
+  PlanKey key;
+  bool keyable = true;
+  for (int d = 0; d < ndim; ++d) keyable = keyable && (old_len[d] == 0 || maps[d]);
+  if (keyable) {
+    key.i32('U');
+    key.i32(s0->dtype), key.i32(s0->default_kind), key.i32(method), key.i32(ndim);
+    key.u32s(old_len, ndim), key.u32s(new_len, ndim);
+    key.tables(maps, old_len, ndim);
+    plan = plan_cache().find(key.bytes);
+  }
+  bool cached = plan != nullptr;
+  if (!plan) {
+    int rc = olap_drillup_plan(&plan, s0->dtype, s0->default_kind, method, ndim, old_len, new_len, maps);
+    if (rc) return rc;
+    if (keyable) {
+      plan_cache().insert(key.bytes, plan);
+      cached = true;
+    }
+  }
+  int rc = check_store_cells(s0, plan);
+  std::vector<const void *> in_v(n);
+  std::vector<const int32_t *> in_s(n);
+  std::vector<void *> out_v(n);
+  std::vector<int32_t *> out_s(n);
+  for (int i = 0; i < n && !rc; ++i) {
+    rc = store_alloc(&out[i], olap_plan_out_cells(plan), s0->dtype, s0->default_kind);
+    if (rc) break;
+    in_v[i] = stores[i]->values;
+    in_s[i] = mask_needed(stores[i]);
+    out_v[i] = out[i]->values;
+    out_s[i] = out[i]->status;
+  }
+  if (!rc) rc = olap_plan_run_batch(plan, n, in_v.data(), in_s.data(), out_v.data(), out_s.data(), nullptr);
+  if (cached) plan_cache().release(plan);
+  else olap_plan_destroy(plan);
+  return rc ? undo(rc) : OLAP_OK;
 }
 
 static int store_drilldown_plain(const olap_store *s, olap_store **out, int ndim, const uint32_t *old_len,

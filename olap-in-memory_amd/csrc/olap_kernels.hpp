@@ -10,6 +10,7 @@
 #include <cstdlib>
 
 #include <type_traits>
+#include <vector>
 
 #include "olap_device.hpp"
 
@@ -34,6 +35,30 @@ struct DrillUpAxis {
   int xcd_order;          // row regime: walk workgroups in XCD-contiguous order
   const uint32_t *gtile;  // device, or nullptr: group-tile regime, first group of every tile [n_gtile + 1]
   uint32_t n_gtile;
+  const uint32_t *perm_cell;  // device, or nullptr: row-tile regime with interleaved groups (TilePerm), [K * inner + 3]
+  const uint32_t *perm_grp;   // device, [2 G]
+  uint32_t perm_pitch;        // members between two rows of the permuted tile
+};
+
+// Several measures of a cube in ONE launch: the same drillUp (cell type, default, rule, shape, map) over up to
+// kMaxBatch independent (input, output) buffer pairs; blockIdx.y picks the pair.  Cube.drillUp calls the store once
+// per measure (src/cube.js:1012-1020); on cubes of a few MB a launch costs more than the bytes it moves, so the
+// measures that share a rule share a launch (olap_plan_run_batch).  A single measure is a batch of one.
+constexpr int kMaxBatch = 8;
+template <typename T>
+struct Batch {
+  const T *in[kMaxBatch];
+  const int32_t *st_in[kMaxBatch];
+  T *out[kMaxBatch];
+  int32_t *st_out[kMaxBatch];
+  static Batch one(const T *in, const int32_t *st_in, T *out, int32_t *st_out) {
+    Batch b{};
+    b.in[0] = in;
+    b.st_in[0] = st_in;
+    b.out[0] = out;
+    b.st_out[0] = st_out;
+    return b;
+  }
 };
 
 // Per-lane accumulator of VEC adjacent output cells.  Additive/product methods run Agg<> in
@@ -121,11 +146,11 @@ struct Lane {
 // side, +7 % on stores: tools/unaligned_probe.hip) and only the row's last, partial slot goes cell by cell —
 // instead of 4-byte lanes (four times the load instructions and waves for the same bytes).
 template <typename T, int METHOD, bool HAS_STATUS, int VEC, int U, bool CONTIG, bool FAST, bool NT = true, bool RAGGED = false>
-__global__ __launch_bounds__(kBlock) void drillup_rows_kernel(const T *__restrict__ in,
-                                                              const int32_t *__restrict__ st_in,
-                                                              T *__restrict__ out,
-                                                              int32_t *__restrict__ st_out,
-                                                              const DrillUpAxis a) {
+__global__ __launch_bounds__(kBlock) void drillup_rows_kernel(const Batch<T> b, const DrillUpAxis a) {
+  const T *__restrict__ in = b.in[blockIdx.y];
+  const int32_t *__restrict__ st_in = b.st_in[blockIdx.y];
+  T *__restrict__ out = b.out[blockIdx.y];
+  int32_t *__restrict__ st_out = b.st_out[blockIdx.y];
   // blocks_per_row = ceil(n_vec / kBlock); blockIdx.x = og * blocks_per_row + chunk  (uniform math)
   const uint32_t bpr = (uint32_t)a.blocks_per_row;
   const uint32_t bid = a.xcd_order ? xcd_contiguous(blockIdx.x, gridDim.x) : blockIdx.x;
@@ -184,6 +209,26 @@ __global__ __launch_bounds__(kBlock) void drillup_rows_kernel(const T *__restric
         }
       }
     };
+    // (not for values + mask — two streams per row already: 149 -> 151 us with it — and not for the plain sums, whose
+    // fold is eight instructions: no difference beyond the run-to-run spread in a same-box A/B)
+    constexpr bool kPrefetch = U == 1 && !FAST && !HAS_STATUS;
+    if constexpr (kPrefetch) {
+      // one row in flight, but the next row is requested BEFORE the current one is folded in: the exact state
+      // machine / the NaN-propagating picks are a dozen VALU instructions per cell, which otherwise sit between
+      // one row's arrival and the next row's request on every lane's critical path
+      if (j < jend) {
+        fetch(CONTIG ? (uint64_t)j : (uint64_t)a.order[j], v[0], s[0]);
+        for (++j; j < jend; ++j) {
+          Vec<T, VEC> nv;
+          Vec<int32_t, VEC> ns;
+          fetch(CONTIG ? (uint64_t)j : (uint64_t)a.order[j], nv, ns);
+          lane.add_row(v[0], s[0], def_nan);
+          v[0] = nv;
+          s[0] = ns;
+        }
+        lane.add_row(v[0], s[0], def_nan);
+      }
+    }
     for (; j + U <= jend; j += U) {
 #pragma unroll
       for (int u = 0; u < U; ++u) fetch(CONTIG ? (uint64_t)(j + u) : (uint64_t)a.order[j + u], v[u], s[u]);
@@ -231,11 +276,11 @@ __global__ __launch_bounds__(kBlock) void drillup_rows_kernel(const T *__restric
 // IDX: the lane index is decoded in 32-bit arithmetic when the launch has < 2^32 lanes (a 64-bit
 // division is a long software sequence on CDNA).
 template <typename T, int METHOD, bool HAS_STATUS, int VEC, bool FAST, typename IDX>
-__global__ __launch_bounds__(kBlock) void drillup_flat_kernel(const T *__restrict__ in,
-                                                              const int32_t *__restrict__ st_in,
-                                                              T *__restrict__ out,
-                                                              int32_t *__restrict__ st_out,
-                                                              const DrillUpAxis a) {
+__global__ __launch_bounds__(kBlock) void drillup_flat_kernel(const Batch<T> b, const DrillUpAxis a) {
+  const T *__restrict__ in = b.in[blockIdx.y];
+  const int32_t *__restrict__ st_in = b.st_in[blockIdx.y];
+  T *__restrict__ out = b.out[blockIdx.y];
+  int32_t *__restrict__ st_out = b.st_out[blockIdx.y];
   const IDX t = (IDX)blockIdx.x * kBlock + threadIdx.x;
   if ((uint64_t)t >= a.total) return;
   const IDX nv = (IDX)a.n_vec, ng = (IDX)a.G;
@@ -278,6 +323,32 @@ __global__ __launch_bounds__(kBlock) void drillup_flat_kernel(const T *__restric
   lane.template finish_and_store<false>(def_nan, out, st_out, (o * a.G + g) * a.inner + i0);
 }
 
+struct SmallDiv {
+  uint32_t d, magic;
+  int how;  // 0: mul-hi by magic; 1: x < 2 d, one compare; 2: d == 1
+};
+__device__ __forceinline__ uint32_t small_div(uint32_t x, const SmallDiv &s) {
+  return s.how == 0 ? __umulhi(x, s.magic) : s.how == 1 ? (x >= s.d ? 1u : 0u) : x;
+}
+// exact for every x <= x_max, or false (m = floor(2^32 / d) + 1 is exact while x d < 2^32)
+inline bool small_div_for(uint64_t d, uint64_t x_max, SmallDiv *out) {
+  if (d == 0 || d > 0xFFFFFFFFull || x_max > 0xFFFFFFFFull) return false;
+  out->d = (uint32_t)d;
+  out->magic = 0;
+  if (d == 1) {
+    out->how = 2;
+    return x_max <= 0xFFFFFFFFull;
+  }
+  if (x_max < 2 * d) {
+    out->how = 1;
+    return true;
+  }
+  if (x_max * d >= (1ull << 32)) return false;
+  out->how = 0;
+  out->magic = (uint32_t)((1ull << 32) / d + 1);
+  return true;
+}
+
 // Tile regime (inner small, K*inner fits LDS): the LDS-staged segmented reduction.  A row of the
 // view is K*inner CONTIGUOUS cells, so a workgroup stages R whole rows with coalesced 16 B streaming
 // loads, then every lane reduces output cells (row, group, i) out of LDS walking the group's
@@ -288,20 +359,117 @@ struct DrillUpTile {
   uint32_t row_elems;       // K * inner
   uint32_t out_row;         // G * inner
   uint32_t inner;
+  // MODE 3 (cells permuted into group order on their way into LDS; tables built by the plan, tile_perm_build)
+  SmallDiv by_row;              // row of a staged cell without a hardware division
+  const uint32_t *perm_cell;    // device, [row_elems + V]: LDS position of every cell of a row (+ the next row's first cells)
+  const uint32_t *perm_grp;     // device, [2 G]: first and one-past-last position (in members) of every group's run
+  uint32_t pitch_cells;         // LDS cells between two rows of the tile (>= row_elems: runs start on chosen banks)
 };
+
+// Host side of MODE 3: where the members of a row go in the permuted tile.  Group g's members become the run
+// [start[g], start[g] + size[g]) (in members; a member is `inner` cells), rows are `pitch` members apart.  The
+// reduction's lanes are (row, group, i) in that order and read member j of their runs in one instruction, so the
+// runs' first cells should fall on distinct LDS banks (32 banks of 4 bytes): start[g] = c g and pitch = c G modulo
+// 32 / gcd(inner, 32) puts lane x of 32 consecutive lanes on bank c x (inner = 1, c odd: a permutation of the banks)
+// or on bank x (inner > 1, c = 1).  c is the odd multiplier that pads least — equal runs of odd length need no
+// padding at all, of even length one cell each.  When the padding would cost more than a quarter of the rows a tile
+// holds, runs are packed (start = gstart) and the bank conflicts are accepted.
+struct TilePerm {
+  std::vector<uint32_t> cell;  // [K * inner + 3]: LDS cell of every cell of a row; entries past the row run into the next row(s)
+  std::vector<uint32_t> grp;   // [2 G]: start[g], start[g] + size[g]
+  uint32_t pitch = 0;
+};
+inline uint64_t tile_rows_for(uint64_t row_elems, uint64_t pitch_cells, uint64_t budget_cells, uint64_t V) {
+  uint64_t R = pitch_cells ? budget_cells / pitch_cells : 0;
+  if (R >= 4) R &= ~3ull;
+  while (R > 0 && (R * row_elems) % V != 0) --R;  // every tile must start 16 B aligned
+  return R;
+}
+inline void tile_perm_build(const uint32_t *gstart, const uint32_t *order, uint32_t K, uint32_t G, uint32_t inner,
+                            uint64_t budget_cells, uint64_t V, TilePerm *out) {
+  uint32_t gcd = inner, b = 32;
+  while (b) {
+    const uint32_t t = gcd % b;
+    gcd = b;
+    b = t;
+  }
+  const uint32_t M = 32 / gcd;
+  auto layout = [&](uint32_t c, std::vector<uint32_t> *start) {
+    uint64_t s = 0;
+    for (uint32_t g = 0; g < G; ++g) {
+      s += ((uint64_t)c * g % M + M - s % M) % M;
+      if (start) (*start)[g] = (uint32_t)s;
+      s += gstart[g + 1] - gstart[g];
+    }
+    s += ((uint64_t)c * G % M + M - s % M) % M;
+    return s;
+  };
+  uint32_t best_c = 0;
+  uint64_t best = ~0ull;
+  for (uint32_t c = 1; c < 32; c += 2) {
+    const uint64_t pitch = layout(c, nullptr);
+    if (pitch < best) {
+      best = pitch;
+      best_c = c;
+    }
+    if (inner != 1) break;
+  }
+  const uint64_t row_elems = (uint64_t)K * inner;
+  std::vector<uint32_t> start(G);
+  const uint64_t rows_packed = tile_rows_for(row_elems, row_elems, budget_cells, V);
+  if (M > 1 && tile_rows_for(row_elems, best * inner, budget_cells, V) * 4 >= rows_packed * 3 && best * inner <= budget_cells) {
+    out->pitch = (uint32_t)layout(best_c, &start);
+  } else {
+    for (uint32_t g = 0; g < G; ++g) start[g] = gstart[g];
+    out->pitch = K;
+  }
+  out->grp.resize(2 * (size_t)G);
+  out->cell.assign(row_elems + 3, 0);
+  for (uint32_t g = 0; g < G; ++g) {
+    out->grp[2 * g] = start[g];
+    out->grp[2 * g + 1] = start[g] + (gstart[g + 1] - gstart[g]);
+    for (uint32_t j = gstart[g]; j < gstart[g + 1]; ++j)
+      for (uint32_t i = 0; i < inner; ++i) out->cell[(uint64_t)order[j] * inner + i] = (start[g] + (j - gstart[g])) * inner + i;
+  }
+  for (uint64_t idx = row_elems; idx < row_elems + 3; ++idx)
+    out->cell[idx] = out->cell[idx % row_elems] + (uint32_t)(idx / row_elems) * out->pitch * inner;
+}
+
+// tools/tile_probe.hip builds this header with OLAP_TILE_PROBE: lane 0 of every workgroup of the tile kernel then
+// records the 100 MHz wall clock at its phase boundaries (not compiled into the product)
+#ifdef OLAP_TILE_PROBE
+__device__ unsigned long long g_tile_probe[1 << 20];
+#define OLAP_PROBE(i)                                                                         \
+  do {                                                                                       \
+    if (threadIdx.x == 0 && blockIdx.x < (1u << 17)) g_tile_probe[blockIdx.x * 8 + (i)] = wall_clock64(); \
+  } while (0)
+__device__ __forceinline__ void g_probe3(uint32_t b) {
+  if (b < (1u << 17)) g_tile_probe[b * 8 + 3] = wall_clock64();
+}
+#else
+#define OLAP_PROBE(i) do { } while (0)
+__device__ __forceinline__ void g_probe3(uint32_t) {}
+#endif
 
 constexpr uint32_t kTileBytes = 16 * 1024;  // cells staged per workgroup: 8 workgroups (32 waves) per CU
 
 // MODE 1 (ALL): one group holding every member in order (the '-> all' roll-ups of slice /
 // removeDimension / collapse): no table reads at all.  MODE 2: groups are contiguous member runs
 // (calendars, attribute roll-ups of sorted items): only gstart[G+1] goes to LDS.  MODE 0: gstart and
-// the member list are copied to LDS once per workgroup.
+// the member list are copied to LDS once per workgroup.  MODE 3 (interleaved groups, the default for them):
+// the cells are PERMUTED into group order on their way into LDS — every group's members become one contiguous
+// run — so that the reduction walks runs as MODE 2 does.  The reduction of MODE 0 reads a member index and then the
+// cell, two dependent LDS round trips per member on the critical path of a lane that walks ~K/G members, and copies
+// the member list into LDS behind the tile's loads; with few outputs per tile (4 rows x 10 groups of 100 members)
+// a workgroup lived 6.6 us of which 3 us reducing (tools/tile_probe.hip).  The runs' first cells are also placed
+// on distinct LDS banks (TilePerm below): lanes (row, group) read member j of their runs in the same instruction,
+// and with runs 100 cells apart 40 lanes shared 8 banks.
 template <typename T, int METHOD, bool HAS_STATUS, bool FAST, int MODE>
-__global__ __launch_bounds__(kBlock) void drillup_tile_kernel(const T *__restrict__ in,
-                                                              const int32_t *__restrict__ st_in,
-                                                              T *__restrict__ out,
-                                                              int32_t *__restrict__ st_out,
-                                                              const DrillUpAxis a, const DrillUpTile tl) {
+__global__ __launch_bounds__(kBlock) void drillup_tile_kernel(const Batch<T> b, const DrillUpAxis a, const DrillUpTile tl) {
+  const T *__restrict__ in = b.in[blockIdx.y];
+  const int32_t *__restrict__ st_in = b.st_in[blockIdx.y];
+  T *__restrict__ out = b.out[blockIdx.y];
+  int32_t *__restrict__ st_out = b.st_out[blockIdx.y];
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   constexpr int V = 16 / sizeof(T);                       // cells per 16 B access
   constexpr uint32_t kCells = kTileBytes / sizeof(T);     // capacity of the staged tile
@@ -310,8 +478,9 @@ __global__ __launch_bounds__(kBlock) void drillup_tile_kernel(const T *__restric
   int32_t *stile = reinterpret_cast<int32_t *>(lds_raw + kTileBytes);
   uint32_t *csr = reinterpret_cast<uint32_t *>(lds_raw + kTileBytes + (HAS_STATUS ? kCells * 4 : 0));
   constexpr bool ALL = MODE == 1;
+  constexpr bool PERMUTE = MODE == 3;
   uint32_t *l_gstart = csr;                 // G + 1 entries
-  uint32_t *l_order = csr + a.G + 1;        // K entries (MODE 0 only)
+  uint32_t *l_order = csr + a.G + 1;        // K entries (MODE 0: member list; MODE 3: rank of every member)
 
   const uint64_t row0 = (uint64_t)(a.xcd_order ? xcd_contiguous(blockIdx.x, gridDim.x) : blockIdx.x) * tl.rows_per_tile;
   const uint32_t rows = (uint32_t)((a.outer - row0) < tl.rows_per_tile ? (a.outer - row0) : tl.rows_per_tile);
@@ -320,10 +489,29 @@ __global__ __launch_bounds__(kBlock) void drillup_tile_kernel(const T *__restric
   const int32_t *ssrc = HAS_STATUS ? st_in + row0 * tl.row_elems : nullptr;
   const bool def_nan = a.def_nan != 0;
 
+  OLAP_PROBE(0);
   // stage: all global loads of the lane first, then the LDS writes
   const uint32_t n_vec = n_in / V;
   Vec<T, V> v[NL];
   Vec<int32_t, V> sv[NL];
+  // MODE 3: where the lane's cells go (tl.perm_cell, built by the plan: the LDS position of every cell of a row, plus V
+  // entries that run into the next row) and the bounds of one group, requested BEFORE the cells — loads complete in
+  // order, so a table load issued behind the tile's would be waited for with the whole tile in front of it.  The
+  // table is a few KB read by every workgroup (L2 / L1 hits) with one 16-byte load at a 4-byte-aligned address per
+  // 16 bytes of cells.
+  typedef uint32_t PosVec __attribute__((ext_vector_type(V), aligned(4)));
+  PosVec pos[NL];
+  uint32_t grp0 = 0;
+  if constexpr (PERMUTE) {
+#pragma unroll
+    for (int u = 0; u < NL; ++u) {
+      const uint32_t iv = threadIdx.x + u * kBlock;
+      const uint32_t c0 = iv < n_vec ? iv * V : 0u;
+      const uint32_t r = small_div(c0, tl.by_row);
+      pos[u] = *reinterpret_cast<const PosVec *>(tl.perm_cell + (c0 - r * tl.row_elems)) + r * tl.pitch_cells;
+    }
+    grp0 = threadIdx.x < 2 * a.G ? tl.perm_grp[threadIdx.x] : 0u;
+  }
 #pragma unroll
   for (int u = 0; u < NL; ++u) {
     const uint32_t i = threadIdx.x + u * kBlock;
@@ -332,26 +520,52 @@ __global__ __launch_bounds__(kBlock) void drillup_tile_kernel(const T *__restric
       if constexpr (HAS_STATUS) sv[u] = load_stream<int32_t, V>(ssrc + (uint64_t)i * V);
     }
   }
-  if constexpr (!ALL) {
-    for (uint32_t i = threadIdx.x; i <= a.G; i += kBlock) l_gstart[i] = a.gstart[i];
-    if constexpr (MODE == 0)
-      for (uint32_t i = threadIdx.x; i < a.K; i += kBlock) l_order[i] = a.order[i];
-  }
+  if constexpr (PERMUTE) {
+    if (threadIdx.x < 2 * a.G) l_gstart[threadIdx.x] = grp0;
+    for (uint32_t i = threadIdx.x + kBlock; i < 2 * a.G; i += kBlock) l_gstart[i] = tl.perm_grp[i];
 #pragma unroll
-  for (int u = 0; u < NL; ++u) {
-    const uint32_t i = threadIdx.x + u * kBlock;
-    if (i < n_vec) {
-      *reinterpret_cast<Vec<T, V> *>(tile + i * V) = v[u];
-      if constexpr (HAS_STATUS) *reinterpret_cast<Vec<int32_t, V> *>(stile + i * V) = sv[u];
+    for (int u = 0; u < NL; ++u) {
+      const uint32_t iv = threadIdx.x + u * kBlock;
+      if (iv < n_vec) {
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+          tile[pos[u][e]] = v[u].v[e];
+          if constexpr (HAS_STATUS) stile[pos[u][e]] = sv[u].v[e];
+        }
+      }
+    }
+    for (uint32_t c = n_vec * V + threadIdx.x; c < n_in; c += kBlock) {  // < V leftover cells
+      const uint32_t r = small_div(c, tl.by_row);
+      const uint32_t at = tl.perm_cell[c - r * tl.row_elems] + r * tl.pitch_cells;
+      tile[at] = src[c];
+      if constexpr (HAS_STATUS) stile[at] = ssrc[c];
+    }
+  } else {
+    if constexpr (!ALL) {
+      for (uint32_t i = threadIdx.x; i <= a.G; i += kBlock) l_gstart[i] = a.gstart[i];
+      if constexpr (MODE == 0)
+        for (uint32_t i = threadIdx.x; i < a.K; i += kBlock) l_order[i] = a.order[i];
+    }
+#pragma unroll
+    for (int u = 0; u < NL; ++u) {
+      const uint32_t i = threadIdx.x + u * kBlock;
+      if (i < n_vec) {
+        *reinterpret_cast<Vec<T, V> *>(tile + i * V) = v[u];
+        if constexpr (HAS_STATUS) *reinterpret_cast<Vec<int32_t, V> *>(stile + i * V) = sv[u];
+      }
+    }
+    for (uint32_t i = n_vec * V + threadIdx.x; i < n_in; i += kBlock) {  // < V leftover cells
+      tile[i] = src[i];
+      if constexpr (HAS_STATUS) stile[i] = ssrc[i];
     }
   }
-  for (uint32_t i = n_vec * V + threadIdx.x; i < n_in; i += kBlock) {  // < V leftover cells
-    tile[i] = src[i];
-    if constexpr (HAS_STATUS) stile[i] = ssrc[i];
-  }
   __syncthreads();
+  OLAP_PROBE(2);
 
   const uint32_t n_out = rows * tl.out_row;
+  // (starting the reducing lanes at a wavefront that differs from workgroup to workgroup — with fewer outputs than
+  // lanes only the first wavefront reduces — was measured and is slower: 69 -> 77 us on 4 rows x 10 runs of 100)
+  const uint32_t tid = threadIdx.x;
   T *dst = out + row0 * tl.out_row;
   int32_t *sdst = st_out ? st_out + row0 * tl.out_row : nullptr;
   if constexpr (ALL && FAST) {  // (FAST: sum / average over a 0 default without a mask)
@@ -361,7 +575,7 @@ __global__ __launch_bounds__(kBlock) void drillup_tile_kernel(const T *__restric
     // re-associated, like the reduce regime and under the same condition (groups of >= 256 members).
     if (tl.inner == 1 && a.K >= 256) {
       constexpr uint32_t L = 16;
-      for (uint32_t slot = threadIdx.x; slot < rows * L; slot += kBlock) {
+      for (uint32_t slot = tid; slot < rows * L; slot += kBlock) {
         const uint32_t r = slot / L, part = slot % L;
         const uint32_t kb = (uint32_t)((uint64_t)a.K * part / L), ke = (uint32_t)((uint64_t)a.K * (part + 1) / L);
         const T *cells = tile + r * tl.row_elems;
@@ -404,28 +618,44 @@ __global__ __launch_bounds__(kBlock) void drillup_tile_kernel(const T *__restric
       return;
     }
   }
-  for (uint32_t idx = threadIdx.x; idx < n_out; idx += kBlock) {
+  for (uint32_t idx = tid; idx < n_out; idx += kBlock) {
     const uint32_t r = idx / tl.out_row;
     const uint32_t rem = idx - r * tl.out_row;
     const uint32_t g = rem / tl.inner;
     const uint32_t i = rem - g * tl.inner;
-    const uint32_t base = r * tl.row_elems + i;
+    const uint32_t base = (PERMUTE ? r * tl.pitch_cells : r * tl.row_elems) + i;
     Lane<T, METHOD, HAS_STATUS, 1, FAST> lane;
     lane.init();
-    uint32_t j = ALL ? 0u : l_gstart[g];
-    const uint32_t jend = ALL ? (uint32_t)a.K : l_gstart[g + 1];
-    constexpr int UJ = MODE == 0 ? 8 : 4;  // independent LDS reads in flight (interleaved groups: member index, then cell — two dependent reads)
-    Vec<T, 1> x[UJ];
-    Vec<int32_t, 1> sx[UJ];
-    for (; j + UJ <= jend; j += UJ) {
+    uint32_t j = ALL ? 0u : PERMUTE ? l_gstart[2 * g] : l_gstart[g];
+    const uint32_t jend = ALL ? (uint32_t)a.K : PERMUTE ? l_gstart[2 * g + 1] : l_gstart[g + 1];
+    constexpr int UJ = (MODE == 0 || MODE == 3) ? 8 : 4;  // independent LDS reads in flight (MODE 0: member index, then cell — two dependent reads; MODE 3: long runs, few lanes)
+    Vec<T, 1> x[UJ], y[UJ];
+    Vec<int32_t, 1> sx[UJ], sy[UJ];
+    auto fetch = [&](uint32_t jj, Vec<T, 1> *xx, Vec<int32_t, 1> *ss) {
       uint32_t kk[UJ];
 #pragma unroll
-      for (int u = 0; u < UJ; ++u) kk[u] = MODE == 0 ? l_order[j + u] : (j + u);
+      for (int u = 0; u < UJ; ++u) kk[u] = MODE == 0 ? l_order[jj + u] : (jj + u);
 #pragma unroll
       for (int u = 0; u < UJ; ++u) {
         const uint32_t k = kk[u];
-        x[u].v[0] = tile[base + k * tl.inner];
-        sx[u].v[0] = HAS_STATUS ? stile[base + k * tl.inner] : OLAP_STATUS_SET;
+        xx[u].v[0] = tile[base + k * tl.inner];
+        ss[u].v[0] = HAS_STATUS ? stile[base + k * tl.inner] : OLAP_STATUS_SET;
+      }
+    };
+    // software pipeline: the next UJ members are requested before the current ones are folded in (a lane walks its
+    // members one after the other — the reference's order — so its float64 adds are one dependent chain; the LDS
+    // round trips must not sit in that chain as well)
+    if (j + UJ <= jend) {
+      fetch(j, x, sx);
+      for (j += UJ; j + UJ <= jend; j += UJ) {
+        fetch(j, y, sy);
+#pragma unroll
+        for (int u = 0; u < UJ; ++u) lane.add_row(x[u], sx[u], def_nan);
+#pragma unroll
+        for (int u = 0; u < UJ; ++u) {
+          x[u] = y[u];
+          sx[u] = sy[u];
+        }
       }
 #pragma unroll
       for (int u = 0; u < UJ; ++u) lane.add_row(x[u], sx[u], def_nan);
@@ -437,6 +667,7 @@ __global__ __launch_bounds__(kBlock) void drillup_tile_kernel(const T *__restric
       lane.add_row(x[0], sx[0], def_nan);
     }
     lane.template finish_and_store<false>(def_nan, dst, sdst, idx);
+    if (idx == 0) g_probe3(blockIdx.x);
   }
 }
 
@@ -449,11 +680,11 @@ constexpr uint32_t kGroupTileMaxGroups = 1024;  // groups per tile of the group-
 // cells, table `gtile`), staged with 16 B loads from the aligned address below its first cell; the
 // reduction and the store are those of the row-tile kernel.
 template <typename T, int METHOD, bool HAS_STATUS, bool FAST>
-__global__ __launch_bounds__(kBlock) void drillup_gtile_kernel(const T *__restrict__ in,
-                                                               const int32_t *__restrict__ st_in,
-                                                               T *__restrict__ out,
-                                                               int32_t *__restrict__ st_out,
-                                                               const DrillUpAxis a, const uint64_t n_cells) {
+__global__ __launch_bounds__(kBlock) void drillup_gtile_kernel(const Batch<T> b, const DrillUpAxis a, const uint64_t n_cells) {
+  const T *__restrict__ in = b.in[blockIdx.y];
+  const int32_t *__restrict__ st_in = b.st_in[blockIdx.y];
+  T *__restrict__ out = b.out[blockIdx.y];
+  int32_t *__restrict__ st_out = b.st_out[blockIdx.y];
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   constexpr int V = 16 / sizeof(T);
   constexpr uint32_t kCells = kTileBytes / sizeof(T);
@@ -1577,32 +1808,6 @@ struct DiceRows {
   int def_nan;
 };
 
-struct SmallDiv {
-  uint32_t d, magic;
-  int how;  // 0: mul-hi by magic; 1: x < 2 d, one compare; 2: d == 1
-};
-__device__ __forceinline__ uint32_t small_div(uint32_t x, const SmallDiv &s) {
-  return s.how == 0 ? __umulhi(x, s.magic) : s.how == 1 ? (x >= s.d ? 1u : 0u) : x;
-}
-// exact for every x <= x_max, or false (m = floor(2^32 / d) + 1 is exact while x d < 2^32)
-inline bool small_div_for(uint64_t d, uint64_t x_max, SmallDiv *out) {
-  if (d == 0 || d > 0xFFFFFFFFull || x_max > 0xFFFFFFFFull) return false;
-  out->d = (uint32_t)d;
-  out->magic = 0;
-  if (d == 1) {
-    out->how = 2;
-    return x_max <= 0xFFFFFFFFull;
-  }
-  if (x_max < 2 * d) {
-    out->how = 1;
-    return true;
-  }
-  if (x_max * d >= (1ull << 32)) return false;
-  out->how = 0;
-  out->magic = (uint32_t)((1ull << 32) / d + 1);
-  return true;
-}
-
 struct DiceDirect {
   DiceRows p;
   SmallDiv by_inner, by_k;
@@ -2468,6 +2673,9 @@ template <typename T>
 struct Launch {
   static hipError_t drillup_axis(int method, bool has_status, int vec, const T *in, const int32_t *st_in, T *out,
                                  int32_t *st_out, const DrillUpAxis &a, hipStream_t stream);
+  // the same roll-up over nb (<= kMaxBatch) buffer pairs in one launch; all with or all without a mask
+  static hipError_t drillup_axis_batch(int method, bool has_status, int vec, const Batch<T> &b, unsigned nb, const DrillUpAxis &a,
+                                       hipStream_t stream);
   static hipError_t drillup_reduce(int method, bool has_status, const T *in, const int32_t *st_in, T *out, int32_t *st_out,
                                    const DrillUpAxis &a, const DrillUpReduce &rd, hipStream_t stream);
   static hipError_t drillup_generic(int method, bool has_status, const T *in, const int32_t *st_in, T *out,
@@ -2526,8 +2734,7 @@ inline unsigned grid_stride_for(uint64_t n) {
 // reasonably (>= 128 slots); otherwise the flat regime.  FAST = additive method, zero default, no
 // mask read.  The grid of the row regime is outer*G*blocks_per_row workgroups.
 template <typename T, int METHOD, bool HS, int VEC>
-static hipError_t drillup_axis_launch(const T *in, const int32_t *st_in, T *out, int32_t *st_out,
-                                      const DrillUpAxis &a, hipStream_t stream) {
+static hipError_t drillup_axis_launch(const Batch<T> &b, unsigned nb, const DrillUpAxis &a, hipStream_t stream) {
   constexpr bool kAdditive = (METHOD == OLAP_SUM || METHOD == OLAP_AVERAGE || METHOD == OLAP_PARTIAL_AVERAGE);
   const bool fast = kAdditive && !HS && !a.def_nan;
   const bool contig = a.order == nullptr;
@@ -2559,32 +2766,39 @@ static hipError_t drillup_axis_launch(const T *in, const int32_t *st_in, T *out,
     // of every cache line): whole rows of K*inner cells staged per workgroup, kTileBytes of cells
     const uint64_t row_elems = a.K * a.inner;
     const uint64_t budget = kTileBytes / sizeof(T);
-    const uint64_t csr_bytes = (a.G + 1 + (contig ? 0 : a.K)) * 4;
-    // rows per tile: as many as fit; every tile must start 16 B aligned, i.e. R*row_elems % V == 0
-    uint64_t R = row_elems ? budget / row_elems : 0;
     constexpr uint64_t V = 16 / sizeof(T);
-    if (R >= 4) R &= ~3ull;
-    while (R > 0 && (R * row_elems) % V != 0) --R;
+    static const bool no_permute = getenv("OLAP_TILE_NO_PERMUTE") != nullptr;
+    // interleaved groups: cells permuted into group order while they are staged (MODE 3, tables from the plan)
+    const bool permute = !contig && a.perm_cell && !no_permute;
+    const uint64_t csr_bytes = permute ? 2 * a.G * 4 : (a.G + 1 + (contig ? 0 : a.K)) * 4;
+    // rows per tile: as many as fit; every tile must start 16 B aligned, i.e. R*row_elems % V == 0
+    const uint64_t R = tile_rows_for(row_elems, permute ? (uint64_t)a.perm_pitch * a.inner : row_elems, budget, V);
     uint64_t tile_max_inner = 128;  // tools/sweep3.py: the LDS form wins up to ~100 cells per row piece
     if (const char *e = getenv("OLAP_TILE_MAX_INNER")) tile_max_inner = (uint64_t)atoll(e);
     if (a.aligned16 && a.inner < tile_max_inner && R > 0 && csr_bytes <= 16 * 1024 && a.G * a.inner <= 0xFFFFFFFFull) {
-      DrillUpTile tl;
+      DrillUpTile tl{};
       tl.rows_per_tile = (uint32_t)R;
       tl.row_elems = (uint32_t)row_elems;
       tl.out_row = (uint32_t)(a.G * a.inner);
       tl.inner = (uint32_t)a.inner;
+      if (permute) {
+        tl.perm_cell = a.perm_cell;
+        tl.perm_grp = a.perm_grp;
+        tl.pitch_cells = (uint32_t)(a.perm_pitch * a.inner);
+        if (!small_div_for(row_elems, budget, &tl.by_row)) return hipErrorInvalidValue;  // (row_elems <= 4096: always exact)
+      }
       const uint64_t tiles = (a.outer + tl.rows_per_tile - 1) / tl.rows_per_tile;
       const bool all = contig && a.G == 1;
       const size_t lds = kTileBytes + (HS ? budget * 4 : 0) + (all ? 0 : csr_bytes);
       if (tiles < 0x7FFFFFFFull) {
-#define OLAP_TILE(F, M) hipLaunchKernelGGL((drillup_tile_kernel<T, METHOD, HS, F, M>), (unsigned)tiles, kBlock, lds, stream, in, st_in, out, st_out, a, tl)
+#define OLAP_TILE(F, M) hipLaunchKernelGGL((drillup_tile_kernel<T, METHOD, HS, F, M>), dim3((unsigned)tiles, nb), kBlock, lds, stream, b, a, tl)
         if constexpr (kAdditive && !HS) {
           if (fast) {
-            if (all) OLAP_TILE(true, 1); else if (contig) OLAP_TILE(true, 2); else OLAP_TILE(true, 0);
+            if (all) OLAP_TILE(true, 1); else if (contig) OLAP_TILE(true, 2); else if (permute) OLAP_TILE(true, 3); else OLAP_TILE(true, 0);
             return hipGetLastError();
           }
         }
-        if (all) OLAP_TILE(false, 1); else if (contig) OLAP_TILE(false, 2); else OLAP_TILE(false, 0);
+        if (all) OLAP_TILE(false, 1); else if (contig) OLAP_TILE(false, 2); else if (permute) OLAP_TILE(false, 3); else OLAP_TILE(false, 0);
 #undef OLAP_TILE
         return hipGetLastError();
       }
@@ -2594,7 +2808,7 @@ static hipError_t drillup_axis_launch(const T *in, const int32_t *st_in, T *out,
     const size_t lds = kTileBytes + (HS ? kTileBytes / sizeof(T) * 4 : 0) + (kGroupTileMaxGroups + 1) * 4;
     const unsigned blocks = (unsigned)(a.outer * a.n_gtile);
     const uint64_t n_cells = a.outer * a.K * a.inner;
-#define OLAP_GTILE(F) hipLaunchKernelGGL((drillup_gtile_kernel<T, METHOD, HS, F>), blocks, kBlock, lds, stream, in, st_in, out, st_out, a, n_cells)
+#define OLAP_GTILE(F) hipLaunchKernelGGL((drillup_gtile_kernel<T, METHOD, HS, F>), dim3(blocks, nb), kBlock, lds, stream, b, a, n_cells)
     if constexpr (kAdditive && !HS) {
       if (fast) { OLAP_GTILE(true); return hipGetLastError(); }
     }
@@ -2602,12 +2816,12 @@ static hipError_t drillup_axis_launch(const T *in, const int32_t *st_in, T *out,
 #undef OLAP_GTILE
     return hipGetLastError();
   }
-#define OLAP_ROWS(C, F) hipLaunchKernelGGL((drillup_rows_kernel<T, METHOD, HS, VEC, U, C, F>), (unsigned)row_blocks, row_lanes, 0, stream, in, st_in, out, st_out, ar)
-#define OLAP_ROWS1(C, F) hipLaunchKernelGGL((drillup_rows_kernel<T, METHOD, HS, VEC, 1, C, F>), (unsigned)row_blocks, row_lanes, 0, stream, in, st_in, out, st_out, ar)
+#define OLAP_ROWS(C, F) hipLaunchKernelGGL((drillup_rows_kernel<T, METHOD, HS, VEC, U, C, F>), dim3((unsigned)row_blocks, nb), row_lanes, 0, stream, b, ar)
+#define OLAP_ROWS1(C, F) hipLaunchKernelGGL((drillup_rows_kernel<T, METHOD, HS, VEC, 1, C, F>), dim3((unsigned)row_blocks, nb), row_lanes, 0, stream, b, ar)
 #define OLAP_FLAT(F)                                                                                                                              \
   do {                                                                                                                                             \
-    if (a.total < 0xFFFFFF00ull) hipLaunchKernelGGL((drillup_flat_kernel<T, METHOD, HS, VEC, F, uint32_t>), grid_for(a.total), kBlock, 0, stream, in, st_in, out, st_out, a); \
-    else hipLaunchKernelGGL((drillup_flat_kernel<T, METHOD, HS, VEC, F, uint64_t>), grid_for(a.total), kBlock, 0, stream, in, st_in, out, st_out, a);                        \
+    if (a.total < 0xFFFFFF00ull) hipLaunchKernelGGL((drillup_flat_kernel<T, METHOD, HS, VEC, F, uint32_t>), dim3(grid_for(a.total), nb), kBlock, 0, stream, b, a); \
+    else hipLaunchKernelGGL((drillup_flat_kernel<T, METHOD, HS, VEC, F, uint64_t>), dim3(grid_for(a.total), nb), kBlock, 0, stream, b, a);                        \
   } while (0)
   DrillUpAxis ar = a;  // the row regime's own workgroup width
   ar.blocks_per_row = (a.n_vec + row_lanes - 1) / row_lanes;
@@ -2629,7 +2843,7 @@ static hipError_t drillup_axis_launch(const T *in, const int32_t *st_in, T *out,
       rg.blocks_per_row = (rg.n_vec + lanes - 1) / lanes;
       const uint64_t blocks = a.outer * a.G * rg.blocks_per_row;
       if (blocks < 0x7FFFFFFFull) {
-#define OLAP_RAGGED(C, F) hipLaunchKernelGGL((drillup_rows_kernel<T, METHOD, HS, RV, U, C, F, true, true>), (unsigned)blocks, lanes, 0, stream, in, st_in, out, st_out, rg)
+#define OLAP_RAGGED(C, F) hipLaunchKernelGGL((drillup_rows_kernel<T, METHOD, HS, RV, U, C, F, true, true>), dim3((unsigned)blocks, nb), lanes, 0, stream, b, rg)
         if constexpr (kAdditive && !HS) {
           if (fast) {
             if (contig) OLAP_RAGGED(true, true); else OLAP_RAGGED(false, true);
@@ -2674,34 +2888,38 @@ static hipError_t drillup_axis_launch(const T *in, const int32_t *st_in, T *out,
 }
 
 template <typename T, int METHOD, bool HS>
-static hipError_t drillup_axis_vec(int vec, const T *in, const int32_t *st_in, T *out, int32_t *st_out,
-                                   const DrillUpAxis &a, hipStream_t stream) {
-  if (vec == 4) return drillup_axis_launch<T, METHOD, HS, 4>(in, st_in, out, st_out, a, stream);
-  if (vec == 2) return drillup_axis_launch<T, METHOD, HS, 2>(in, st_in, out, st_out, a, stream);
-  return drillup_axis_launch<T, METHOD, HS, 1>(in, st_in, out, st_out, a, stream);
+static hipError_t drillup_axis_vec(int vec, const Batch<T> &b, unsigned nb, const DrillUpAxis &a, hipStream_t stream) {
+  if (vec == 4) return drillup_axis_launch<T, METHOD, HS, 4>(b, nb, a, stream);
+  if (vec == 2) return drillup_axis_launch<T, METHOD, HS, 2>(b, nb, a, stream);
+  return drillup_axis_launch<T, METHOD, HS, 1>(b, nb, a, stream);
 }
 
 template <typename T, bool HS>
-static hipError_t drillup_axis_method(int method, int vec, const T *in, const int32_t *st_in, T *out, int32_t *st_out,
-                                      const DrillUpAxis &a, hipStream_t stream) {
+static hipError_t drillup_axis_method(int method, int vec, const Batch<T> &b, unsigned nb, const DrillUpAxis &a, hipStream_t stream) {
   switch (method) {
-    case OLAP_SUM: return drillup_axis_vec<T, OLAP_SUM, HS>(vec, in, st_in, out, st_out, a, stream);
-    case OLAP_AVERAGE: return drillup_axis_vec<T, OLAP_AVERAGE, HS>(vec, in, st_in, out, st_out, a, stream);
-    case OLAP_HIGHEST: return drillup_axis_vec<T, OLAP_HIGHEST, HS>(vec, in, st_in, out, st_out, a, stream);
-    case OLAP_LOWEST: return drillup_axis_vec<T, OLAP_LOWEST, HS>(vec, in, st_in, out, st_out, a, stream);
-    case OLAP_FIRST: return drillup_axis_vec<T, OLAP_FIRST, HS>(vec, in, st_in, out, st_out, a, stream);
-    case OLAP_LAST: return drillup_axis_vec<T, OLAP_LAST, HS>(vec, in, st_in, out, st_out, a, stream);
-    case OLAP_PARTIAL_AVERAGE: return drillup_axis_vec<T, OLAP_PARTIAL_AVERAGE, HS>(vec, in, st_in, out, st_out, a, stream);
-    default: return drillup_axis_vec<T, OLAP_PRODUCT, HS>(vec, in, st_in, out, st_out, a, stream);
+    case OLAP_SUM: return drillup_axis_vec<T, OLAP_SUM, HS>(vec, b, nb, a, stream);
+    case OLAP_AVERAGE: return drillup_axis_vec<T, OLAP_AVERAGE, HS>(vec, b, nb, a, stream);
+    case OLAP_HIGHEST: return drillup_axis_vec<T, OLAP_HIGHEST, HS>(vec, b, nb, a, stream);
+    case OLAP_LOWEST: return drillup_axis_vec<T, OLAP_LOWEST, HS>(vec, b, nb, a, stream);
+    case OLAP_FIRST: return drillup_axis_vec<T, OLAP_FIRST, HS>(vec, b, nb, a, stream);
+    case OLAP_LAST: return drillup_axis_vec<T, OLAP_LAST, HS>(vec, b, nb, a, stream);
+    case OLAP_PARTIAL_AVERAGE: return drillup_axis_vec<T, OLAP_PARTIAL_AVERAGE, HS>(vec, b, nb, a, stream);
+    default: return drillup_axis_vec<T, OLAP_PRODUCT, HS>(vec, b, nb, a, stream);
   }
 }
 
 template <typename T>
 hipError_t Launch<T>::drillup_axis(int method, bool has_status, int vec, const T *in, const int32_t *st_in, T *out,
                                    int32_t *st_out, const DrillUpAxis &a, hipStream_t stream) {
-  if (a.total == 0) return hipSuccess;
-  return has_status ? drillup_axis_method<T, true>(method, vec, in, st_in, out, st_out, a, stream)
-                    : drillup_axis_method<T, false>(method, vec, in, st_in, out, st_out, a, stream);
+  return drillup_axis_batch(method, has_status, vec, Batch<T>::one(in, st_in, out, st_out), 1, a, stream);
+}
+
+template <typename T>
+hipError_t Launch<T>::drillup_axis_batch(int method, bool has_status, int vec, const Batch<T> &b, unsigned nb, const DrillUpAxis &a,
+                                         hipStream_t stream) {
+  if (a.total == 0 || nb == 0) return hipSuccess;
+  return has_status ? drillup_axis_method<T, true>(method, vec, b, nb, a, stream)
+                    : drillup_axis_method<T, false>(method, vec, b, nb, a, stream);
 }
 
 template <typename T, int METHOD>

@@ -151,6 +151,19 @@ class Plan:
         check(capi.lib().olap_plan_run(self._h, in_values or None, in_status or None, out_values or None,
                                        out_status or None, stream or None))
 
+    def run_batch(self, in_values, in_status, out_values, out_status, stream=None):
+        """The same plan over several buffer pairs in one call (one launch where the plan allows it): lists of device
+        addresses; in_status / out_status may be None (no masks) or lists with 0 / None entries."""
+        n = len(in_values)
+
+        def ptrs(xs):
+            if xs is None:
+                return None
+            return (C.c_void_p * n)(*[x or None for x in xs])
+
+        check(capi.lib().olap_plan_run_batch(self._h, n, ptrs(in_values), ptrs(in_status), ptrs(out_values), ptrs(out_status),
+                                             stream or None))
+
     def status(self):
         check(capi.lib().olap_plan_status(self._h))
 
@@ -326,6 +339,19 @@ class HipStore:
         check(self._lib.olap_store_drillup(self._h, C.byref(h), len(ol), ol.ctypes.data_as(capi._pu32),
                                            nl.ctypes.data_as(capi._pu32), arr, _method_code(method)))
         return HipStore(0, _handle=h)
+
+    @staticmethod
+    def drill_up_batch(stores, old_len, new_len, maps, method="sum"):
+        """drillUp of several measures of a cube by the same maps and rule: one launch when they share cell type,
+        default and size (olap_store_drillup_batch); returns the new stores in order."""
+        ol, nl = _u32(old_len), _u32(new_len)
+        keep, arr = _tables(maps, np.uint32, C.c_uint32)
+        n = len(stores)
+        hs = (C.c_void_p * n)(*[s._h for s in stores])
+        outs = (C.c_void_p * n)()
+        check(capi.lib().olap_store_drillup_batch(n, hs, outs, len(ol), ol.ctypes.data_as(capi._pu32), nl.ctypes.data_as(capi._pu32), arr,
+                                                  _method_code(method)))
+        return [HipStore(0, _handle=C.c_void_p(outs[i])) for i in range(n)]
 
     def drill_down(self, old_len, new_len, maps, method="sum", distributions=None):
         ol, nl = _u32(old_len), _u32(new_len)

@@ -449,7 +449,24 @@ class Cube {
       return this;
     }
     const newDimensions = this._withDimension(index, rolled);
-    return this._derive(newDimensions, (store, id) => store.drillUp(this.dimensions, newDimensions, this.storedMeasuresRules[id][dimensionId]));
+    // The reference rolls its measures up one store call at a time (src/cube.js:1012-1020); measures that share the
+    // rule for this dimension go to the device together (HipStore.drillUpMany: one launch per cell type).
+    const byRule = new Map();
+    for (const id of this.storedMeasureIds) {
+      const rule = this.storedMeasuresRules[id][dimensionId];
+      if (!byRule.has(rule)) byRule.set(rule, []);
+      byRule.get(rule).push(id);
+    }
+    const rolledUp = {};
+    for (const [rule, ids] of byRule) {
+      const Store = this.storedMeasures[ids[0]].constructor;
+      if (ids.length < 2 || typeof Store.drillUpMany !== 'function') continue;
+      const results = Store.drillUpMany(ids.map((id) => this.storedMeasures[id]), this.dimensions, newDimensions, rule);
+      ids.forEach((id, i) => {
+        rolledUp[id] = results[i];
+      });
+    }
+    return this._derive(newDimensions, (store, id) => rolledUp[id] || store.drillUp(this.dimensions, newDimensions, this.storedMeasuresRules[id][dimensionId]));
   }
 
   drillDown(dimensionId, attribute) {

@@ -287,6 +287,40 @@ class HipStore {
     return this._wrap(onShards(this._native, 'drillUp', [lengthsOf(oldDimensions), lengthsOf(newDimensions), maps, code]));
   }
 
+  /**
+   * drillUp of several measures of one cube by the same rule — what Cube.drillUp asks of every stored measure in turn
+   * (src/cube.js:1012-1020).  Measures held whole on one device with the same cell type and default go to the device
+   * as ONE launch (addon drillUpBatch -> olap_store_drillup_batch); the others (pending selections, sharded or
+   * order-tracking measures, a lone measure) take drillUp one by one.  Returns the new stores in the order given.
+   */
+  static drillUpMany(stores, oldDimensions, newDimensions, method = 'sum') {
+    const out = new Array(stores.length);
+    const batches = new Map();
+    stores.forEach((store, i) => {
+      const native = store._pending ? null : store._nativeStore;
+      if (!native || native.isSharded || native.orderTracked) return;
+      const key = `${store._type}/${Number.isNaN(store._defaultValue) ? 'nan' : '0'}`;
+      if (!batches.has(key)) batches.set(key, []);
+      batches.get(key).push(i);
+    });
+    let code, maps;
+    for (const members of batches.values()) {
+      if (members.length < 2) continue;
+      if (maps === undefined) {
+        code = backend.load().methodFromName(method); // throws 'Unsupported aggregation method: <m>'
+        maps = newDimensions.map((dim, i) => Uint32Array.from(oldDimensions[i].getGroupIndexFromRootIndexMap(dim.rootAttribute)));
+      }
+      const natives = backend.load().drillUpBatch(members.map((i) => stores[i]._nativeStore), lengthsOf(oldDimensions), lengthsOf(newDimensions), maps, code);
+      members.forEach((i, j) => {
+        out[i] = stores[i]._wrap(natives[j]);
+      });
+    }
+    stores.forEach((store, i) => {
+      if (!out[i]) out[i] = store.drillUp(oldDimensions, newDimensions, method);
+    });
+    return out;
+  }
+
   /** in-memory.js:336-430 — any method other than 'sum' copies the parent value (:421-423) */
   drillDown(oldDimensions, newDimensions, method = 'sum', distributions = null) {
     const maps = oldDimensions.map((dim, i) => Uint32Array.from(newDimensions[i].getGroupIndexFromRootIndexMap(dim.rootAttribute)));

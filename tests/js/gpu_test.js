@@ -712,4 +712,36 @@ describe('insertion order (measures with a first / last rule keep the reference 
   });
 });
 
+describe('measures that share a rule are rolled up in one launch (HipStore.drillUpMany)', () => {
+  it('equals the per-measure roll-ups: mixed cell types, defaults and rules, a lazily diced measure', () => {
+    const items = (name, n) => Array.from({ length: n }, (_, i) => `${name}${i}`);
+    const a = new GenericDimension('da', 'item', items('a', 7));
+    a.addAttribute('item', 'pair', Object.fromEntries(items('a', 7).map((it, i) => [it, `p${i % 3}`])));
+    const dims = [a, new GenericDimension('db', 'item', items('b', 6)), new GenericDimension('dc', 'item', items('c', 5))];
+    const cube = new Cube(dims);
+    const specs = [['s1', 'sum', 'float32', 0], ['s2', 'sum', 'float32', 0], ['s3', 'sum', 'float32', 0], ['av', 'average', 'float32', 0],
+      ['i1', 'sum', 'int32', 0], ['i2', 'sum', 'int32', 0], ['n1', 'sum', 'float32', NaN_], ['n2', 'sum', 'float32', NaN_], ['u1', 'highest', 'uint32', NaN_], ['u2', 'highest', 'uint32', NaN_]];
+    let seed = 12345;
+    const rnd = () => ((seed = (seed * 1103515245 + 12345) % 2147483648) / 2147483648);
+    for (const [id, rule, type, def] of specs) {
+      cube.createStoredMeasure(id, { da: rule, db: rule, dc: rule }, type, def);
+      cube.setData(id, Array.from({ length: 210 }, () => (rnd() < 0.3 ? def : Math.floor(rnd() * 17) - (type === 'uint32' ? 0 : 8))));
+    }
+    for (const [dim, attr] of [['da', 'pair'], ['da', 'all'], ['db', 'all'], ['dc', 'all']]) {
+      const together = cube.drillUp(dim, attr);
+      for (const [id, rule] of specs) {
+        const index = cube.getDimensionIndex(dim);
+        const alone = cube.storedMeasures[id].drillUp(cube.dimensions, together.dimensions, rule);
+        assert.deepEqual(together.getData(id), alone.data, `${id} ${dim}->${attr}`);
+        assert.deepEqual(Array.from(together.getStatusMap(id).keys()), Array.from(alone._dataMap.keys()), `${id} ${dim}->${attr} keys`);
+        assert.equal(index >= 0, true);
+      }
+    }
+    // a slice keeps its selection pending: those measures take the fused single-store path, same values
+    const sliced = cube.dice('db', 'item', ['b1', 'b4']);
+    const viaBatch = sliced.drillUp('da', 'pair');
+    for (const [id] of specs) assert.deepEqual(viaBatch.getData(id), cube.drillUp('da', 'pair').dice('db', 'item', ['b1', 'b4']).getData(id), id);
+  });
+});
+
 run();

@@ -1,5 +1,6 @@
 """CPU-side checks of the C ABI: the library loads, exports every symbol include/olap_hip.h
 declares, and validates arguments before it touches a device (same errors with and without a GPU)."""
+import ctypes as C
 import os
 import re
 
@@ -68,6 +69,19 @@ def test_argument_errors_precede_device_use():
            "float32", 0.0, "sum", [1], [3], [[0, 0, 1]])
     expect(capi.ERR_INDEX_RANGE, "outside this store's dimension", pkg.Plan.load,
            "float32", 0.0, 0.0, [2], [2], [[0, 2]])
+
+
+def test_batch_entry_points_validate_before_the_device():
+    """olap_plan_run_batch / olap_store_drillup_batch (several measures of a cube in one call) refuse NULL lists and
+    NULL members before anything touches a device."""
+    L = capi.lib()
+    assert L.olap_plan_run_batch(None, 2, None, None, None, None, None) == capi.ERR_INVALID_ARGUMENT
+    assert "plan is NULL" in capi.last_error()
+    assert L.olap_store_drillup_batch(2, None, None, 0, None, None, None, 0) == capi.ERR_INVALID_ARGUMENT
+    hs, outs = (C.c_void_p * 2)(None, None), (C.c_void_p * 2)()
+    assert L.olap_store_drillup_batch(2, hs, outs, 0, None, None, None, 0) == capi.ERR_INVALID_ARGUMENT
+    assert "store 0 of the batch is NULL" in capi.last_error()
+    assert L.olap_store_drillup_batch(0, hs, outs, 0, None, None, None, 0) == 0  # an empty cube: nothing to do
 
 
 def test_no_cpu_fallback_without_device():

@@ -6,6 +6,7 @@ Where a golden input was inserted in a shuffled order (the reference's first/las
 insertion order, which a dense buffer cannot represent), the expectation is the oracle run on the
 same cells inserted ascending; this is stated per assertion below.
 """
+import ctypes as C
 import os
 
 import numpy as np
@@ -18,6 +19,7 @@ from oracle.oracle import OracleStore, to_typed
 pytestmark = pytest.mark.gpu
 
 pkg = load_package()
+capi = pkg.capi
 KAT = load_cases("store_kat.json")
 RND = load_cases("store_random.json")
 CFG = load_cases("configs.json")
@@ -901,6 +903,60 @@ def test_tile_regime_long_last_dimension(K, type_name, method):
     assert np.array_equal(out.get_status() == 2, ev != 0)
 
 
+@pytest.mark.parametrize("method", ["sum", "average", "last", "product"])
+@pytest.mark.parametrize("type_name,default", [("float32", 0.0), ("float32", float("nan")), ("float64", 0.0), ("uint32", float("nan")), ("int32", 0.0)])
+@pytest.mark.parametrize("outer,K,inner,groups", [
+    (1003, 1000, 1, "mod10"),      # 4 rows x 10 runs of 100 per tile (runs padded onto distinct banks), last tile partial
+    (1001, 1000, 1, "mod100"),     # 100 runs of 10: the padding costs a row of the tile (3 rows instead of 4)
+    (501, 100, 10, "mod10"),       # inner = 10: a member is ten cells
+    (77, 4096, 1, "random"),       # a row fills the whole tile (float32; two tiles' worth for float64 -> another regime)
+    (1999, 37, 3, "random"),       # odd everything: rows of 111 cells, ragged runs
+    (260, 613, 5, "ragged"),       # runs of very different lengths
+])
+def test_tile_regime_permuted_groups(outer, K, inner, groups, type_name, default, method):
+    """Interleaved groups in the row-tile regime (drillup_tile_kernel MODE 3): the cells of a row are permuted into
+    group order on their way into LDS, runs padded onto distinct banks when that fits.  Bit-exact against the oracle."""
+    rng = np.random.default_rng(K * 31 + inner)
+    if groups == "mod10":
+        amap = (np.arange(K) % 10).astype(np.uint32)
+    elif groups == "mod100":
+        amap = (np.arange(K) % 100).astype(np.uint32)
+    elif groups == "ragged":
+        raw = np.minimum(rng.geometric(0.15, size=K) - 1, 20)
+        first = {}
+        amap = np.array([first.setdefault(int(g), len(first)) for g in raw], dtype=np.uint32)
+    else:
+        raw = rng.integers(0, max(2, K // 7), size=K)
+        first = {}
+        amap = np.array([first.setdefault(int(g), len(first)) for g in raw], dtype=np.uint32)
+    lens = [outer, K, inner]
+    new = [outer, int(amap.max()) + 1, inner]
+    n = outer * K * inner
+    if method == "product":
+        vals = np.where(rng.random(n) < 0.5, 1.0, -1.0) if type_name != "uint32" else np.ones(n)
+        vals = vals * np.where(rng.random(n) < 4.0 / K, 2.0, 1.0)
+    else:
+        vals = rng.integers(0 if type_name == "uint32" else -8, 9, size=n).astype(np.float64)
+        if type_name.startswith("float"):
+            vals = vals * 0.5
+    dense = np.where(rng.random(n) < 0.3, default, vals)
+    maps = [np.arange(outer, dtype=np.uint32), amap, np.arange(inner, dtype=np.uint32)]
+    plan = pkg.Plan.drillup(type_name, default, method, lens, new, maps)
+    if K * inner * (8 if type_name == "float64" else 4) <= 16384:
+        assert plan.kernel_name == "drillup_tile_kernel", plan.kernel_name
+    o = OracleStore(n, type_name, default)
+    typed = to_typed(dense, type_name).astype(np.float64)
+    if type_name in ("int32", "uint32") and default != default:
+        typed = np.where(np.isnan(dense), np.nan, typed)
+    o.set_data(typed)
+    ev, es = expected_typed(o.drill_up(lens, new, maps, method))
+    g = pkg.HipStore(n, type_name, default)
+    g.set_data_f64(dense)
+    out = g.drill_up(lens, new, maps, method)
+    assert np.array_equal(out.get_status(), es), plan.kernel_name
+    assert same_typed(out.get_data(), ev), plan.kernel_name
+
+
 @pytest.mark.parametrize("lens,axis", [([7, 9, 513], 1), ([3, 30, 1001], 1), ([5, 4, 2049], 1), ([12, 3, 171], 0), ([2, 40, 515], 1),
                                        ([300, 7, 65], 1), ([3, 5, 7, 33], 1), ([1, 6, 1023], 1)])
 @pytest.mark.parametrize("type_name,default", [("float32", 0.0), ("float32", float("nan")), ("uint32", float("nan")), ("float64", 0.0), ("int32", 0.0)])
@@ -1143,3 +1199,80 @@ def test_drilldown_row_form(type_name, default, method):
         out = g.drill_down(old_len, new_len, maps, method)
         assert np.array_equal(out.get_status(), es)
         assert same_typed(out.get_data(), ev)
+
+
+@pytest.mark.parametrize("type_name,default", [("float32", 0.0), ("float32", float("nan")), ("uint32", float("nan")), ("float64", 0.0), ("int32", 0.0)])
+@pytest.mark.parametrize("lens,axis,kind,method", [
+    ([6, 40, 1100], 0, "all", "sum"),            # row regime, 16-byte lanes
+    ([9, 30, 1027], 1, "interleaved", "last"),   # row regime, ragged slots
+    ([40, 30, 200], 1, "contiguous", "average"),  # flat regime
+    ([300, 100, 3], 1, "interleaved", "sum"),     # row tile, permuted groups
+    ([300, 100, 3], 1, "all", "highest"),         # row tile, one group
+    ([3, 9000, 5], 1, "thirty", "sum"),           # group tiles
+    ([2, 5000, 2], 1, "all", "sum"),              # few outputs, long groups: the reduce regime runs pair by pair
+    ([5, 4, 3], 2, "all", "product"),
+])
+@pytest.mark.parametrize("n", [1, 3, 8, 11])
+def test_drillup_batch_matches_single(lens, axis, kind, method, type_name, default, n):
+    """olap_store_drillup_batch / olap_plan_run_batch: n measures in one call (one launch per 8 where the plan allows
+    it) give exactly the stores that n single calls give; the first is also checked against the oracle."""
+    rng = np.random.default_rng(sum(lens) * 7 + n)
+    K = lens[axis]
+    amap = {"all": np.zeros(K), "interleaved": np.arange(K) % 7, "contiguous": np.arange(K) // 4, "thirty": np.arange(K) // 30}[kind].astype(np.uint32)
+    new = list(lens)
+    new[axis] = int(amap.max()) + 1
+    maps = [amap if d == axis else np.arange(l, dtype=np.uint32) for d, l in enumerate(lens)]
+    cells = int(np.prod(lens))
+    stores, denses = [], []
+    for _ in range(n):
+        if method == "product":
+            vals = np.where(rng.random(cells) < 0.5, 1.0, 2.0)
+        else:
+            vals = rng.integers(0 if type_name == "uint32" else -8, 9, size=cells).astype(np.float64)
+        dense = np.where(rng.random(cells) < 0.3, default, vals)
+        g = pkg.HipStore(cells, type_name, default)
+        g.set_data_f64(dense)
+        stores.append(g)
+        denses.append(dense)
+    batch = pkg.HipStore.drill_up_batch(stores, lens, new, maps, method)
+    assert len(batch) == n
+    for g, b in zip(stores, batch):
+        single = g.drill_up(lens, new, maps, method)
+        assert np.array_equal(b.get_status(), single.get_status())
+        assert same_typed(b.get_data(), single.get_data())
+    o = OracleStore(cells, type_name, default)
+    typed = to_typed(denses[0], type_name).astype(np.float64)
+    if type_name in ("int32", "uint32") and default != default:
+        typed = np.where(np.isnan(denses[0]), np.nan, typed)
+    o.set_data(typed)
+    ev, es = expected_typed(o.drill_up(lens, new, maps, method))
+    if not (kind == "all" and K >= 256 and method in ("sum", "average", "product")):  # (re-associated regimes: checked above against the single call)
+        assert np.array_equal(batch[0].get_status(), es)
+        assert same_typed(batch[0].get_data(), ev)
+
+
+def test_drillup_batch_falls_back_and_validates():
+    """Stores that differ in cell type, or track their insertion order, are rolled up one by one behind the same call;
+    raw-pointer batches with masks on some pairs only run pair by pair; a NULL in the list is refused."""
+    lens, new = [4, 6, 5], [1, 6, 5]
+    maps = [np.zeros(4, np.uint32), np.arange(6, dtype=np.uint32), np.arange(5, dtype=np.uint32)]
+    rng = np.random.default_rng(5)
+    a, b, c = pkg.HipStore(120, "float32", 0.0), pkg.HipStore(120, "int32", 0.0), pkg.HipStore(120, "float32", 0.0)
+    for s in (a, b, c):
+        s.set_data_f64(rng.integers(-3, 4, size=120).astype(np.float64))
+    c.track_order(True)
+    c.set_value(7, 0.0)
+    c.set_value(7, 9.0)  # leaves the flat index order: the tracked path
+    outs = pkg.HipStore.drill_up_batch([a, b, c], lens, new, maps, "first")
+    for s, o in zip((a, b, c), outs):
+        single = s.drill_up(lens, new, maps, "first")
+        assert np.array_equal(o.get_data(), single.get_data()) and np.array_equal(o.get_status(), single.get_status())
+    assert pkg.HipStore.drill_up_batch([], lens, new, maps, "sum") == []
+    L = pkg.lib()
+    hs = (C.c_void_p * 2)(a._h, None)
+    outs2 = (C.c_void_p * 2)()
+    ol, nl = np.asarray(lens, np.uint32), np.asarray(new, np.uint32)
+    keep = [np.ascontiguousarray(m) for m in maps]
+    arr = (capi._pu32 * 3)(*[m.ctypes.data_as(capi._pu32) for m in keep])
+    rc = L.olap_store_drillup_batch(2, hs, outs2, 3, ol.ctypes.data_as(capi._pu32), nl.ctypes.data_as(capi._pu32), arr, 0)
+    assert rc != 0 and b"NULL" in L.olap_last_error() and outs2[0] is None

@@ -210,7 +210,7 @@ int main(int argc, char **argv) {
   vs.push_back({"read_sum<2> 8192 blocks", [&] { hipLaunchKernelGGL(read_sum_kernel<2>, 8192, 256, 0, 0, (const float4 *)in, N / 4, sink); }, N * 4.0, {}});
   vs.push_back({"copy 2048 blocks (r+w)", [&] { hipLaunchKernelGGL(copy_kernel, 2048, 256, 0, 0, (const float4 *)in, (float4 *)out, N / 4); }, N * 8.0, {}});
   vs.push_back({"colsum_f32<10> value-only", [&] { hipLaunchKernelGGL(colsum_f32_kernel<10>, rows_grid, 256, 0, 0, (const float4 *)in, (float4 *)out, inner / 4); }, N * 4.0 + inner * 4.0, {}});
-#define ROWS(U, FAST, NT, ST, NAME) vs.push_back({NAME, [&] { hipLaunchKernelGGL((drillup_rows_kernel<float, OLAP_SUM, false, 4, U, true, FAST, NT>), rows_grid, 256, 0, 0, in, nullptr, out, ST, a); }, (ST) ? alg : N * 4.0 + inner * 4.0, {}})
+#define ROWS(U, FAST, NT, ST, NAME) vs.push_back({NAME, [&] { hipLaunchKernelGGL((drillup_rows_kernel<float, OLAP_SUM, false, 4, U, true, FAST, NT>), rows_grid, 256, 0, 0, Batch<float>::one(in, nullptr, out, ST), a); }, (ST) ? alg : N * 4.0 + inner * 4.0, {}})
   ROWS(8, true, true, (int32_t *)nullptr, "rows U=8 nt values only");
   ROWS(4, true, true, (int32_t *)nullptr, "rows U=4 nt values only (product)");
   ROWS(2, true, true, (int32_t *)nullptr, "rows U=2 nt values only");
@@ -223,8 +223,8 @@ int main(int argc, char **argv) {
     a8.total = a8.n_vec;
     a8.blocks_per_row = (a8.n_vec + 255) / 256;
     const unsigned g8 = (unsigned)a8.blocks_per_row;
-    vs.push_back({"rows VEC=8 U=4 nt values only", [&, g8] { hipLaunchKernelGGL((drillup_rows_kernel<float, OLAP_SUM, false, 8, 4, true, true, true>), g8, 256, 0, 0, in, nullptr, out, (int32_t *)nullptr, a8); }, N * 4.0 + inner * 4.0, {}});
-    vs.push_back({"rows VEC=8 U=2 nt values only", [&, g8] { hipLaunchKernelGGL((drillup_rows_kernel<float, OLAP_SUM, false, 8, 2, true, true, true>), g8, 256, 0, 0, in, nullptr, out, (int32_t *)nullptr, a8); }, N * 4.0 + inner * 4.0, {}});
+    vs.push_back({"rows VEC=8 U=4 nt values only", [&, g8] { hipLaunchKernelGGL((drillup_rows_kernel<float, OLAP_SUM, false, 8, 4, true, true, true>), g8, 256, 0, 0, Batch<float>::one(in, nullptr, out, nullptr), a8); }, N * 4.0 + inner * 4.0, {}});
+    vs.push_back({"rows VEC=8 U=2 nt values only", [&, g8] { hipLaunchKernelGGL((drillup_rows_kernel<float, OLAP_SUM, false, 8, 2, true, true, true>), g8, 256, 0, 0, Batch<float>::one(in, nullptr, out, nullptr), a8); }, N * 4.0 + inner * 4.0, {}});
   }
 #define COLS(C, X, NAME) vs.push_back({NAME, [&] { hipLaunchKernelGGL((colrows_kernel<C, X>), (unsigned)((inner / 4 + 256 * C - 1) / (256 * C)), 256, 0, 0, in, out, inner, (int)K); }, N * 4.0 + inner * 4.0, {}})
   COLS(1, false, "colrows C=1");
@@ -245,11 +245,11 @@ int main(int argc, char **argv) {
   ROWS(1, false, true, (int32_t *)nullptr, "rows U=1 exact");
   ROWS(2, false, true, (int32_t *)nullptr, "rows U=2 exact");
   ROWS(4, false, true, (int32_t *)nullptr, "rows U=4 exact");
-#define ROWS_ST(U, NAME) vs.push_back({NAME, [&] { hipLaunchKernelGGL((drillup_rows_kernel<float, OLAP_SUM, true, 4, U, true, false, true>), rows_grid, 256, 0, 0, in, st_in, out, st_out, a); }, 2 * alg, {}})
+#define ROWS_ST(U, NAME) vs.push_back({NAME, [&] { hipLaunchKernelGGL((drillup_rows_kernel<float, OLAP_SUM, true, 4, U, true, false, true>), rows_grid, 256, 0, 0, Batch<float>::one(in, st_in, out, st_out), a); }, 2 * alg, {}})
   ROWS_ST(1, "rows U=1 mask in+out");
   ROWS_ST(2, "rows U=2 mask in+out");
   ROWS_ST(4, "rows U=4 mask in+out");
-#define ROWS_HI(U, NAME) vs.push_back({NAME, [&] { hipLaunchKernelGGL((drillup_rows_kernel<float, OLAP_HIGHEST, false, 4, U, true, false, true>), rows_grid, 256, 0, 0, in, nullptr, out, (int32_t *)nullptr, a); }, N * 4.0 + inner * 4.0, {}})
+#define ROWS_HI(U, NAME) vs.push_back({NAME, [&] { hipLaunchKernelGGL((drillup_rows_kernel<float, OLAP_HIGHEST, false, 4, U, true, false, true>), rows_grid, 256, 0, 0, Batch<float>::one(in, nullptr, out, nullptr), a); }, N * 4.0 + inner * 4.0, {}})
   ROWS_HI(1, "rows U=1 highest");
   ROWS_HI(4, "rows U=4 highest");
 
