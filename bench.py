@@ -541,6 +541,30 @@ def main():
                 except Exception as err:  # a capture problem must not cost the headline line
                     res["axis%d" % axis]["graph_error"] = str(err)[:200]
             extra["cache_resident_1e6"] = res
+            # several measures of a cube that share a rule: one launch for all (olap_plan_run_batch) against one
+            # launch per measure, on the 10^6-cell cube (launch-bound) — what Cube.drillUp does per stored measure
+            try:
+                nm = 4
+                new6 = [1] + lens6[1:]
+                maps6 = [np.zeros(10, np.uint32)] + [np.arange(10, dtype=np.uint32) for _ in range(5)]
+                o = pkg.Plan.drillup("float32", 0.0, "sum", lens6, new6, maps6)
+                ins = [engine.empty(10 ** 6, "float32") for _ in range(nm)]
+                for t in ins:
+                    capi.check(pkg.lib().olap_fill_seeded(t.data_ptr(), None, 10 ** 6, 0, 2, 20240807, 1.0, stream))
+                outs = [engine.empty(10 ** 5, "float32") for _ in range(nm)]
+                ip, op = [t.data_ptr() for t in ins], [t.data_ptr() for t in outs]
+
+                def one_by_one():
+                    for i in range(nm):
+                        o.run(ip[i], None, op[i], None, stream)
+
+                us1 = _time(torch, one_by_one, iters=200, warm=20)
+                usb = _time(torch, lambda: o.run_batch(ip, None, op, None, stream), iters=200, warm=20)
+                extra["batched_measures_1e6"] = {"measures": nm, "one_launch_each_us": round(us1, 3), "one_launch_for_all_us": round(usb, 3),
+                                                 "cell_measures_per_s": nm * 1e6 / (usb * 1e-6), "kernel": o.kernel_name}
+                del ins, outs
+            except Exception as err:  # must not cost the headline line
+                extra["batched_measures_1e6"] = {"error": str(err)[:200]}
             extra["config3_chain"] = bench_config3(pkg, engine, values, torch)
             extra["config5_time_rollup"] = bench_config5(pkg, engine, torch)
             del values, partial

@@ -35,5 +35,23 @@ for shape, perm in CASES:
     b.record()
     torch.cuda.synchronize()
     us = a.elapsed_time(b) / 10 * 1e3
-    print("%-20s perm %-10s %8.1f us  %.3f  %s" % (shape, perm, us, 2 * n * 4 / (us * 1e-6) / 8e12, plan.kernel_name), flush=True)
+    phases = ""
+    if hasattr(L, "olap_diag_xy_probe") and "xy" in plan.kernel_name:
+        # a library built with -DOLAP_XY_PROBE (OLAP_LIBOLAPGPU=...): mean time from a workgroup's start to its tables
+        # being ready, its tile being in LDS and its last store being issued, and the workgroups resident per CU
+        import ctypes as C
+
+        plan.run(*args)
+        torch.cuda.synchronize()
+        nb = 1 << 17
+        buf = (C.c_ulonglong * (nb * 8))()
+        L.olap_diag_xy_probe.restype, L.olap_diag_xy_probe.argtypes = C.c_int, [C.c_void_p, C.c_ulonglong]
+        assert L.olap_diag_xy_probe(buf, nb * 8) == 0
+        q = np.frombuffer(buf, dtype=np.uint64).reshape(nb, 8).astype(np.int64)
+        q = q[q[:, 3] > q[:, 0]]
+        span = (q[:, 3].max() - q[:, 0].min()) * 0.01
+        phases = "  tables %.2f us, tile in LDS %.2f us, stores issued %.2f us, resident/CU %.1f (first %d workgroups)" % (
+            (q[:, 1] - q[:, 0]).mean() * 0.01, (q[:, 2] - q[:, 0]).mean() * 0.01, (q[:, 3] - q[:, 0]).mean() * 0.01,
+            (q[:, 3] - q[:, 0]).sum() * 0.01 / span / 256, len(q))
+    print("%-20s perm %-10s %8.1f us  %.3f  %s%s" % (shape, perm, us, 2 * n * 4 / (us * 1e-6) / 8e12, plan.kernel_name, phases), flush=True)
     del vals, out
