@@ -982,27 +982,21 @@ extern "C" int olap_reorder_plan(olap_plan **out, int dtype, int default_kind, i
       // measured (tools/pmc_probe.py): long runs matter more on the write side
       t.ty = t.ly >= 96 ? 128 : 64;
       t.tx = 64;
-      if (const char *e = getenv("OLAP_XY_TILE")) {  // developer knob: "64x64" | "64x128" | "128x128" | "64x256" | "128x256"
+      if (const char *e = getenv("OLAP_XY_TILE")) {  // developer knob: "64x64" | "128x64" | "64x128"
         int a = 0, b2 = 0;
-        if (sscanf(e, "%dx%d", &a, &b2) == 2 && ((a == 64 && (b2 == 64 || b2 == 128 || b2 == 256)) || (a == 128 && (b2 == 128 || b2 == 256)))) {
+        if (sscanf(e, "%dx%d", &a, &b2) == 2 && (a == 64 || a == 128) && (b2 == 64 || b2 == 128)) {
           t.tx = a;
           t.ty = b2;
         }
       }
-      t.phases = 2;  // (tools/transpose_probe.py: what bounds the kernel is the number of tiles a CU keeps in flight)
-      if (const char *e = getenv("OLAP_XY_PHASES")) {
-        const int h = atoi(e);
-        if (h == 1 || h == 2) t.phases = h;
-      }
-      // workgroups that run at the same time cover 4 x 4 blocks of tiles (pieces of the same rows on both sides):
-      // [3652,27400] 231 -> 201 us, neutral elsewhere; 16 x 16 and more lose to the padding of the grid (tools/xy_order.sh)
-      t.super = 4;
+      // walking tiles in 2 x 2 .. 8 x 8 blocks was measured twice and bought nothing beyond the run-to-run spread
+      // (profiles/transpose_order_r02.txt); 16 x 16 and more lose to the padding of the grid
+      t.super = 1;
       if (const char *e = getenv("OLAP_XY_SUPER")) t.super = std::max(1, atoi(e));
       t.y_first = 0;
       if (const char *e = getenv("OLAP_XY_ORDER")) t.y_first = e[0] == 'y';
       t.tiles_x = (t.lx + t.tx - 1) / t.tx;
       t.tiles_y = (t.ly + t.ty - 1) / t.ty;
-      if (t.tiles_x < (uint64_t)t.super || t.tiles_y < (uint64_t)t.super) t.super = 1;  // (the grid is padded to whole blocks)
       t.vec_in = in4 && t.lx % 4 == 0;
       t.vec_out = out4 && t.ly % 4 == 0;
       const bool is_float = dtype == OLAP_FLOAT32;

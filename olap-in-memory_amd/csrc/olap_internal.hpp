@@ -88,7 +88,6 @@ struct TransposeXY {
   int tx, ty;                                // tile extents (cells)
   int super;                                 // tiles are walked in super x super blocks
   int y_first;                               // tile order: Y fastest (write locality) instead of X fastest (read locality)
-  int phases;                                // the tile leaves through LDS in 1, 2 or 4 parts (a part's worth of LDS per workgroup)
   int vec_in, vec_out;                       // every tile row starts 16-byte aligned on that side
   int default_test;                          // how a generated mask tells the default: 0 int/0, 1 float/0, 2 float/NaN, 3 never
 };

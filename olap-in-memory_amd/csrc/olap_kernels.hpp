@@ -299,22 +299,40 @@ __global__ __launch_bounds__(kBlock) void drillup_flat_kernel(const Batch<T> b, 
   Lane<T, METHOD, HAS_STATUS, VEC, FAST> lane;
   lane.init();
   constexpr int U = 4;
-  for (; j < jend; j += U) {
-    const uint32_t n = (jend - j) < (uint32_t)U ? (jend - j) : (uint32_t)U;
+  // software pipeline: a batch of U members (their list entries, then their row pieces: two dependent loads) is
+  // requested while the previous batch is folded in — lanes of a wavefront walk different groups, so nothing else
+  // overlaps one lane's load latency with its own arithmetic
+  auto fetch = [&](uint32_t j0, Vec<T, VEC> *v, Vec<int32_t, VEC> *s) {
+    const uint32_t n = (jend - j0) < (uint32_t)U ? (jend - j0) : (uint32_t)U;
     uint64_t k[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const uint32_t jj = (uint32_t)u < n ? j + u : j;  // clamp: re-reads a valid row, result unused
+      const uint32_t jj = (uint32_t)u < n ? j0 + u : j0;  // clamp: re-reads a valid row, result unused
       k[u] = a.order ? (uint64_t)a.order[jj] : (uint64_t)jj;
     }
-    Vec<T, VEC> v[U];
-    Vec<int32_t, VEC> s[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       // (cached loads: with short row pieces neighbouring outputs share lines — streaming loads
       // took [3001,3333,10] from 89 to 159 us)
       v[u] = load_vec<T, VEC>(base + k[u] * a.inner);
       if constexpr (HAS_STATUS) s[u] = load_vec<int32_t, VEC>(sbase + k[u] * a.inner);
+    }
+    return n;
+  };
+  if (j < jend) {
+    Vec<T, VEC> v[U], w[U];
+    Vec<int32_t, VEC> s[U], ws[U];
+    uint32_t n = fetch(j, v, s);
+    for (j += U; j < jend; j += U) {
+      const uint32_t nn = fetch(j, w, ws);
+#pragma unroll
+      for (int u = 0; u < U; ++u) lane.add_row(v[u], s[u], def_nan);  // (only a group's last batch is partial)
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        v[u] = w[u];
+        s[u] = ws[u];
+      }
+      n = nn;
     }
 #pragma unroll
     for (int u = 0; u < U; ++u)

@@ -18,10 +18,17 @@
 //   * 16-byte global accesses (lane = 4 adjacent cells) are conflict-free when a 32-lane group covers
 //     8 quads x 4 lines (4q + j + line distinct), on the way in and on the way out alike;
 //   * 4-byte global accesses (lane = one cell, 64 adjacent cells per wave) are conflict-free as they are.
-// Both sides move 16 bytes per lane: at 16-byte-aligned addresses when every row of every tile starts aligned on
-// that side, at cell-aligned addresses otherwise (cubes with odd extents).
+// The 16-byte form of each side is used when every row of every tile starts 16-byte aligned on that
+// side; otherwise that side moves 4 bytes per lane (cubes with odd extents).
 //
 // HBM-bound: 4 B read + 4 B written per cell.
+//
+// Measured and dropped in round 2 (profiles/transpose_phases_r02.txt, transpose_tiles_r02.txt, transpose_order_r02.txt):
+// a variant that kept the tile in registers and passed it through LDS in halves or quarters (8 instead of ~3
+// workgroups resident per CU) — every phase of a workgroup's life took twice as long and the kernel the same time,
+// i.e. the memory system, not latency or residency, bounds this access pattern; 128 x 128, 64 x 256 and 128 x 256
+// tiles with 512 / 1024 lanes (512-byte reads, 1 KB writes: within +-5 %); 16-byte accesses at cell-aligned addresses
+// instead of the 4-byte lanes on odd extents (free in the streaming kernels, 25 % SLOWER here: 245 against 195 us).
 #include <hip/hip_runtime.h>
 
 #include "olap_device.hpp"
@@ -29,8 +36,8 @@
 
 using namespace olap;
 
-// tools/transpose_probe.py --phases builds this file with OLAP_XY_PROBE: lane 0 of every workgroup records the 100 MHz
-// wall clock at its phase boundaries (not compiled into the product)
+// tools/transpose_probe.py prints per-phase times when the library is built with OLAP_XY_PROBE: lane 0 of every
+// workgroup records the 100 MHz wall clock at its phase boundaries (not compiled into the product)
 #ifdef OLAP_XY_PROBE
 __device__ unsigned long long g_xy_probe[1 << 20];
 #define XY_PROBE(i)                                                                                  \
@@ -46,21 +53,11 @@ extern "C" int olap_diag_xy_probe(unsigned long long *host, unsigned long long n
 
 namespace {
 
-// AIN / AOUT: every row of every tile starts 16-byte aligned on that side (aligned 16-byte accesses); otherwise the
-// same 16-byte accesses go to cell-aligned addresses (cubes with odd extents: gfx950 takes a dwordx4 at any 4-byte
-// boundary, free on the load side and ~7 % on the store side, tools/unaligned_probe.hip) and only a quad that runs over
-// the tile's ragged edge moves cell by cell.
-// H: the tile leaves in H phases of TX / H source columns each, through an LDS buffer of that size.  The tile's cells
-// wait in REGISTERS (32 per lane) from the moment their loads are issued; LDS is only the transposing step.  A
-// workgroup lives ~10 us (tools/transpose_probe.py with an OLAP_XY_PROBE build: 4-9 us until its rows have arrived,
-// 3-5 us issuing its stores), so what bounds the kernel is how many tiles a CU keeps in flight: a whole 64 x 128 tile
-// in LDS (33 KB) allows 4 workgroups per CU, half of it 8 — twice the loads in flight.
-template <int TX, int TY, bool AIN, bool AOUT, int H, int NT>
-__global__ __launch_bounds__(NT) void transpose_xy_kernel(const uint32_t *__restrict__ in, uint32_t *__restrict__ out,
+template <int TX, int TY, bool VIN, bool VOUT>
+__global__ __launch_bounds__(kBlock) void transpose_xy_kernel(const uint32_t *__restrict__ in, uint32_t *__restrict__ out,
                                                               int32_t *__restrict__ st_out, const TransposeXY t) {
   constexpr int P = TY + 1;
-  constexpr int TXH = TX / H;
-  extern __shared__ __attribute__((aligned(16))) uint32_t tile[];  // TXH * P cells
+  extern __shared__ __attribute__((aligned(16))) uint32_t tile[];  // TX * P cells
   __shared__ uint64_t out_x[TX];  // destination offset of tile column x (relative to the tile's base)
   __shared__ uint64_t in_y[TY];   // source offset of tile row y
 
@@ -129,44 +126,65 @@ __global__ __launch_bounds__(NT) void transpose_xy_kernel(const uint32_t *__rest
       }
     out_x[i] = off;
   };
-  for (uint32_t i = threadIdx.x; i < (uint32_t)TY; i += NT) decode_row(i);
+  for (uint32_t i = threadIdx.x; i < (uint32_t)TY; i += kBlock) decode_row(i);
   __syncthreads();
   XY_PROBE(1);
 
-  // ---- in: rows along X, the whole tile into registers.  A 32-lane group = 8 quads x 4 rows; the workgroup's
-  // groups tile QX quad-blocks x RY row-blocks
   const uint32_t *src = in + base_in;
-  constexpr int G32 = NT / 32;         // 32-lane groups of the workgroup
-  constexpr int QX = TX / 32;          // 32-cell blocks across a row
-  constexpr int RY = G32 / QX;         // row blocks per pass
-  constexpr int ROWS = RY * 4;         // rows per pass
-  constexpr int PASSES = TY / ROWS;    // 16-byte loads per lane (8 for 64 x 128)
-  const uint32_t g = threadIdx.x >> 5, l = threadIdx.x & 31;
-  const uint32_t q = (g % QX) * 8 + (l & 7);          // quad index in the row
-  const uint32_t r0 = (g / QX) * 4 + (l >> 3);        // row within the pass
-  const bool whole_in = 4 * q + 3 < nx;               // (a quad that runs over the ragged edge goes cell by cell)
-  Vec<uint32_t, 4> v[PASSES];
+  // ---- in: rows along X
+  if constexpr (VIN) {
+    // a 32-lane group = 8 quads x 4 rows; the workgroup's 8 groups tile QX quad-blocks x RY row-blocks
+    constexpr int QX = TX / 32;          // 32-cell blocks across a row
+    constexpr int RY = 8 / QX;           // row blocks per pass
+    constexpr int ROWS = RY * 4;         // rows per pass
+    const uint32_t g = threadIdx.x >> 5, l = threadIdx.x & 31;
+    const uint32_t q = (g % QX) * 8 + (l & 7);          // quad index in the row
+    const uint32_t r0 = (g / QX) * 4 + (l >> 3);        // row within the pass
+    constexpr int PASSES = TY / ROWS;
+    constexpr int UB = PASSES < 8 ? PASSES : 8;
+    for (int p0 = 0; p0 < PASSES; p0 += UB) {
+      Vec<uint32_t, 4> v[UB];
 #pragma unroll
-  for (int u = 0; u < PASSES; ++u) {
-    const uint32_t y = u * ROWS + r0;
-    if (y < ny && whole_in) {
-      const uint32_t *p = src + in_y[y] + 4 * q;
-      v[u] = AIN ? load_stream<uint32_t, 4>(p) : load_stream_cell_aligned<uint32_t, 4>(p);
+      for (int u = 0; u < UB; ++u) {
+        const uint32_t y = (p0 + u) * ROWS + r0;
+        if (y < ny && 4 * q < nx) v[u] = load_stream<uint32_t, 4>(src + in_y[y] + 4 * q);
+      }
+      if (p0 == 0)
+        for (uint32_t i = threadIdx.x; i < (uint32_t)TX; i += kBlock) decode_col(i);
+#pragma unroll
+      for (int u = 0; u < UB; ++u) {
+        const uint32_t y = (p0 + u) * ROWS + r0;
+        if (y < ny && 4 * q < nx) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) tile[(4 * q + j) * P + y] = v[u].v[j];
+        }
+      }
     }
-  }
-  if (!whole_in && 4 * q < nx) {
+  } else {
+    constexpr int ROWS = kBlock / TX > 0 ? kBlock / TX : 1;  // rows per pass (TX <= 256)
+    const uint32_t x = threadIdx.x % TX, r0 = threadIdx.x / TX;
+    constexpr int PASSES = TY / ROWS;
+    constexpr int UB = 8;
+    for (int p0 = 0; p0 < PASSES; p0 += UB) {
+      uint32_t v[UB];
 #pragma unroll
-    for (int u = 0; u < PASSES; ++u) {
-      const uint32_t y = u * ROWS + r0;
-      if (y < ny) {
+      for (int u = 0; u < UB; ++u) {
+        const uint32_t y = (p0 + u) * ROWS + r0;
+        if (p0 + u < PASSES && y < ny && x < nx) v[u] = __builtin_nontemporal_load(src + in_y[y] + x);
+      }
+      if (p0 == 0)
+        for (uint32_t i = threadIdx.x; i < (uint32_t)TX; i += kBlock) decode_col(i);
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-          if (4 * q + j < nx) v[u].v[j] = __builtin_nontemporal_load(src + in_y[y] + 4 * q + j);
+      for (int u = 0; u < UB; ++u) {
+        const uint32_t y = (p0 + u) * ROWS + r0;
+        if (p0 + u < PASSES && y < ny && x < nx) tile[x * P + y] = v[u];
       }
     }
   }
-  for (uint32_t i = threadIdx.x; i < (uint32_t)TX; i += NT) decode_col(i);
+  __syncthreads();
+  XY_PROBE(2);
 
+  // ---- out: rows along Y
   uint32_t *dst = out + base_out;
   int32_t *sdst = st_out ? st_out + base_out : nullptr;
   auto status_of = [&](uint32_t bits) -> int32_t {
@@ -179,101 +197,82 @@ __global__ __launch_bounds__(NT) void transpose_xy_kernel(const uint32_t *__rest
     }
     return is_default ? 0 : OLAP_STATUS_SET;
   };
-  constexpr int QY = TY / 32;
-  constexpr int RX = G32 / QY;
-  constexpr int ROWS_O = RX * 4;
-  constexpr int PASSES_O = TXH / ROWS_O;
-  static_assert(TXH % ROWS_O == 0 && TXH % 4 == 0, "a phase is whole passes of whole quads");
-  const uint32_t qo = (g % QY) * 8 + (l & 7);
-  const uint32_t ro = (g / QY) * 4 + (l >> 3);
-  const bool whole_out = 4 * qo + 3 < ny;
+  if constexpr (VOUT) {
+    constexpr int QY = TY / 32;
+    constexpr int RX = 8 / QY;
+    constexpr int ROWS = RX * 4;
+    const uint32_t g = threadIdx.x >> 5, l = threadIdx.x & 31;
+    const uint32_t q = (g % QY) * 8 + (l & 7);
+    const uint32_t r0 = (g / QY) * 4 + (l >> 3);
+    constexpr int PASSES = TX / ROWS;
+    for (int p = 0; p < PASSES; ++p) {
+      const uint32_t x = p * ROWS + r0;
+      if (x < nx && 4 * q < ny) {
+        Vec<uint32_t, 4> v;
 #pragma unroll
-  for (int h = 0; h < H; ++h) {
-    if (h > 0) __syncthreads();  // the previous phase has left LDS
-    // LDS: cell (x, y) at (x - h TXH) * P + y; P = 1 (mod 32) makes the bank (x + y) mod 32: a 32-lane group's 8 quads
-    // x 4 rows are conflict-free on the way in, its 8 quads x 4 columns on the way out
-    if ((4 * q) / TXH == (uint32_t)h && 4 * q < nx) {
+        for (int j = 0; j < 4; ++j) v.v[j] = tile[x * P + 4 * q + j];
+        store_stream<uint32_t, 4>(dst + out_x[x] + 4 * q, v);
+        if (sdst) {
+          Vec<int32_t, 4> s;
 #pragma unroll
-      for (int u = 0; u < PASSES; ++u) {
-        const uint32_t y = u * ROWS + r0;
-        if (y < ny) {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) tile[(4 * q + j - h * TXH) * P + y] = v[u].v[j];
+          for (int j = 0; j < 4; ++j) s.v[j] = status_of(v.v[j]);
+          store_stream<int32_t, 4>(sdst + out_x[x] + 4 * q, s);
         }
       }
     }
-    __syncthreads();
-    if (h == 0) XY_PROBE(2);
-    // ---- out: rows along Y
-#pragma unroll
-    for (int p = 0; p < PASSES_O; ++p) {
-      const uint32_t xl = p * ROWS_O + ro, x = h * TXH + xl;
-      if (x < nx && 4 * qo < ny) {
-        Vec<uint32_t, 4> w;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) w.v[j] = tile[xl * P + 4 * qo + j];
-        uint32_t *d = dst + out_x[x] + 4 * qo;
-        if (whole_out) {
-          if constexpr (AOUT) store_stream<uint32_t, 4>(d, w);
-          else store_stream_cell_aligned<uint32_t, 4>(d, w);
-        } else {
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-            if (4 * qo + j < ny) __builtin_nontemporal_store(w.v[j], d + j);
-        }
-        if (sdst) {
-          Vec<int32_t, 4> sw;
-#pragma unroll
-          for (int j = 0; j < 4; ++j) sw.v[j] = status_of(w.v[j]);
-          int32_t *sd = sdst + out_x[x] + 4 * qo;
-          if (whole_out) {
-            if constexpr (AOUT) store_stream<int32_t, 4>(sd, sw);
-            else store_stream_cell_aligned<int32_t, 4>(sd, sw);
-          } else {
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-              if (4 * qo + j < ny) __builtin_nontemporal_store(sw.v[j], sd + j);
-          }
-        }
+  } else {
+    constexpr int ROWS = kBlock / TY > 0 ? kBlock / TY : 1;
+    const uint32_t y = threadIdx.x % TY, r0 = threadIdx.x / TY;
+    constexpr int PASSES = TX / ROWS;
+    for (int p = 0; p < PASSES; ++p) {
+      const uint32_t x = p * ROWS + r0;
+      if (x < nx && y < ny) {
+        const uint32_t v = tile[x * P + y];
+        __builtin_nontemporal_store(v, dst + out_x[x] + y);
+        if (sdst) __builtin_nontemporal_store(status_of(v), sdst + out_x[x] + y);
       }
     }
   }
   XY_PROBE(3);
 }
 
-template <int TX, int TY, bool AIN, bool AOUT, int H, int NT>
+template <int TX, int TY, bool VIN, bool VOUT>
 hipError_t launch_one(const TransposeXY &t, const uint32_t *in, uint32_t *out, int32_t *st_out, unsigned grid, hipStream_t stream) {
-  constexpr size_t lds = (size_t)(TX / H) * (TY + 1) * sizeof(uint32_t);
-  hipLaunchKernelGGL((transpose_xy_kernel<TX, TY, AIN, AOUT, H, NT>), grid, NT, lds, stream, in, out, st_out, t);
+  constexpr size_t lds = (size_t)TX * (TY + 1) * sizeof(uint32_t);
+  if (lds > 48 * 1024) {
+    static PerDeviceFlag raised;  // (per instantiation, per device)
+    if (!raised.test_and_set()) {
+      hipError_t e = hipFuncSetAttribute((const void *)transpose_xy_kernel<TX, TY, VIN, VOUT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return e;
+    }
+  }
+  hipLaunchKernelGGL((transpose_xy_kernel<TX, TY, VIN, VOUT>), grid, kBlock, lds, stream, in, out, st_out, t);
   return hipGetLastError();
 }
 
-template <int TX, int TY, int H, int NT>
-hipError_t launch_tile(const TransposeXY &t, const uint32_t *in, uint32_t *out, int32_t *st_out, bool ain, bool aout, hipStream_t stream) {
+template <int TX, int TY>
+hipError_t launch_tile(const TransposeXY &t, const uint32_t *in, uint32_t *out, int32_t *st_out, bool vin, bool vout, hipStream_t stream) {
   const uint64_t kSuper = (uint64_t)t.super;
   const uint64_t sx = (t.tiles_x + kSuper - 1) / kSuper, sy = (t.tiles_y + kSuper - 1) / kSuper;
   const uint64_t tiles = sx * sy * kSuper * kSuper * t.batch;
   if (t.tiles_x * t.tiles_y * t.batch == 0) return hipSuccess;
   if (tiles > 0x7FFFFFFFull) return hipErrorInvalidValue;
   const unsigned grid = (unsigned)tiles;
-  if (ain && aout) return launch_one<TX, TY, true, true, H, NT>(t, in, out, st_out, grid, stream);
-  if (ain) return launch_one<TX, TY, true, false, H, NT>(t, in, out, st_out, grid, stream);
-  if (aout) return launch_one<TX, TY, false, true, H, NT>(t, in, out, st_out, grid, stream);
-  return launch_one<TX, TY, false, false, H, NT>(t, in, out, st_out, grid, stream);
+  if (vin && vout) return launch_one<TX, TY, true, true>(t, in, out, st_out, grid, stream);
+  if (vin) return launch_one<TX, TY, true, false>(t, in, out, st_out, grid, stream);
+  if (vout) return launch_one<TX, TY, false, true>(t, in, out, st_out, grid, stream);
+  return launch_one<TX, TY, false, false>(t, in, out, st_out, grid, stream);
 }
 
 }  // namespace
 
-// Tile shapes: 64 x 64 and 64 x 128 with 256 lanes (the whole tile or half of it in LDS at a time); 128 x 128 and
-// 64 x 256 with 512 lanes, 128 x 256 with 1024 — longer runs per row, a quarter or an eighth of the tile in LDS at a time
 hipError_t launch_transpose_xy(const TransposeXY &t, const void *in, void *out, int32_t *st_out, bool aligned16, hipStream_t stream) {
-  const bool ain = t.vec_in && aligned16, aout = t.vec_out && aligned16;
+  const bool vin = t.vec_in && aligned16, vout = t.vec_out && aligned16;
   const uint32_t *src = (const uint32_t *)in;
   uint32_t *dst = (uint32_t *)out;
-  if (t.tx == 64 && t.ty == 64) return t.phases == 1 ? launch_tile<64, 64, 1, 256>(t, src, dst, st_out, ain, aout, stream) : launch_tile<64, 64, 2, 256>(t, src, dst, st_out, ain, aout, stream);
-  if (t.tx == 64 && t.ty == 128) return t.phases == 1 ? launch_tile<64, 128, 1, 256>(t, src, dst, st_out, ain, aout, stream) : launch_tile<64, 128, 2, 256>(t, src, dst, st_out, ain, aout, stream);
-  if (t.tx == 128 && t.ty == 128) return launch_tile<128, 128, 4, 512>(t, src, dst, st_out, ain, aout, stream);
-  if (t.tx == 64 && t.ty == 256) return launch_tile<64, 256, 4, 512>(t, src, dst, st_out, ain, aout, stream);
-  if (t.tx == 128 && t.ty == 256) return launch_tile<128, 256, 8, 1024>(t, src, dst, st_out, ain, aout, stream);
+  if (t.tx == 64 && t.ty == 64) return launch_tile<64, 64>(t, src, dst, st_out, vin, vout, stream);
+  if (t.tx == 128 && t.ty == 64) return launch_tile<128, 64>(t, src, dst, st_out, vin, vout, stream);
+  if (t.tx == 64 && t.ty == 128) return launch_tile<64, 128>(t, src, dst, st_out, vin, vout, stream);
+  if (t.tx == 128 && t.ty == 128) return launch_tile<128, 128>(t, src, dst, st_out, vin, vout, stream);
   return hipErrorInvalidValue;
 }

@@ -28,4 +28,7 @@ timeout -k 10 200 python tools/big.py 2>&1 | grep -v amdgpu.ids > "$O/big.txt" &
 timeout -k 10 200 node tools/js_bench.js > "$O/js_bench.txt" 2>&1 && tail -5 "$O/js_bench.txt"
 timeout -k 10 200 node tools/js_reference_benchmark.js > "$O/js_reference_benchmark.txt" 2>&1 && tail -3 "$O/js_reference_benchmark.txt"
 timeout -k 10 200 node tools/js_chain.js > "$O/js_chain.txt" 2>&1 && tail -3 "$O/js_chain.txt"
+timeout -k 10 200 python tools/transpose_probe.py 2>&1 | grep -v amdgpu.ids > "$O/transpose_probe.txt" && tail -3 "$O/transpose_probe.txt"
+if [ ! -x tools/tile_probe.bin ]; then hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -DOLAP_TILE_PROBE -I include -I olap-in-memory_amd/csrc tools/tile_probe.hip -o tools/tile_probe.bin; fi
+timeout -k 10 120 ./tools/tile_probe.bin > "$O/tile_probe.txt" 2>&1 && tail -4 "$O/tile_probe.txt"
 echo evidence done
