@@ -995,6 +995,7 @@ extern "C" int olap_reorder_plan(olap_plan **out, int dtype, int default_kind, i
       if (const char *e = getenv("OLAP_XY_SUPER")) t.super = std::max(1, atoi(e));
       t.y_first = 0;
       if (const char *e = getenv("OLAP_XY_ORDER")) t.y_first = e[0] == 'y';
+      t.cached_stores = getenv("OLAP_XY_CACHED_STORES") != nullptr;
       t.tiles_x = (t.lx + t.tx - 1) / t.tx;
       t.tiles_y = (t.ly + t.ty - 1) / t.ty;
       t.vec_in = in4 && t.lx % 4 == 0;

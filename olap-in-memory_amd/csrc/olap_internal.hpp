@@ -88,6 +88,7 @@ struct TransposeXY {
   int tx, ty;                                // tile extents (cells)
   int super;                                 // tiles are walked in super x super blocks
   int y_first;                               // tile order: Y fastest (write locality) instead of X fastest (read locality)
+  int cached_stores;                         // OLAP_XY_CACHED_STORES=1: plain instead of streaming stores (L2 may merge neighbouring tiles' pieces)
   int vec_in, vec_out;                       // every tile row starts 16-byte aligned on that side
   int default_test;                          // how a generated mask tells the default: 0 int/0, 1 float/0, 2 float/NaN, 3 never
 };

@@ -692,6 +692,9 @@ __global__ __launch_bounds__(kBlock) void drillup_tile_kernel(const Batch<T> b, 
 constexpr uint32_t kTotalBlocks = 4096;  // workgroups (and partial slots) of the store total
 constexpr uint32_t kGroupTileMaxGroups = 1024;  // groups per tile of the group-tile regime (LDS holds their bounds)
 
+// (Measured and dropped: the tile's bounds as ONE scalar load instead of two dependent ones, and the row-tile kernel's
+// software-pipelined reduction loop — 62.4 -> 64 us on [900,3652,30] day -> month; skipping the gstart loads of a
+// '-> all' roll-up in the row regime changed nothing.)
 // Group-tile regime: contiguous groups (calendars) whose rows K*inner do not fit LDS — e.g. day ->
 // month on [100, 3652, 30].  The members of consecutive groups are consecutive memory, so a tile is a
 // run of whole GROUPS of one outer row (the plan cuts the group list into tiles of <= kTileBytes of

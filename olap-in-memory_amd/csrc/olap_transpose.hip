@@ -211,7 +211,8 @@ __global__ __launch_bounds__(kBlock) void transpose_xy_kernel(const uint32_t *__
         Vec<uint32_t, 4> v;
 #pragma unroll
         for (int j = 0; j < 4; ++j) v.v[j] = tile[x * P + 4 * q + j];
-        store_stream<uint32_t, 4>(dst + out_x[x] + 4 * q, v);
+        if (t.cached_stores) store_vec<uint32_t, 4>(dst + out_x[x] + 4 * q, v);
+        else store_stream<uint32_t, 4>(dst + out_x[x] + 4 * q, v);
         if (sdst) {
           Vec<int32_t, 4> s;
 #pragma unroll
@@ -228,7 +229,8 @@ __global__ __launch_bounds__(kBlock) void transpose_xy_kernel(const uint32_t *__
       const uint32_t x = p * ROWS + r0;
       if (x < nx && y < ny) {
         const uint32_t v = tile[x * P + y];
-        __builtin_nontemporal_store(v, dst + out_x[x] + y);
+        if (t.cached_stores) dst[out_x[x] + y] = v;
+        else __builtin_nontemporal_store(v, dst + out_x[x] + y);
         if (sdst) __builtin_nontemporal_store(status_of(v), sdst + out_x[x] + y);
       }
     }
