@@ -989,15 +989,17 @@ extern "C" int olap_reorder_plan(olap_plan **out, int dtype, int default_kind, i
           t.ty = b2;
         }
       }
-      // walking tiles in 2 x 2 .. 8 x 8 blocks was measured twice and bought nothing beyond the run-to-run spread
-      // (profiles/transpose_order_r02.txt); 16 x 16 and more lose to the padding of the grid
-      t.super = 1;
+      // workgroups that run at the same time cover 4 x 4 blocks of tiles, Y-fastest — pieces of the same rows on both
+      // sides: 5-16 % on every 2-D shape of tools/xy_order.sh ([3652,27400] 211 -> 179 us), profiles/transpose_order_r02.txt;
+      // 16 x 16 and more lose to the padding of the grid.  (Streaming or cached stores: no difference.)
+      t.super = 4;
       if (const char *e = getenv("OLAP_XY_SUPER")) t.super = std::max(1, atoi(e));
-      t.y_first = 0;
+      t.y_first = 1;
       if (const char *e = getenv("OLAP_XY_ORDER")) t.y_first = e[0] == 'y';
       t.cached_stores = getenv("OLAP_XY_CACHED_STORES") != nullptr;
       t.tiles_x = (t.lx + t.tx - 1) / t.tx;
       t.tiles_y = (t.ly + t.ty - 1) / t.ty;
+      if (t.tiles_x < (uint64_t)t.super || t.tiles_y < (uint64_t)t.super) t.super = 1;  // (the grid is padded to whole blocks)
       t.vec_in = in4 && t.lx % 4 == 0;
       t.vec_out = out4 && t.ly % 4 == 0;
       const bool is_float = dtype == OLAP_FLOAT32;
