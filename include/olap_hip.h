@@ -213,6 +213,12 @@ int olap_memcpy_to_device(void *device, const void *host, uint64_t bytes);
  * lane (the achievable read ceiling of the box, measured in the same run as the kernels
  * it is compared with).  `scratch` needs 4 * 2048 bytes.  Asynchronous on `stream`. */
 int olap_diag_read_ceiling(const void *device, uint64_t bytes, void *scratch, void *stream);
+/* Diagnostic, host-only (no device): where the cells of one row of the view [outer, K, inner] go in the LDS tile of the
+ * row-tile drillUp regime when groups interleave (DESIGN.md K1', MODE 3) — cell_pos[K * inner] (LDS cell of every cell
+ * of a row), group_bounds[2 G] (first and one-past-last member position of every group's run) and *pitch (members
+ * between two rows of the tile).  `map` is a drillUp map as in olap_drillup_plan.  For tests of the planning code. */
+int olap_diag_tile_placement(int dtype, uint32_t K, uint32_t G, uint32_t inner, const uint32_t *map, uint32_t *cell_pos,
+                             uint32_t *group_bounds, uint32_t *pitch);
 /* `total` getter (in-memory.js:22-28): float64 sum of the set cells, and their count.
  * Synchronises `stream`. */
 int olap_total(const void *values, const int32_t *status, uint64_t n, int dtype, int default_kind,

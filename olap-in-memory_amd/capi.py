@@ -61,6 +61,7 @@ SIGNATURES = {
     "olap_plan_out_cells": (_u64, [_vp]),
     "olap_plan_kernel_name": (C.c_char_p, [_vp]),
     "olap_plan_run": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp]),
+    "olap_diag_tile_placement": (_i32, [_i32, C.c_uint32, C.c_uint32, C.c_uint32, _pu32, _pu32, _pu32, _pu32]),
     "olap_plan_run_batch": (_i32, [_vp, _i32, _pvp, _pvp, _pvp, _pvp, _vp]),
     "olap_plan_status": (_i32, [_vp]),
     "olap_plan_destroy": (None, [_vp]),

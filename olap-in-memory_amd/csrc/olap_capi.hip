@@ -1780,6 +1780,30 @@ __global__ __launch_bounds__(kBlock) void diag_read_kernel(const float *__restri
   if (acc == 123456.789f) scratch[blockIdx.x & 2047] = acc;  // keeps the loads alive without a store per lane
 }
 
+extern "C" int olap_diag_tile_placement(int dtype, uint32_t K, uint32_t G, uint32_t inner, const uint32_t *map, uint32_t *cell_pos,
+                                        uint32_t *group_bounds, uint32_t *pitch) {
+  int rc;
+  if ((rc = check_dtype(dtype))) return rc;
+  if (!map || !cell_pos || !group_bounds || !pitch || K == 0 || G == 0 || inner == 0)
+    return fail(OLAP_ERR_INVALID_ARGUMENT, "tile placement: NULL argument or empty extent");
+  const uint64_t budget = kTileBytes / olap_dtype_size(dtype);
+  if ((uint64_t)K * inner > budget) return fail(OLAP_ERR_INVALID_ARGUMENT, "tile placement: a row of %llu cells does not fit a tile of %llu", (unsigned long long)K * inner, (unsigned long long)budget);
+  std::vector<uint32_t> gstart((size_t)G + 1, 0), order(K);
+  for (uint32_t k = 0; k < K; ++k) {
+    if (map[k] >= G) return fail(OLAP_ERR_INDEX_RANGE, "tile placement: map entry %u = %u is outside the new dimension (%u items)", k, map[k], G);
+    gstart[map[k] + 1]++;
+  }
+  for (uint32_t g = 0; g < G; ++g) gstart[g + 1] += gstart[g];
+  std::vector<uint32_t> cur(gstart.begin(), gstart.end() - 1);
+  for (uint32_t k = 0; k < K; ++k) order[cur[map[k]]++] = k;
+  TilePerm tp;
+  tile_perm_build(gstart.data(), order.data(), K, G, inner, budget, 16 / olap_dtype_size(dtype), &tp);
+  memcpy(cell_pos, tp.cell.data(), (size_t)K * inner * sizeof(uint32_t));
+  memcpy(group_bounds, tp.grp.data(), tp.grp.size() * sizeof(uint32_t));
+  *pitch = tp.pitch;
+  return OLAP_OK;
+}
+
 extern "C" int olap_diag_read_ceiling(const void *device, uint64_t bytes, void *scratch, void *stream) {
   if (!device || !scratch) return fail(OLAP_ERR_INVALID_ARGUMENT, "device/scratch is NULL");
   if (((uintptr_t)device & 15u) != 0) return fail(OLAP_ERR_INVALID_ARGUMENT, "buffer must be 16-byte aligned");

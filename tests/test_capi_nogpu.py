@@ -84,6 +84,50 @@ def test_batch_entry_points_validate_before_the_device():
     assert L.olap_store_drillup_batch(0, hs, outs, 0, None, None, None, 0) == 0  # an empty cube: nothing to do
 
 
+@pytest.mark.parametrize("K,G,inner,kind,dtype", [(1000, 10, 1, "mod", "float32"), (1000, 100, 1, "mod", "float32"), (100, 10, 10, "mod", "float32"),
+                                                  (613, 0, 5, "ragged", "float32"), (37, 0, 3, "random", "int32"), (2048, 7, 1, "mod", "float64"),
+                                                  (4096, 585, 1, "random", "uint32"), (96, 6, 32, "mod", "float32")])
+def test_tile_placement_of_interleaved_groups(K, G, inner, kind, dtype):
+    """Host side of the row-tile regime with interleaved groups (tile_perm_build): every cell of a row gets its own LDS
+    cell, a group's members form ONE run in ascending member order, and — when the padding was affordable — the runs of
+    32 consecutive reducing lanes start on 32 different LDS banks."""
+    import numpy as np
+
+    rng = np.random.default_rng(K + inner)
+    if kind == "mod":
+        amap = (np.arange(K) % G).astype(np.uint32)
+    else:
+        raw = np.minimum(rng.geometric(0.15, size=K) - 1, 20) if kind == "ragged" else rng.integers(0, max(2, K // 7), size=K)
+        first = {}
+        amap = np.array([first.setdefault(int(g), len(first)) for g in raw], dtype=np.uint32)
+        G = int(amap.max()) + 1
+    cell = np.zeros(K * inner, np.uint32)
+    grp = np.zeros(2 * G, np.uint32)
+    pitch = C.c_uint32()
+    L = capi.lib()
+    capi.check(L.olap_diag_tile_placement(capi.DTYPES[dtype], K, G, inner, amap.ctypes.data_as(capi._pu32), cell.ctypes.data_as(capi._pu32),
+                                          grp.ctypes.data_as(capi._pu32), C.byref(pitch)))
+    P = pitch.value
+    assert P >= K and len(set(cell.tolist())) == K * inner and int(cell.max()) < P * inner
+    size = np.bincount(amap, minlength=G)
+    starts, ends = grp[0::2].astype(np.int64), grp[1::2].astype(np.int64)
+    assert np.array_equal(ends - starts, size) and np.all(starts[1:] >= ends[:-1]) and ends[-1] <= P
+    for g in range(G):  # the run of group g holds its members in ascending order, `inner` cells each
+        members = np.nonzero(amap == g)[0]
+        for r, k in enumerate(members):
+            assert np.array_equal(cell[k * inner:(k + 1) * inner], (starts[g] + r) * inner + np.arange(inner))
+    if P > K or np.all(starts == np.concatenate(([0], np.cumsum(size)[:-1]))) and inner >= 32:
+        # lanes (row, group, i): bank of the first cell each reads
+        rows = max(1, min(4, (16384 // capi.DTYPE_SIZE[capi.DTYPES[dtype]]) // (P * inner)))
+        banks = [((r * P + starts[g]) * inner + i) % 32 for r in range(rows) for g in range(G) for i in range(inner)]
+        for lo in range(0, max(1, len(banks) - 31), 32):
+            window = banks[lo:lo + 32]
+            assert len(set(window)) == len(window), (lo, window)
+    cap = 16384 // capi.DTYPE_SIZE[capi.DTYPES[dtype]]
+    assert L.olap_diag_tile_placement(capi.DTYPES[dtype], cap + 1, 1, 1, np.zeros(cap + 1, np.uint32).ctypes.data_as(capi._pu32), cell.ctypes.data_as(capi._pu32),
+                                      grp.ctypes.data_as(capi._pu32), C.byref(pitch)) == capi.ERR_INVALID_ARGUMENT
+
+
 def test_no_cpu_fallback_without_device():
     if capi.lib().olap_device_count() > 0:
         pytest.skip("a GPU is present")
