@@ -1276,3 +1276,53 @@ def test_drillup_batch_falls_back_and_validates():
     arr = (capi._pu32 * 3)(*[m.ctypes.data_as(capi._pu32) for m in keep])
     rc = L.olap_store_drillup_batch(2, hs, outs2, 3, ol.ctypes.data_as(capi._pu32), nl.ctypes.data_as(capi._pu32), arr, 0)
     assert rc != 0 and b"NULL" in L.olap_last_error() and outs2[0] is None
+
+
+@pytest.mark.parametrize("lens,gmap_mod", [([7, 12, 20], 5), ([3, 40, 1028], 7), ([50, 64, 6], 4)])
+def test_plan_run_batch_on_raw_pointers(lens, gmap_mod):
+    """olap_plan_run_batch on raw device pointers: aligned buffers, buffers 4 bytes off a 16-byte boundary (the whole
+    batch then moves cell by cell), masks on every pair, and masks on SOME pairs only (pair by pair behind the call) —
+    the same cells as single runs."""
+    import torch
+
+    n = int(np.prod(lens))
+    K = lens[1]
+    maps = [np.arange(lens[0], dtype=np.uint32), (np.arange(K) % gmap_mod).astype(np.uint32), np.arange(lens[2], dtype=np.uint32)]
+    new = [lens[0], gmap_mod, lens[2]]
+    nm = 5
+    rng = np.random.default_rng(n)
+    for method in ("sum", "last"):
+        plan = pkg.Plan.drillup("float32", 0.0, method, lens, new, maps)
+        n_out = plan.out_cells
+        srcs = [pkg.HipStore(n, "float32", 0.0) for _ in range(nm)]
+        for s in srcs:
+            s.set_data_f64(np.where(rng.random(n) < 0.3, 0.0, rng.integers(-8, 9, size=n) * 0.5))
+        want = []
+        for s in srcs:
+            o = pkg.HipStore(n_out, "float32", 0.0)
+            plan.run(s.values_ptr, None, o.values_ptr, o.status_ptr)
+            want.append((o.get_data(), o.get_status()))
+        for off in (0, 1):  # cells off a 16-byte boundary
+            ins = [torch.empty(n + 4, dtype=torch.float32, device="cuda") for _ in range(nm)]
+            outs = [torch.empty(n_out + 4, dtype=torch.float32, device="cuda") for _ in range(nm)]
+            sts = [torch.empty(n_out + 4, dtype=torch.int32, device="cuda") for _ in range(nm)]
+            for t, s in zip(ins, srcs):
+                t[off:off + n].copy_(torch.from_numpy(s.get_data()).cuda())
+            torch.cuda.synchronize()
+            plan.run_batch([t.data_ptr() + 4 * off for t in ins], None, [t.data_ptr() + 4 * off for t in outs], [t.data_ptr() + 4 * off for t in sts])
+            torch.cuda.synchronize()
+            for i in range(nm):
+                assert same_typed(outs[i][off:off + n_out].cpu().numpy(), want[i][0]), (method, off, i)
+                assert np.array_equal(sts[i][off:off + n_out].cpu().numpy(), want[i][1]), (method, off, i)
+        # masks on every pair / on some pairs only
+        outs = [pkg.HipStore(n_out, "float32", 0.0) for _ in range(nm)]
+        plan.run_batch([s.values_ptr for s in srcs], [s.status_ptr for s in srcs], [o.values_ptr for o in outs], [o.status_ptr for o in outs])
+        pkg.capi.check(pkg.lib().olap_device_synchronize())
+        for i in range(nm):
+            assert same_typed(outs[i].get_data(), want[i][0]) and np.array_equal(outs[i].get_status(), want[i][1])
+        outs = [pkg.HipStore(n_out, "float32", 0.0) for _ in range(nm)]
+        plan.run_batch([s.values_ptr for s in srcs], [s.status_ptr if i % 2 else 0 for i, s in enumerate(srcs)], [o.values_ptr for o in outs],
+                       [o.status_ptr for o in outs])
+        pkg.capi.check(pkg.lib().olap_device_synchronize())
+        for i in range(nm):
+            assert same_typed(outs[i].get_data(), want[i][0]) and np.array_equal(outs[i].get_status(), want[i][1])
