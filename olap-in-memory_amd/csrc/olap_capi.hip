@@ -497,6 +497,11 @@ extern "C" int olap_drillup_plan(olap_plan **out, int dtype, int default_kind, i
           while ((uint64_t)rows4 * 2 * a.inner <= (uint64_t)rd.unit * 4) rows4 *= 2;
           if (contiguous && a.G == 1 && olap_dtype_size(dtype) == 4 && (a.K * a.inner) % 4 == 0 &&
               (uint64_t)rows4 * a.inner <= (uint64_t)rd.unit * 4) {
+            // as many rows per step as the unit's lanes hold (whole 16-byte groups): 10 rows of 100 cells fill 250 of 256
+            // lanes where the power of two below fills 200; the rows are then merged through LDS instead of lane to lane
+            uint64_t rows_any = (uint64_t)rd.unit * 4 / a.inner;
+            while (rows_any > rows4 && (rows_any * a.inner) % 4 != 0) --rows_any;
+            if (a.inner > 2 && rows_any * 10 >= (uint64_t)rows4 * 11 && !getenv("OLAP_REDUCE_POW2_ROWS")) rows4 = (uint32_t)rows_any;
             rd.vec4 = 1;
             rd.rows = rows4;
             rd.seg_len = (uint32_t)seg_len;

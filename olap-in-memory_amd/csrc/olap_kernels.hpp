@@ -1102,7 +1102,9 @@ __global__ __launch_bounds__(kBlock) void drillup_reduce4_kernel(const T *__rest
   // inside the first wavefront and are wave shuffles; a workgroup-wide unit folds the longer ones
   // through LDS first (three levels at most).
   // Idle lanes hold the identity.  With one segment per group the result is final and leaves from here.
-  const bool by_shuffle = inner % 4 == 0 || inner <= 2;
+  // (rows per step need not be a power of two — 10 rows of 100 cells fill 250 of a unit's 256 lanes where 8 fill 200 —
+  // but the lane-to-lane merge needs one: other row counts take the LDS tree below)
+  const bool by_shuffle = inner <= 2 || (inner % 4 == 0 && (rd.rows & (rd.rows - 1)) == 0);
   if (by_shuffle) {
     uint32_t m, top;  // lanes per row, rows spread over the unit's lanes
     uint32_t ne = 4;  // accumulators per lane still in play
@@ -1177,8 +1179,21 @@ __global__ __launch_bounds__(kBlock) void drillup_reduce4_kernel(const T *__rest
 #pragma unroll
   for (int e = 0; e < 4; ++e) lds[lds_base + lane * 4 + e] = p[e];
   __syncthreads();
-  // tree over the rows of a step: flat slot f = r*inner + i
-  for (uint32_t s = rd.rows >> 1; s > 0; s >>= 1) {
+  // tree over the rows of a step: flat slot f = r*inner + i.  Rows beyond the largest power of two are folded onto
+  // the first rows before the tree starts.
+  uint32_t pow2 = 1;
+  while (pow2 * 2 <= rd.rows) pow2 *= 2;
+  if (pow2 < rd.rows) {
+    if (live) {
+      for (uint32_t f = lane; f < (rd.rows - pow2) * inner; f += rd.unit) {
+        Partial x = lds[lds_base + f];
+        partial_merge_fast<METHOD, FAST>(x, lds[lds_base + f + pow2 * inner], def_nan);
+        lds[lds_base + f] = x;
+      }
+    }
+    __syncthreads();
+  }
+  for (uint32_t s = pow2 >> 1; s > 0; s >>= 1) {
     if (live) {
       for (uint32_t f = lane; f < s * inner; f += rd.unit) {
         Partial x = lds[lds_base + f];
