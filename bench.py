@@ -230,9 +230,26 @@ def bench_config5(pkg, engine, torch):
 
     us1, us2 = _time(torch, months, iters=20), _time(torch, countries, iters=50)
     b1 = 4 * (n + 120 * 27400) * 4
-    return {"cells": n, "measures": 4, "drillUp_time_month_us": us1, "drillUp_time_month_GBps": b1 / (us1 * 1e-6) / 1e9,
-            "drillUp_time_month_frac": b1 / (us1 * 1e-6) / 1e9 / HBM_PEAK_GBS, "cell_measures_per_s": 4 * n / (us1 * 1e-6),
-            "drillUp_location_country_us": us2, "kernel": measures[0][1].kernel_name}
+    res = {"cells": n, "measures": 4, "drillUp_time_month_us": us1, "drillUp_time_month_GBps": b1 / (us1 * 1e-6) / 1e9,
+           "drillUp_time_month_frac": b1 / (us1 * 1e-6) / 1e9 / HBM_PEAK_GBS, "cell_measures_per_s": 4 * n / (us1 * 1e-6),
+           "drillUp_location_country_us": us2, "kernel": measures[0][1].kernel_name}
+    # the four measures, each with its own rule, as ONE launch (olap_plan_run_batch_rules: what Cube.drillUp sends)
+    try:
+        rules = ("sum", "average", "first", "last")
+        p1, p2 = measures[0][1], measures[0][2]
+
+        def months_one_launch():
+            p1.run_batch_rules(rules, [m[0].data_ptr() for m in measures], None, [m[3].data_ptr() for m in measures], None, st)
+
+        def countries_one_launch():
+            p2.run_batch_rules(rules, [m[3].data_ptr() for m in measures], None, [m[4].data_ptr() for m in measures], None, st)
+
+        u1, u2 = _time(torch, months_one_launch, iters=20), _time(torch, countries_one_launch, iters=50)
+        res["one_launch"] = {"drillUp_time_month_us": u1, "drillUp_time_month_frac": b1 / (u1 * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                             "drillUp_location_country_us": u2, "kernel": "drillup_rows_mixed_kernel"}
+    except Exception as err:  # must not cost the headline line
+        res["one_launch"] = {"error": str(err)[:200]}
+    return res
 
 
 def bench_1e9_single_gpu(pkg, engine, torch, iters=10):
@@ -560,8 +577,19 @@ def main():
 
                 us1 = _time(torch, one_by_one, iters=200, warm=20)
                 usb = _time(torch, lambda: o.run_batch(ip, None, op, None, stream), iters=200, warm=20)
+                rules4 = ("sum", "average", "first", "last")
+                plans4 = [pkg.Plan.drillup("float32", 0.0, r, lens6, new6, maps6) for r in rules4]
+
+                def rule_by_rule():
+                    for i in range(nm):
+                        plans4[i].run(ip[i], None, op[i], None, stream)
+
+                usr1 = _time(torch, rule_by_rule, iters=200, warm=20)
+                usr = _time(torch, lambda: o.run_batch_rules(rules4, ip, None, op, None, stream), iters=200, warm=20)
                 extra["batched_measures_1e6"] = {"measures": nm, "one_launch_each_us": round(us1, 3), "one_launch_for_all_us": round(usb, 3),
-                                                 "cell_measures_per_s": nm * 1e6 / (usb * 1e-6), "kernel": o.kernel_name}
+                                                 "cell_measures_per_s": nm * 1e6 / (usb * 1e-6), "kernel": o.kernel_name,
+                                                 "four_rules": {"rules": list(rules4), "one_launch_each_us": round(usr1, 3),
+                                                                "one_launch_for_all_us": round(usr, 3), "kernel": "drillup_rows_mixed_kernel"}}
                 del ins, outs
             except Exception as err:  # must not cost the headline line
                 extra["batched_measures_1e6"] = {"error": str(err)[:200]}

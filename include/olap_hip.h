@@ -164,6 +164,12 @@ int olap_plan_run(olap_plan *plan, const void *in_values, const int32_t *in_stat
  * lists whose entries may be NULL.  Same results as n olap_plan_run calls. */
 int olap_plan_run_batch(olap_plan *plan, int n, const void *const *in_values, const int32_t *const *in_status,
                         void *const *out_values, int32_t *const *out_status, void *stream);
+/* A drillUp plan over n pairs with a rule EACH (methods[i], one of the seven reference methods; the rule the plan
+ * was built with is ignored — a drillUp plan's tables do not depend on it).  ONE launch when the roll-up runs in the
+ * row regime with full 16-byte lanes and the pairs all carry masks or none (drillup_rows_mixed_kernel: the rule is a
+ * workgroup-uniform switch); pair by pair otherwise.  Same results as n runs of n plans. */
+int olap_plan_run_batch_rules(olap_plan *plan, int n, const int *methods, const void *const *in_values,
+                              const int32_t *const *in_status, void *const *out_values, int32_t *const *out_status, void *stream);
 /* After the stream has been synchronised: OLAP_OK, or the deferred data-dependent error of the
  * last run (OLAP_ERR_DISTRIBUTION_MISSING, message as in-memory.js:398). */
 int olap_plan_status(olap_plan *plan);
@@ -312,6 +318,14 @@ int olap_store_drillup(const olap_store *store, olap_store **out, int ndim, cons
  * returned.  Replaces the per-measure loop of src/cube.js:1012-1020 for measures with the same rule. */
 int olap_store_drillup_batch(int n, const olap_store *const *stores, olap_store **out, int ndim, const uint32_t *old_len,
                              const uint32_t *new_len, const uint32_t *const *maps, int method);
+/* The same for stored measures with a rule EACH (methods[i], one of the seven reference methods): what Cube.drillUp does
+ * for every stored measure of a cube, `store.drillUp(oldDims, newDims, storedMeasuresRules[id][dimensionId])`
+ * (src/cube.js:1012-1020).  Measures that share cell type, default and size leave in ONE launch even when their rules
+ * differ, when the roll-up runs in the row regime with full 16-byte lanes (the rule of a measure is a workgroup-uniform
+ * switch: config 5's sum / average / first / last); otherwise one launch per rule (olap_store_drillup_batch), and
+ * stores that fit no group one by one.  Same results as n olap_store_drillup calls. */
+int olap_store_drillup_multi(int n, const olap_store *const *stores, const int *methods, olap_store **out, int ndim,
+                             const uint32_t *old_len, const uint32_t *new_len, const uint32_t *const *maps);
 int olap_store_drilldown(const olap_store *store, olap_store **out, int ndim,
                          const uint32_t *old_len, const uint32_t *new_len,
                          const uint32_t *const *maps, int method, const double *distributions,

@@ -63,6 +63,7 @@ SIGNATURES = {
     "olap_plan_run": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "olap_diag_tile_placement": (_i32, [_i32, C.c_uint32, C.c_uint32, C.c_uint32, _pu32, _pu32, _pu32, _pu32]),
     "olap_plan_run_batch": (_i32, [_vp, _i32, _pvp, _pvp, _pvp, _pvp, _vp]),
+    "olap_plan_run_batch_rules": (_i32, [_vp, _i32, C.POINTER(C.c_int), _pvp, _pvp, _pvp, _pvp, _vp]),
     "olap_plan_status": (_i32, [_vp]),
     "olap_plan_destroy": (None, [_vp]),
     "olap_canonicalize": (_i32, [_vp, _vp, _u64, _i32, _i32, _i32, _vp]),
@@ -100,6 +101,7 @@ SIGNATURES = {
     "olap_store_totals": (_i32, [_vp, _i32, _pu32, C.POINTER(C.c_int), _pdbl, _pi32, C.POINTER(C.c_int), _pu64]),
     "olap_store_drillup": (_i32, [_vp, _pvp, _i32, _pu32, _pu32, _ppu32, _i32]),
     "olap_store_drillup_batch": (_i32, [_i32, _pvp, _pvp, _i32, _pu32, _pu32, _ppu32, _i32]),
+    "olap_store_drillup_multi": (_i32, [_i32, _pvp, C.POINTER(C.c_int), _pvp, _i32, _pu32, _pu32, _ppu32]),
     "olap_store_drilldown": (_i32, [_vp, _pvp, _i32, _pu32, _pu32, _ppu32, _i32, _pdbl, _u64]),
     "olap_store_dice": (_i32, [_vp, _pvp, _i32, _pu32, _pu32, _ppi32]),
     "olap_store_dice_drillup": (_i32, [_vp, _pvp, _i32, _pu32, _pu32, _pu32, _ppi32, _ppu32, _i32]),

@@ -1626,6 +1626,88 @@ static int run_batch_typed(olap_plan *p, int n, const void *const *in_v, const i
   return OLAP_OK;
 }
 
+// n pairs whose rules differ (methods[i]), same plan otherwise.  OLAP_OK when they went out as mixed-rule launches;
+// OLAP_ERR_UNSUPPORTED (nothing launched) when this plan / these buffers need rule-by-rule launches.
+constexpr int OLAP_MIXED_NOT_APPLICABLE = -1000;
+template <typename T>
+static int run_mixed_typed(olap_plan *p, int n, const int *methods, const void *const *in_v, const int32_t *const *in_s, void *const *out_v,
+                           int32_t *const *out_s, hipStream_t stream) {
+  const bool hs = in_s && in_s[0];
+  bool deep = false;
+  for (int i = 0; i < n; ++i) deep = deep || methods[i] == OLAP_PRODUCT;
+  for (int first = 0; first < n; first += kMaxBatch) {
+    const int nb = std::min(n - first, (int)kMaxBatch);
+    Batch<T> b{};
+    bool al = true;
+    for (int i = 0; i < nb; ++i) {
+      b.in[i] = (const T *)in_v[first + i];
+      b.st_in[i] = hs ? in_s[first + i] : nullptr;
+      b.out[i] = (T *)out_v[first + i];
+      b.st_out[i] = out_s ? out_s[first + i] : nullptr;
+      b.method[i] = methods[first + i];
+      al = al && aligned16(b.in[i]) && aligned16(b.out[i]) && (!b.st_in[i] || aligned16(b.st_in[i])) && (!b.st_out[i] || aligned16(b.st_out[i]));
+    }
+    DrillUpAxis a = p->axis;
+    a.aligned16 = al;
+    a.n_vec = a.inner / (uint64_t)p->vec;
+    a.total = a.outer * a.G * a.n_vec;
+    a.blocks_per_row = (a.n_vec + kBlock - 1) / kBlock;
+    { const char *x = getenv("OLAP_XCD_ORDER"); a.xcd_order = x ? atoi(x) : 1; }
+    hipError_t e = Launch<T>::drillup_rows_mixed(hs, p->vec, b, (unsigned)nb, a, deep, stream);
+    if (e == hipErrorNotSupported && first == 0) return OLAP_MIXED_NOT_APPLICABLE;
+    if (e != hipSuccess) return hip_fail(e, "drillup_rows_mixed_kernel");
+  }
+  return OLAP_OK;
+}
+
+// (internal) the pairs of one plan with a rule each; masks on all pairs or on none
+static int plan_run_mixed(olap_plan *p, int n, const int *methods, const void *const *in_values, const int32_t *const *in_status,
+                          void *const *out_values, int32_t *const *out_status, hipStream_t s) {
+  if (p->kind != PLAN_DRILLUP_AXIS || p->reduce.S != 0 || plan_dry() || getenv("OLAP_NO_MIXED_RULES")) return OLAP_MIXED_NOT_APPLICABLE;
+  for (int i = 0; i < n; ++i)
+    if (methods[i] < OLAP_SUM || methods[i] > OLAP_PRODUCT) return OLAP_MIXED_NOT_APPLICABLE;
+  int cur = -1;
+  if (hipGetDevice(&cur) == hipSuccess && cur != p->device) return OLAP_MIXED_NOT_APPLICABLE;
+  p->last_stream = s;
+  p->ran = true;
+  switch (p->dtype) {
+    case OLAP_INT32: return run_mixed_typed<int32_t>(p, n, methods, in_values, in_status, out_values, out_status, s);
+    case OLAP_UINT32: return run_mixed_typed<uint32_t>(p, n, methods, in_values, in_status, out_values, out_status, s);
+    case OLAP_FLOAT32: return run_mixed_typed<float>(p, n, methods, in_values, in_status, out_values, out_status, s);
+    default: return run_mixed_typed<double>(p, n, methods, in_values, in_status, out_values, out_status, s);
+  }
+}
+
+extern "C" int olap_plan_run_batch_rules(olap_plan *p, int n, const int *methods, const void *const *in_values,
+                                         const int32_t *const *in_status, void *const *out_values, int32_t *const *out_status, void *stream) {
+  if (!p) return fail(OLAP_ERR_INVALID_ARGUMENT, "plan is NULL");
+  if (n < 0 || (n > 0 && (!methods || !in_values || !out_values))) return fail(OLAP_ERR_INVALID_ARGUMENT, "batch of %d: method and values lists must not be NULL", n);
+  if (p->kind != PLAN_DRILLUP_AXIS && p->kind != PLAN_DRILLUP_GENERIC) return fail(OLAP_ERR_INVALID_ARGUMENT, "rules per pair need a drillUp plan");
+  if (plan_dry()) return fail(OLAP_ERR_NO_DEVICE, "OLAP_PLAN_DRY is set: plans are built for inspection only; libolapgpu has no CPU fallback");
+  bool masks_in = false, masks_out = false, mixed_masks = false;
+  for (int i = 0; i < n; ++i) {
+    if (methods[i] < OLAP_SUM || methods[i] > OLAP_PRODUCT) return fail(OLAP_ERR_UNSUPPORTED_METHOD, "Unsupported aggregation method: %d", methods[i]);
+    if ((p->in_cells && !in_values[i]) || (p->out_cells && !out_values[i]))
+      return fail(OLAP_ERR_INVALID_ARGUMENT, "values pointers must not be NULL (pair %d of the batch)", i);
+    const bool mi = in_status && in_status[i], mo = out_status && out_status[i];
+    if (i == 0) masks_in = mi, masks_out = mo;
+    else if (mi != masks_in || mo != masks_out) mixed_masks = true;
+  }
+  if (n > 1 && !mixed_masks) {
+    const int rc = plan_run_mixed(p, n, methods, in_values, in_status, out_values, out_status, (hipStream_t)stream);
+    if (rc != OLAP_MIXED_NOT_APPLICABLE) return rc;
+  }
+  // pair by pair: a drillUp plan's tables do not depend on the rule
+  const int planned = p->method;
+  int rc = OLAP_OK;
+  for (int i = 0; i < n && !rc; ++i) {
+    p->method = methods[i];
+    rc = olap_plan_run(p, in_values[i], in_status ? in_status[i] : nullptr, out_values[i], out_status ? out_status[i] : nullptr, stream);
+  }
+  p->method = planned;
+  return rc;
+}
+
 extern "C" int olap_plan_run_batch(olap_plan *p, int n, const void *const *in_values, const int32_t *const *in_status,
                                    void *const *out_values, int32_t *const *out_status, void *stream) {
   if (!p) return fail(OLAP_ERR_INVALID_ARGUMENT, "plan is NULL");
@@ -2622,6 +2704,86 @@ extern "C" int olap_store_drillup_batch(int n, const olap_store *const *stores, 
   if (cached) plan_cache().release(plan);
   else olap_plan_destroy(plan);
   return rc ? undo(rc) : OLAP_OK;
+}
+
+// Cube.drillUp over ALL stored measures of a cube, each with its own rule for the rolled-up dimension (methods[i]):
+// measures that share cell type, default and size go out together — one mixed-rule launch when the roll-up runs in
+// the row regime (drillup_rows_mixed_kernel), one launch per rule otherwise — the rest one by one.
+extern "C" int olap_store_drillup_multi(int n, const olap_store *const *stores, const int *methods, olap_store **out, int ndim,
+                                        const uint32_t *old_len, const uint32_t *new_len, const uint32_t *const *maps) {
+  if (n < 0 || (n > 0 && (!stores || !out || !methods))) return fail(OLAP_ERR_INVALID_ARGUMENT, "store / method list is NULL");
+  for (int i = 0; i < n; ++i) out[i] = nullptr;
+  for (int i = 0; i < n; ++i) {
+    if (!stores[i]) return fail(OLAP_ERR_INVALID_ARGUMENT, "store %d of the batch is NULL", i);
+    if (methods[i] < OLAP_SUM || methods[i] > OLAP_PRODUCT) return fail(OLAP_ERR_UNSUPPORTED_METHOD, "Unsupported aggregation method: %d", methods[i]);
+  }
+  auto undo = [&](int rc) {
+    for (int i = 0; i < n; ++i) {
+      if (out[i]) olap_store_destroy(out[i]);
+      out[i] = nullptr;
+    }
+    return rc;
+  };
+  bool same = n > 1, one_rule = true;
+  for (int i = 0; i < n; ++i) {
+    same = same && stores[i]->dtype == stores[0]->dtype && stores[i]->default_kind == stores[0]->default_kind && stores[i]->size == stores[0]->size &&
+           stores[i]->device == stores[0]->device && !stores[i]->track_order;
+    one_rule = one_rule && methods[i] == methods[0];
+  }
+  bool keyable = !bad_dims(ndim, old_len, new_len) && (ndim == 0 || maps);
+  for (int d = 0; keyable && d < ndim; ++d) keyable = old_len[d] == 0 || maps[d];
+  if (same && !one_rule && keyable) {
+    const olap_store *s0 = stores[0];
+    OnStoreDevice on_device__(s0);
+    PlanKey key;
+    key.i32('U');
+    key.i32(s0->dtype), key.i32(s0->default_kind), key.i32(methods[0]), key.i32(ndim);
+    key.u32s(old_len, ndim), key.u32s(new_len, ndim);
+    key.tables(maps, old_len, ndim);
+    olap_plan *plan = plan_cache().find(key.bytes);
+    if (!plan) {
+      int rc = olap_drillup_plan(&plan, s0->dtype, s0->default_kind, methods[0], ndim, old_len, new_len, maps);
+      if (rc) return rc;
+      plan_cache().insert(key.bytes, plan);
+    }
+    int rc = check_store_cells(s0, plan);
+    std::vector<const void *> in_v(n);
+    std::vector<const int32_t *> in_s(n);
+    std::vector<void *> out_v(n);
+    std::vector<int32_t *> out_s(n);
+    for (int i = 0; i < n && !rc; ++i) {
+      rc = store_alloc(&out[i], olap_plan_out_cells(plan), s0->dtype, s0->default_kind);
+      if (rc) break;
+      in_v[i] = stores[i]->values;
+      in_s[i] = mask_needed(stores[i]);
+      out_v[i] = out[i]->values;
+      out_s[i] = out[i]->status;
+    }
+    if (!rc) rc = plan_run_mixed(plan, n, methods, in_v.data(), in_s.data(), out_v.data(), out_s.data(), nullptr);
+    plan_cache().release(plan);
+    if (rc == OLAP_OK) return OLAP_OK;
+    undo(rc);
+    if (rc != OLAP_MIXED_NOT_APPLICABLE) return rc;
+  }
+  // rule by rule: the measures of one rule together (olap_store_drillup_batch groups further by cell type)
+  std::vector<char> done(n, 0);
+  for (int i = 0; i < n; ++i) {
+    if (done[i]) continue;
+    std::vector<int> members;
+    for (int j = i; j < n; ++j)
+      if (!done[j] && methods[j] == methods[i] && stores[j]->dtype == stores[i]->dtype && stores[j]->default_kind == stores[i]->default_kind &&
+          stores[j]->size == stores[i]->size) {
+        members.push_back(j);
+        done[j] = 1;
+      }
+    std::vector<const olap_store *> in(members.size());
+    std::vector<olap_store *> res(members.size(), nullptr);
+    for (size_t k = 0; k < members.size(); ++k) in[k] = stores[members[k]];
+    const int rc = olap_store_drillup_batch((int)members.size(), in.data(), res.data(), ndim, old_len, new_len, maps, methods[i]);
+    if (rc) return undo(rc);
+    for (size_t k = 0; k < members.size(); ++k) out[members[k]] = res[k];
+  }
+  return OLAP_OK;
 }
 
 static int store_drilldown_plain(const olap_store *s, olap_store **out, int ndim, const uint32_t *old_len,

@@ -51,6 +51,7 @@ struct Batch {
   const int32_t *st_in[kMaxBatch];
   T *out[kMaxBatch];
   int32_t *st_out[kMaxBatch];
+  int32_t method[kMaxBatch];  // only read by the mixed-rule kernel (drillup_rows_mixed_kernel)
   static Batch one(const T *in, const int32_t *st_in, T *out, int32_t *st_out) {
     Batch b{};
     b.in[0] = in;
@@ -146,11 +147,8 @@ struct Lane {
 // side, +7 % on stores: tools/unaligned_probe.hip) and only the row's last, partial slot goes cell by cell —
 // instead of 4-byte lanes (four times the load instructions and waves for the same bytes).
 template <typename T, int METHOD, bool HAS_STATUS, int VEC, int U, bool CONTIG, bool FAST, bool NT = true, bool RAGGED = false>
-__global__ __launch_bounds__(kBlock) void drillup_rows_kernel(const Batch<T> b, const DrillUpAxis a) {
-  const T *__restrict__ in = b.in[blockIdx.y];
-  const int32_t *__restrict__ st_in = b.st_in[blockIdx.y];
-  T *__restrict__ out = b.out[blockIdx.y];
-  int32_t *__restrict__ st_out = b.st_out[blockIdx.y];
+__device__ __forceinline__ void drillup_rows_body(const T *__restrict__ in, const int32_t *__restrict__ st_in, T *__restrict__ out,
+                                                  int32_t *__restrict__ st_out, const DrillUpAxis &a) {
   // blocks_per_row = ceil(n_vec / kBlock); blockIdx.x = og * blocks_per_row + chunk  (uniform math)
   const uint32_t bpr = (uint32_t)a.blocks_per_row;
   const uint32_t bid = a.xcd_order ? xcd_contiguous(blockIdx.x, gridDim.x) : blockIdx.x;
@@ -271,6 +269,40 @@ __global__ __launch_bounds__(kBlock) void drillup_rows_kernel(const Batch<T> b, 
     }
   }
 }
+
+template <typename T, int METHOD, bool HAS_STATUS, int VEC, int U, bool CONTIG, bool FAST, bool NT = true, bool RAGGED = false>
+__global__ __launch_bounds__(kBlock) void drillup_rows_kernel(const Batch<T> b, const DrillUpAxis a) {
+  drillup_rows_body<T, METHOD, HAS_STATUS, VEC, U, CONTIG, FAST, NT, RAGGED>(b.in[blockIdx.y], b.st_in[blockIdx.y], b.out[blockIdx.y],
+                                                                               b.st_out[blockIdx.y], a);
+}
+
+// Measures with DIFFERENT rules in one launch (config 5: sum / average / first / last over the same roll-up): the rule
+// of pair blockIdx.y is a workgroup-uniform switch in front of the same bodies.  The kernel carries every rule's code
+// and the registers of the greediest, so it only serves batches whose rules differ; one rule -> drillup_rows_kernel.
+template <typename T, bool HAS_STATUS, int VEC, int U, bool CONTIG>
+__global__ __launch_bounds__(kBlock) void drillup_rows_mixed_kernel(const Batch<T> b, const DrillUpAxis a) {
+  const T *in = b.in[blockIdx.y];
+  const int32_t *st_in = b.st_in[blockIdx.y];
+  T *out = b.out[blockIdx.y];
+  int32_t *st_out = b.st_out[blockIdx.y];
+  const bool fast = !HAS_STATUS && !a.def_nan;  // additive rules over a 0 default without a mask: plain running sums
+  switch (b.method[blockIdx.y]) {
+    case OLAP_SUM:
+      if (fast) drillup_rows_body<T, OLAP_SUM, HAS_STATUS, VEC, U, CONTIG, !HAS_STATUS>(in, st_in, out, st_out, a);
+      else drillup_rows_body<T, OLAP_SUM, HAS_STATUS, VEC, U, CONTIG, false>(in, st_in, out, st_out, a);
+      break;
+    case OLAP_AVERAGE:
+      if (fast) drillup_rows_body<T, OLAP_AVERAGE, HAS_STATUS, VEC, U, CONTIG, !HAS_STATUS>(in, st_in, out, st_out, a);
+      else drillup_rows_body<T, OLAP_AVERAGE, HAS_STATUS, VEC, U, CONTIG, false>(in, st_in, out, st_out, a);
+      break;
+    case OLAP_HIGHEST: drillup_rows_body<T, OLAP_HIGHEST, HAS_STATUS, VEC, U, CONTIG, false>(in, st_in, out, st_out, a); break;
+    case OLAP_LOWEST: drillup_rows_body<T, OLAP_LOWEST, HAS_STATUS, VEC, U, CONTIG, false>(in, st_in, out, st_out, a); break;
+    case OLAP_FIRST: drillup_rows_body<T, OLAP_FIRST, HAS_STATUS, VEC, U, CONTIG, false>(in, st_in, out, st_out, a); break;
+    case OLAP_LAST: drillup_rows_body<T, OLAP_LAST, HAS_STATUS, VEC, U, CONTIG, false>(in, st_in, out, st_out, a); break;
+    default: drillup_rows_body<T, OLAP_PRODUCT, HAS_STATUS, VEC, U, CONTIG, false>(in, st_in, out, st_out, a); break;
+  }
+}
+
 
 // Flat regime (inner small): one lane per VEC output cells, (outer, group) decoded per lane.
 // IDX: the lane index is decoded in 32-bit arithmetic when the launch has < 2^32 lanes (a 64-bit
@@ -2712,6 +2744,10 @@ struct Launch {
   // the same roll-up over nb (<= kMaxBatch) buffer pairs in one launch; all with or all without a mask
   static hipError_t drillup_axis_batch(int method, bool has_status, int vec, const Batch<T> &b, unsigned nb, const DrillUpAxis &a,
                                        hipStream_t stream);
+  // pairs with DIFFERENT rules (b.method[]) in one launch: the row regime with full 16-byte lanes only — anything else
+  // returns hipErrorNotSupported and the caller launches rule by rule.  `deep`: some pair's rule wants 4 rows in flight.
+  static hipError_t drillup_rows_mixed(bool has_status, int vec, const Batch<T> &b, unsigned nb, const DrillUpAxis &a, bool deep,
+                                       hipStream_t stream);
   static hipError_t drillup_reduce(int method, bool has_status, const T *in, const int32_t *st_in, T *out, int32_t *st_out,
                                    const DrillUpAxis &a, const DrillUpReduce &rd, hipStream_t stream);
   static hipError_t drillup_generic(int method, bool has_status, const T *in, const int32_t *st_in, T *out,
@@ -2956,6 +2992,40 @@ hipError_t Launch<T>::drillup_axis_batch(int method, bool has_status, int vec, c
   if (a.total == 0 || nb == 0) return hipSuccess;
   return has_status ? drillup_axis_method<T, true>(method, vec, b, nb, a, stream)
                     : drillup_axis_method<T, false>(method, vec, b, nb, a, stream);
+}
+
+template <typename T>
+hipError_t Launch<T>::drillup_rows_mixed(bool has_status, int vec, const Batch<T> &b, unsigned nb, const DrillUpAxis &a, bool deep,
+                                         hipStream_t stream) {
+  constexpr int VEC = 16 / sizeof(T);
+  if (a.total == 0 || nb == 0) return hipSuccess;
+  if (vec != VEC || !a.aligned16 || a.n_vec < 128) return hipErrorNotSupported;
+  unsigned row_lanes = kBlock;  // (as drillup_axis_launch picks it)
+  {
+    double best = 0.0;
+    for (unsigned cand : {256u, 128u, 64u}) {
+      const double fill = (double)a.n_vec / (double)(((a.n_vec + cand - 1) / cand) * cand);
+      if (fill >= 0.85) { row_lanes = cand; break; }
+      if (fill > best) { best = fill; row_lanes = cand; }
+    }
+  }
+  DrillUpAxis ar = a;
+  ar.blocks_per_row = (a.n_vec + row_lanes - 1) / row_lanes;
+  const uint64_t row_blocks = a.outer * a.G * ar.blocks_per_row;
+  if (row_blocks >= 0x7FFFFFFFull) return hipErrorNotSupported;
+  const bool shallow = !deep && a.n_vec >= 1024;
+  const bool contig = a.order == nullptr;
+  const dim3 grid((unsigned)row_blocks, nb);
+#define OLAP_MIXED(HS, UU, C) hipLaunchKernelGGL((drillup_rows_mixed_kernel<T, HS, VEC, UU, C>), grid, row_lanes, 0, stream, b, ar)
+  if (has_status) {
+    if (shallow) { if (contig) OLAP_MIXED(true, 1, true); else OLAP_MIXED(true, 1, false); }
+    else { if (contig) OLAP_MIXED(true, 4, true); else OLAP_MIXED(true, 4, false); }
+  } else {
+    if (shallow) { if (contig) OLAP_MIXED(false, 1, true); else OLAP_MIXED(false, 1, false); }
+    else { if (contig) OLAP_MIXED(false, 4, true); else OLAP_MIXED(false, 4, false); }
+  }
+#undef OLAP_MIXED
+  return hipGetLastError();
 }
 
 template <typename T, int METHOD>

@@ -164,6 +164,20 @@ class Plan:
         check(capi.lib().olap_plan_run_batch(self._h, n, ptrs(in_values), ptrs(in_status), ptrs(out_values), ptrs(out_status),
                                              stream or None))
 
+    def run_batch_rules(self, methods, in_values, in_status, out_values, out_status, stream=None):
+        """A drillUp plan over several buffer pairs with a rule each (names or codes): one mixed-rule launch where the
+        plan allows it (olap_plan_run_batch_rules)."""
+        n = len(in_values)
+
+        def ptrs(xs):
+            if xs is None:
+                return None
+            return (C.c_void_p * n)(*[x or None for x in xs])
+
+        codes = (C.c_int * n)(*[m if isinstance(m, int) else _method_code(m) for m in methods])
+        check(capi.lib().olap_plan_run_batch_rules(self._h, n, codes, ptrs(in_values), ptrs(in_status), ptrs(out_values), ptrs(out_status),
+                                                   stream or None))
+
     def status(self):
         check(capi.lib().olap_plan_status(self._h))
 
@@ -351,6 +365,19 @@ class HipStore:
         outs = (C.c_void_p * n)()
         check(capi.lib().olap_store_drillup_batch(n, hs, outs, len(ol), ol.ctypes.data_as(capi._pu32), nl.ctypes.data_as(capi._pu32), arr,
                                                   _method_code(method)))
+        return [HipStore(0, _handle=C.c_void_p(outs[i])) for i in range(n)]
+
+    @staticmethod
+    def drill_up_multi(stores, methods, old_len, new_len, maps):
+        """drillUp of the stored measures of a cube, each with its own rule (olap_store_drillup_multi): one mixed-rule
+        launch where the roll-up allows it; returns the new stores in order."""
+        ol, nl = _u32(old_len), _u32(new_len)
+        keep, arr = _tables(maps, np.uint32, C.c_uint32)
+        n = len(stores)
+        hs = (C.c_void_p * n)(*[s._h for s in stores])
+        codes = (C.c_int * n)(*[_method_code(m) for m in methods])
+        outs = (C.c_void_p * n)()
+        check(capi.lib().olap_store_drillup_multi(n, hs, codes, outs, len(ol), ol.ctypes.data_as(capi._pu32), nl.ctypes.data_as(capi._pu32), arr))
         return [HipStore(0, _handle=C.c_void_p(outs[i])) for i in range(n)]
 
     def drill_down(self, old_len, new_len, maps, method="sum", distributions=None):

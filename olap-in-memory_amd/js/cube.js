@@ -449,19 +449,13 @@ class Cube {
       return this;
     }
     const newDimensions = this._withDimension(index, rolled);
-    // The reference rolls its measures up one store call at a time (src/cube.js:1012-1020); measures that share the
-    // rule for this dimension go to the device together (HipStore.drillUpMany: one launch per cell type).
-    const byRule = new Map();
-    for (const id of this.storedMeasureIds) {
-      const rule = this.storedMeasuresRules[id][dimensionId];
-      if (!byRule.has(rule)) byRule.set(rule, []);
-      byRule.get(rule).push(id);
-    }
+    // The reference rolls its measures up one store call at a time (src/cube.js:1012-1020); here the stored measures go
+    // to the device together, each with its rule for this dimension (HipStore.drillUpMany: one launch where possible).
+    const ids = this.storedMeasureIds;
     const rolledUp = {};
-    for (const [rule, ids] of byRule) {
-      const Store = this.storedMeasures[ids[0]].constructor;
-      if (ids.length < 2 || typeof Store.drillUpMany !== 'function') continue;
-      const results = Store.drillUpMany(ids.map((id) => this.storedMeasures[id]), this.dimensions, newDimensions, rule);
+    const Store = ids.length ? this.storedMeasures[ids[0]].constructor : null;
+    if (ids.length >= 2 && typeof Store.drillUpMany === 'function') {
+      const results = Store.drillUpMany(ids.map((id) => this.storedMeasures[id]), this.dimensions, newDimensions, ids.map((id) => this.storedMeasuresRules[id][dimensionId]));
       ids.forEach((id, i) => {
         rolledUp[id] = results[i];
       });

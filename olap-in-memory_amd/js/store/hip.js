@@ -288,35 +288,30 @@ class HipStore {
   }
 
   /**
-   * drillUp of several measures of one cube by the same rule — what Cube.drillUp asks of every stored measure in turn
-   * (src/cube.js:1012-1020).  Measures held whole on one device with the same cell type and default go to the device
-   * as ONE launch (addon drillUpBatch -> olap_store_drillup_batch); the others (pending selections, sharded or
+   * drillUp of the stored measures of one cube, each by its own rule — what Cube.drillUp asks of every stored measure
+   * in turn (src/cube.js:1012-1020).  Measures held whole on one device go to the device TOGETHER (addon drillUpMulti ->
+   * olap_store_drillup_multi: one launch for the measures that share cell type and default — even with different rules
+   * when the roll-up streams whole rows — one launch per rule otherwise); the others (pending selections, sharded or
    * order-tracking measures, a lone measure) take drillUp one by one.  Returns the new stores in the order given.
    */
-  static drillUpMany(stores, oldDimensions, newDimensions, method = 'sum') {
+  static drillUpMany(stores, oldDimensions, newDimensions, methods) {
     const out = new Array(stores.length);
-    const batches = new Map();
+    const together = [];
     stores.forEach((store, i) => {
       const native = store._pending ? null : store._nativeStore;
-      if (!native || native.isSharded || native.orderTracked) return;
-      const key = `${store._type}/${Number.isNaN(store._defaultValue) ? 'nan' : '0'}`;
-      if (!batches.has(key)) batches.set(key, []);
-      batches.get(key).push(i);
+      if (native && !native.isSharded && !native.orderTracked) together.push(i);
     });
-    let code, maps;
-    for (const members of batches.values()) {
-      if (members.length < 2) continue;
-      if (maps === undefined) {
-        code = backend.load().methodFromName(method); // throws 'Unsupported aggregation method: <m>'
-        maps = newDimensions.map((dim, i) => Uint32Array.from(oldDimensions[i].getGroupIndexFromRootIndexMap(dim.rootAttribute)));
-      }
-      const natives = backend.load().drillUpBatch(members.map((i) => stores[i]._nativeStore), lengthsOf(oldDimensions), lengthsOf(newDimensions), maps, code);
-      members.forEach((i, j) => {
+    if (together.length >= 2) {
+      const addon = backend.load();
+      const codes = Int32Array.from(together, (i) => addon.methodFromName(methods[i] === undefined ? 'sum' : methods[i])); // throws 'Unsupported aggregation method: <m>'
+      const maps = newDimensions.map((dim, i) => Uint32Array.from(oldDimensions[i].getGroupIndexFromRootIndexMap(dim.rootAttribute)));
+      const natives = addon.drillUpMulti(together.map((i) => stores[i]._nativeStore), codes, lengthsOf(oldDimensions), lengthsOf(newDimensions), maps);
+      together.forEach((i, j) => {
         out[i] = stores[i]._wrap(natives[j]);
       });
     }
     stores.forEach((store, i) => {
-      if (!out[i]) out[i] = store.drillUp(oldDimensions, newDimensions, method);
+      if (!out[i]) out[i] = store.drillUp(oldDimensions, newDimensions, methods[i]);
     });
     return out;
   }

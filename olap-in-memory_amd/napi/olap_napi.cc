@@ -691,6 +691,50 @@ static napi_value DrillUpBatch(napi_env env, napi_callback_info info) {
   return arr;
 }
 
+// drillUpMulti(stores: Store[], methods: Int32Array, oldLen, newLen, maps) -> Store[]
+// Every stored measure of a cube with its own rule for the rolled-up dimension (olap_store_drillup_multi): one
+// mixed-rule launch where the roll-up allows it, one launch per rule otherwise.
+static napi_value DrillUpMulti(napi_env env, napi_callback_info info) {
+  size_t argc = 5;
+  napi_value argv[5];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+  OpArgs a;
+  bool is_arr = false;
+  if (argc >= 1) napi_is_array(env, argv[0], &is_arr);
+  napi_typedarray_type mt;
+  size_t n_methods = 0;
+  void *mdata = nullptr;
+  if (argc < 5 || !is_arr || napi_get_typedarray_info(env, argv[1], &mt, &n_methods, &mdata, nullptr, nullptr) != napi_ok || mt != napi_int32_array ||
+      !a.decode(env, argv[2], argv[3], argv[4]))
+    return bad_args(env, "drillUpMulti(stores: Store[], methods: Int32Array, oldLen: Uint32Array, newLen: Uint32Array, maps: Uint32Array[])");
+  uint32_t n = 0;
+  napi_get_array_length(env, argv[0], &n);
+  if (n_methods != n) return bad_args(env, "drillUpMulti: one method per store");
+  std::vector<const olap_store *> stores(n);
+  for (uint32_t i = 0; i < n; ++i) {
+    napi_value e;
+    NAPI_OK(napi_get_element(env, argv[0], i, &e));
+    stores[i] = unwrap(env, e);
+    if (!stores[i]) return nullptr;
+  }
+  std::vector<olap_store *> outs(n, nullptr);
+  static const int none = 0;
+  int rc = olap_store_drillup_multi((int)n, stores.data(), n ? (const int *)mdata : &none, outs.data(), (int)a.a_len.size(), a.a_len.data(), a.b_len.data(),
+                                    a.ptrs.data());
+  if (rc) return throw_olap(env, rc);
+  napi_value arr;
+  NAPI_OK(napi_create_array_with_length(env, n, &arr));
+  for (uint32_t i = 0; i < n; ++i) {
+    napi_value w = wrap_new_store(env, outs[i]);
+    if (!w) {
+      for (uint32_t j = i + 1; j < n; ++j) olap_store_destroy(outs[j]);
+      return nullptr;
+    }
+    napi_set_element(env, arr, i, w);
+  }
+  return arr;
+}
+
 // ---- ShardedStore: a measure split along dimension 0 over the devices of setDevices() -----------
 // Wraps olap_sharded_store* (include/olap_hip.h, "Multi-GPU").  Method names and argument shapes are
 // those of Store, so the JS HipStore drives either; what a sharded store cannot do in place throws an
@@ -1204,6 +1248,7 @@ static napi_value Init(napi_env env, napi_value exports) {
       {"evalFormulaSharded", nullptr, EvalFormulaSharded, nullptr, nullptr, nullptr, napi_default, nullptr},
       {"evalFormula", nullptr, EvalFormula, nullptr, nullptr, nullptr, napi_default, nullptr},
       {"drillUpBatch", nullptr, DrillUpBatch, nullptr, nullptr, nullptr, napi_default, nullptr},
+      {"drillUpMulti", nullptr, DrillUpMulti, nullptr, nullptr, nullptr, napi_default, nullptr},
       {"storeFromSparse", nullptr, StoreFromSparse, nullptr, nullptr, nullptr, napi_default, nullptr},
       {"methodFromName", nullptr, MethodFromName, nullptr, nullptr, nullptr, napi_default, nullptr},
       {"heldBytes", nullptr, HeldBytes, nullptr, nullptr, nullptr, napi_default, nullptr},

@@ -82,6 +82,11 @@ def test_batch_entry_points_validate_before_the_device():
     assert L.olap_store_drillup_batch(2, hs, outs, 0, None, None, None, 0) == capi.ERR_INVALID_ARGUMENT
     assert "store 0 of the batch is NULL" in capi.last_error()
     assert L.olap_store_drillup_batch(0, hs, outs, 0, None, None, None, 0) == 0  # an empty cube: nothing to do
+    methods = (C.c_int * 2)(0, 99)
+    assert L.olap_store_drillup_multi(2, hs, methods, outs, 0, None, None, None) == capi.ERR_INVALID_ARGUMENT  # NULL stores come first
+    assert L.olap_store_drillup_multi(2, None, methods, outs, 0, None, None, None) == capi.ERR_INVALID_ARGUMENT
+    assert L.olap_store_drillup_multi(0, hs, methods, outs, 0, None, None, None) == 0
+    assert L.olap_plan_run_batch_rules(None, 2, methods, None, None, None, None, None) == capi.ERR_INVALID_ARGUMENT
 
 
 @pytest.mark.parametrize("K,G,inner,kind,dtype", [(1000, 10, 1, "mod", "float32"), (1000, 100, 1, "mod", "float32"), (100, 10, 10, "mod", "float32"),

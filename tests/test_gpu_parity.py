@@ -1326,3 +1326,92 @@ def test_plan_run_batch_on_raw_pointers(lens, gmap_mod):
         pkg.capi.check(pkg.lib().olap_device_synchronize())
         for i in range(nm):
             assert same_typed(outs[i].get_data(), want[i][0]) and np.array_equal(outs[i].get_status(), want[i][1])
+
+
+RULES = ["sum", "average", "highest", "lowest", "first", "last", "product"]
+
+
+@pytest.mark.parametrize("type_name,default", [("float32", 0.0), ("float32", float("nan")), ("uint32", float("nan")), ("float64", 0.0), ("int32", 0.0)])
+@pytest.mark.parametrize("lens,axis,kind", [
+    ([6, 40, 1100], 0, "all"),            # row regime, 16-byte lanes, wide rows: one mixed-rule launch
+    ([9, 30, 4100], 1, "interleaved"),    # row regime, one row in flight, member list
+    ([12, 31, 520], 1, "contiguous"),     # row regime, four rows in flight
+    ([9, 30, 1027], 1, "interleaved"),    # ragged rows: rule by rule
+    ([300, 100, 3], 1, "interleaved"),    # row tile: rule by rule
+    ([2, 5000, 2], 1, "all"),             # reduce regime: rule by rule
+])
+@pytest.mark.parametrize("n", [2, 4, 9])
+def test_drillup_multi_rules_matches_single(lens, axis, kind, type_name, default, n):
+    """olap_store_drillup_multi: n measures with a rule EACH in one call — one mixed-rule launch in the row regime
+    (drillup_rows_mixed_kernel), one launch per rule elsewhere — give exactly the stores n single calls give."""
+    rng = np.random.default_rng(sum(lens) * 13 + n)
+    K = lens[axis]
+    amap = {"all": np.zeros(K), "interleaved": np.arange(K) % 7, "contiguous": np.arange(K) // 4}[kind].astype(np.uint32)
+    new = list(lens)
+    new[axis] = int(amap.max()) + 1
+    maps = [amap if d == axis else np.arange(l, dtype=np.uint32) for d, l in enumerate(lens)]
+    cells = int(np.prod(lens))
+    rules = [RULES[i % 7] for i in rng.permutation(max(n, 7))[:n]]
+    if n >= 4:
+        rules[:4] = ["sum", "average", "first", "last"]  # config 5's
+    stores = []
+    for rule in rules:
+        if rule == "product":
+            vals = np.where(rng.random(cells) < 0.5, 1.0, 2.0)
+        else:
+            vals = rng.integers(0 if type_name == "uint32" else -8, 9, size=cells).astype(np.float64)
+        g = pkg.HipStore(cells, type_name, default)
+        g.set_data_f64(np.where(rng.random(cells) < 0.3, default, vals))
+        stores.append(g)
+    multi = pkg.HipStore.drill_up_multi(stores, rules, lens, new, maps)
+    assert len(multi) == n
+    for g, rule, m in zip(stores, rules, multi):
+        single = g.drill_up(lens, new, maps, rule)
+        assert np.array_equal(m.get_status(), single.get_status()), rule
+        assert same_typed(m.get_data(), single.get_data()), rule
+
+
+def test_drillup_multi_mixed_stores_and_plan_level():
+    """Stores of different cell types in one olap_store_drillup_multi call (grouped behind it); olap_plan_run_batch_rules
+    on raw pointers: one mixed-rule launch, and pair by pair when the buffers are off a 16-byte boundary."""
+    import torch
+
+    lens, new = [5, 20, 1200], [5, 4, 1200]
+    maps = [np.arange(5, dtype=np.uint32), (np.arange(20) % 4).astype(np.uint32), np.arange(1200, dtype=np.uint32)]
+    n = int(np.prod(lens))
+    rng = np.random.default_rng(77)
+    kinds = [("float32", 0.0, "sum"), ("int32", 0.0, "last"), ("float32", 0.0, "highest"), ("float64", 0.0, "average"), ("int32", 0.0, "sum"),
+             ("float32", float("nan"), "first")]
+    stores = []
+    for t, d, _r in kinds:
+        g = pkg.HipStore(n, t, d)
+        g.set_data_f64(np.where(rng.random(n) < 0.3, d, rng.integers(-8, 9, size=n).astype(np.float64)))
+        stores.append(g)
+    outs = pkg.HipStore.drill_up_multi(stores, [k[2] for k in kinds], lens, new, maps)
+    for g, k, o in zip(stores, kinds, outs):
+        single = g.drill_up(lens, new, maps, k[2])
+        assert same_typed(o.get_data(), single.get_data()) and np.array_equal(o.get_status(), single.get_status()), k
+    with pytest.raises(pkg.OlapError) as ei:
+        pkg.HipStore.drill_up_multi(stores[:2], ["sum", "median"], lens, new, maps)
+    assert "Unsupported aggregation method" in str(ei.value)
+    # plan level
+    rules = ["sum", "average", "first", "last", "product"]
+    srcs = [stores[0], stores[2]] + [pkg.HipStore(n, "float32", 0.0) for _ in range(3)]
+    for s_ in srcs[2:]:
+        s_.set_data_f64(np.where(rng.random(n) < 0.3, 0.0, np.where(rng.random(n) < 0.5, 1.0, 2.0)))
+    plan = pkg.Plan.drillup("float32", 0.0, "lowest", lens, new, maps)  # (the planned rule is ignored)
+    n_out = plan.out_cells
+    want = [s_.drill_up(lens, new, maps, r) for s_, r in zip(srcs, rules)]
+    for off in (0, 1):
+        ins = [torch.empty(n + 4, dtype=torch.float32, device="cuda") for _ in srcs]
+        outs_t = [torch.empty(n_out + 4, dtype=torch.float32, device="cuda") for _ in srcs]
+        sts = [torch.empty(n_out + 4, dtype=torch.int32, device="cuda") for _ in srcs]
+        for t, s_ in zip(ins, srcs):
+            t[off:off + n].copy_(torch.from_numpy(s_.get_data()).cuda())
+        torch.cuda.synchronize()
+        plan.run_batch_rules(rules, [t.data_ptr() + 4 * off for t in ins], None, [t.data_ptr() + 4 * off for t in outs_t],
+                             [t.data_ptr() + 4 * off for t in sts])
+        torch.cuda.synchronize()
+        for i in range(len(srcs)):
+            assert same_typed(outs_t[i][off:off + n_out].cpu().numpy(), want[i].get_data()), (off, rules[i])
+            assert np.array_equal(sts[i][off:off + n_out].cpu().numpy(), want[i].get_status()), (off, rules[i])
