@@ -1004,7 +1004,17 @@ extern "C" int olap_reorder_plan(olap_plan **out, int dtype, int default_kind, i
       t.cached_stores = getenv("OLAP_XY_CACHED_STORES") != nullptr;
       t.tiles_x = (t.lx + t.tx - 1) / t.tx;
       t.tiles_y = (t.ly + t.ty - 1) / t.ty;
-      if (t.tiles_x < (uint64_t)t.super || t.tiles_y < (uint64_t)t.super) t.super = 1;  // (the grid is padded to whole blocks)
+      {
+        // the grid is padded to whole blocks: with 5 tiles across, 4 x 4 blocks launch 8 (three of them empty) and the
+        // Y-fastest walk loses its point — [3652,100,274] -> (sku, day, location) 176 -> 224 us; such shapes keep the
+        // plain X-fastest walk
+        const uint64_t k = (uint64_t)t.super;
+        const uint64_t padded = (t.tiles_x + k - 1) / k * k * ((t.tiles_y + k - 1) / k * k);
+        if (padded * 4 > t.tiles_x * t.tiles_y * 5 && !getenv("OLAP_XY_SUPER")) {  // (29 tiles padded to 32 still gain 15 %)
+          t.super = 1;
+          if (!getenv("OLAP_XY_ORDER")) t.y_first = 0;
+        }
+      }
       t.vec_in = in4 && t.lx % 4 == 0;
       t.vec_out = out4 && t.ly % 4 == 0;
       const bool is_float = dtype == OLAP_FLOAT32;
