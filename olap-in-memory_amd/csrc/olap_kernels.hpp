@@ -2994,12 +2994,8 @@ hipError_t Launch<T>::drillup_axis_batch(int method, bool has_status, int vec, c
                     : drillup_axis_method<T, false>(method, vec, b, nb, a, stream);
 }
 
-template <typename T>
-hipError_t Launch<T>::drillup_rows_mixed(bool has_status, int vec, const Batch<T> &b, unsigned nb, const DrillUpAxis &a, bool deep,
-                                         hipStream_t stream) {
-  constexpr int VEC = 16 / sizeof(T);
-  if (a.total == 0 || nb == 0) return hipSuccess;
-  if (vec != VEC || !a.aligned16 || a.n_vec < 128) return hipErrorNotSupported;
+template <typename T, int VEC>
+static hipError_t drillup_rows_mixed_vec(bool has_status, const Batch<T> &b, unsigned nb, const DrillUpAxis &a, bool deep, hipStream_t stream) {
   unsigned row_lanes = kBlock;  // (as drillup_axis_launch picks it)
   {
     double best = 0.0;
@@ -3013,7 +3009,7 @@ hipError_t Launch<T>::drillup_rows_mixed(bool has_status, int vec, const Batch<T
   ar.blocks_per_row = (a.n_vec + row_lanes - 1) / row_lanes;
   const uint64_t row_blocks = a.outer * a.G * ar.blocks_per_row;
   if (row_blocks >= 0x7FFFFFFFull) return hipErrorNotSupported;
-  const bool shallow = !deep && a.n_vec >= 1024;
+  const bool shallow = !deep && VEC * sizeof(T) >= 16 && a.n_vec >= 1024;
   const bool contig = a.order == nullptr;
   const dim3 grid((unsigned)row_blocks, nb);
 #define OLAP_MIXED(HS, UU, C) hipLaunchKernelGGL((drillup_rows_mixed_kernel<T, HS, VEC, UU, C>), grid, row_lanes, 0, stream, b, ar)
@@ -3026,6 +3022,21 @@ hipError_t Launch<T>::drillup_rows_mixed(bool has_status, int vec, const Batch<T
   }
 #undef OLAP_MIXED
   return hipGetLastError();
+}
+
+template <typename T>
+hipError_t Launch<T>::drillup_rows_mixed(bool has_status, int vec, const Batch<T> &b, unsigned nb, const DrillUpAxis &a, bool deep,
+                                         hipStream_t stream) {
+  constexpr int FULL = 16 / sizeof(T);
+  if (a.total == 0 || nb == 0) return hipSuccess;
+  // the row regime with 16-byte lanes, or 8-byte lanes of 4-byte cells (rows of an even number of cells: config 5's
+  // [120,100,274] -> country); single cells per lane and the other regimes go rule by rule
+  if (!a.aligned16 || a.n_vec < 128) return hipErrorNotSupported;
+  if (vec == FULL) return drillup_rows_mixed_vec<T, FULL>(has_status, b, nb, a, deep, stream);
+  if constexpr (FULL == 4) {
+    if (vec == 2) return drillup_rows_mixed_vec<T, 2>(has_status, b, nb, a, deep, stream);
+  }
+  return hipErrorNotSupported;
 }
 
 template <typename T, int METHOD>

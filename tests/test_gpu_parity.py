@@ -1336,6 +1336,7 @@ RULES = ["sum", "average", "highest", "lowest", "first", "last", "product"]
     ([6, 40, 1100], 0, "all"),            # row regime, 16-byte lanes, wide rows: one mixed-rule launch
     ([9, 30, 4100], 1, "interleaved"),    # row regime, one row in flight, member list
     ([12, 31, 520], 1, "contiguous"),     # row regime, four rows in flight
+    ([20, 100, 274], 1, "contiguous"),    # rows of an even number of cells: 8-byte lanes (config 5's city -> country)
     ([9, 30, 1027], 1, "interleaved"),    # ragged rows: rule by rule
     ([300, 100, 3], 1, "interleaved"),    # row tile: rule by rule
     ([2, 5000, 2], 1, "all"),             # reduce regime: rule by rule
