@@ -586,7 +586,20 @@ def main():
 
                 usr1 = _time(torch, rule_by_rule, iters=200, warm=20)
                 usr = _time(torch, lambda: o.run_batch_rules(rules4, ip, None, op, None, stream), iters=200, warm=20)
+                # the same four rules rolled up along an INNER dimension (axis 3: the row-tile regime)
+                new6i = lens6[:3] + [1] + lens6[4:]
+                maps6i = [np.arange(10, dtype=np.uint32) for _ in range(3)] + [np.zeros(10, np.uint32)] + [np.arange(10, dtype=np.uint32) for _ in range(2)]
+                plans4i = [pkg.Plan.drillup("float32", 0.0, r, lens6, new6i, maps6i) for r in rules4]
+
+                def rule_by_rule_inner():
+                    for i in range(nm):
+                        plans4i[i].run(ip[i], None, op[i], None, stream)
+
+                usi1 = _time(torch, rule_by_rule_inner, iters=200, warm=20)
+                usi = _time(torch, lambda: plans4i[0].run_batch_rules(rules4, ip, None, op, None, stream), iters=200, warm=20)
                 extra["batched_measures_1e6"] = {"measures": nm, "one_launch_each_us": round(us1, 3), "one_launch_for_all_us": round(usb, 3),
+                                                 "four_rules_inner_axis": {"axis": 3, "one_launch_each_us": round(usi1, 3), "one_launch_for_all_us": round(usi, 3),
+                                                                           "kernel": "drillup_tile_mixed_kernel"},
                                                  "cell_measures_per_s": nm * 1e6 / (usb * 1e-6), "kernel": o.kernel_name,
                                                  "four_rules": {"rules": list(rules4), "one_launch_each_us": round(usr1, 3),
                                                                 "one_launch_for_all_us": round(usr, 3), "kernel": "drillup_rows_mixed_kernel"}}

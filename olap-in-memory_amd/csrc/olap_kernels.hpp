@@ -518,11 +518,8 @@ constexpr uint32_t kTileBytes = 16 * 1024;  // cells staged per workgroup: 8 wor
 // on distinct LDS banks (TilePerm below): lanes (row, group) read member j of their runs in the same instruction,
 // and with runs 100 cells apart 40 lanes shared 8 banks.
 template <typename T, int METHOD, bool HAS_STATUS, bool FAST, int MODE>
-__global__ __launch_bounds__(kBlock) void drillup_tile_kernel(const Batch<T> b, const DrillUpAxis a, const DrillUpTile tl) {
-  const T *__restrict__ in = b.in[blockIdx.y];
-  const int32_t *__restrict__ st_in = b.st_in[blockIdx.y];
-  T *__restrict__ out = b.out[blockIdx.y];
-  int32_t *__restrict__ st_out = b.st_out[blockIdx.y];
+__device__ __forceinline__ void drillup_tile_body(const T *__restrict__ in, const int32_t *__restrict__ st_in, T *__restrict__ out,
+                                                  int32_t *__restrict__ st_out, const DrillUpAxis &a, const DrillUpTile &tl) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   constexpr int V = 16 / sizeof(T);                       // cells per 16 B access
   constexpr uint32_t kCells = kTileBytes / sizeof(T);     // capacity of the staged tile
@@ -723,6 +720,38 @@ __global__ __launch_bounds__(kBlock) void drillup_tile_kernel(const Batch<T> b, 
     if (idx == 0) g_probe3(blockIdx.x);
   }
 }
+
+template <typename T, int METHOD, bool HAS_STATUS, bool FAST, int MODE>
+__global__ __launch_bounds__(kBlock) void drillup_tile_kernel(const Batch<T> b, const DrillUpAxis a, const DrillUpTile tl) {
+  drillup_tile_body<T, METHOD, HAS_STATUS, FAST, MODE>(b.in[blockIdx.y], b.st_in[blockIdx.y], b.out[blockIdx.y], b.st_out[blockIdx.y], a, tl);
+}
+
+// Measures with DIFFERENT rules in one launch, row-tile regime (see drillup_rows_mixed_kernel): small cubes rolled up
+// along an inner dimension, where a launch per rule is what costs.
+template <typename T, bool HAS_STATUS, int MODE>
+__global__ __launch_bounds__(kBlock) void drillup_tile_mixed_kernel(const Batch<T> b, const DrillUpAxis a, const DrillUpTile tl) {
+  const T *in = b.in[blockIdx.y];
+  const int32_t *st_in = b.st_in[blockIdx.y];
+  T *out = b.out[blockIdx.y];
+  int32_t *st_out = b.st_out[blockIdx.y];
+  const bool fast = !HAS_STATUS && !a.def_nan;
+  switch (b.method[blockIdx.y]) {
+    case OLAP_SUM:
+      if (fast) drillup_tile_body<T, OLAP_SUM, HAS_STATUS, !HAS_STATUS, MODE>(in, st_in, out, st_out, a, tl);
+      else drillup_tile_body<T, OLAP_SUM, HAS_STATUS, false, MODE>(in, st_in, out, st_out, a, tl);
+      break;
+    case OLAP_AVERAGE:
+      if (fast) drillup_tile_body<T, OLAP_AVERAGE, HAS_STATUS, !HAS_STATUS, MODE>(in, st_in, out, st_out, a, tl);
+      else drillup_tile_body<T, OLAP_AVERAGE, HAS_STATUS, false, MODE>(in, st_in, out, st_out, a, tl);
+      break;
+    case OLAP_HIGHEST: drillup_tile_body<T, OLAP_HIGHEST, HAS_STATUS, false, MODE>(in, st_in, out, st_out, a, tl); break;
+    case OLAP_LOWEST: drillup_tile_body<T, OLAP_LOWEST, HAS_STATUS, false, MODE>(in, st_in, out, st_out, a, tl); break;
+    case OLAP_FIRST: drillup_tile_body<T, OLAP_FIRST, HAS_STATUS, false, MODE>(in, st_in, out, st_out, a, tl); break;
+    case OLAP_LAST: drillup_tile_body<T, OLAP_LAST, HAS_STATUS, false, MODE>(in, st_in, out, st_out, a, tl); break;
+    default: drillup_tile_body<T, OLAP_PRODUCT, HAS_STATUS, false, MODE>(in, st_in, out, st_out, a, tl); break;
+  }
+}
+
 
 constexpr uint32_t kTotalBlocks = 4096;  // workgroups (and partial slots) of the store total
 constexpr uint32_t kGroupTileMaxGroups = 1024;  // groups per tile of the group-tile regime (LDS holds their bounds)
@@ -2747,8 +2776,9 @@ struct Launch {
   // the same roll-up over nb (<= kMaxBatch) buffer pairs in one launch; all with or all without a mask
   static hipError_t drillup_axis_batch(int method, bool has_status, int vec, const Batch<T> &b, unsigned nb, const DrillUpAxis &a,
                                        hipStream_t stream);
-  // pairs with DIFFERENT rules (b.method[]) in one launch: the row regime with full 16-byte lanes only — anything else
-  // returns hipErrorNotSupported and the caller launches rule by rule.  `deep`: some pair's rule wants 4 rows in flight.
+  // pairs with DIFFERENT rules (b.method[]) in one launch: the row regime (16-byte lanes, or 8-byte lanes of 4-byte cells)
+  // and the row-tile regime — anything else returns hipErrorNotSupported and the caller launches rule by rule.  `deep`:
+  // some pair's rule wants 4 rows in flight.
   static hipError_t drillup_rows_mixed(bool has_status, int vec, const Batch<T> &b, unsigned nb, const DrillUpAxis &a, bool deep,
                                        hipStream_t stream);
   static hipError_t drillup_reduce(int method, bool has_status, const T *in, const int32_t *st_in, T *out, int32_t *st_out,
@@ -2805,6 +2835,47 @@ inline unsigned grid_stride_for(uint64_t n) {
 
 #ifdef OLAP_KERNELS_IMPL
 
+// Whether the LDS row-tile regime takes this roll-up (small `inner`: short row pieces make the flat regime's accesses
+// waste much of every cache line; whole rows of K*inner cells staged per workgroup, kTileBytes of cells), and how.
+struct TileGeometry {
+  DrillUpTile tl{};
+  uint64_t tiles = 0;
+  size_t lds = 0;
+  int mode = 0;  // table mode of drillup_tile_kernel
+};
+template <typename T>
+static bool tile_geometry(const DrillUpAxis &a, bool has_status, TileGeometry *out) {
+  const bool contig = a.order == nullptr;
+  const uint64_t row_elems = a.K * a.inner;
+  const uint64_t budget = kTileBytes / sizeof(T);
+  constexpr uint64_t V = 16 / sizeof(T);
+  static const bool no_permute = getenv("OLAP_TILE_NO_PERMUTE") != nullptr;
+  // interleaved groups: cells permuted into group order while they are staged (MODE 3, tables from the plan)
+  const bool permute = !contig && a.perm_cell && !no_permute;
+  const uint64_t csr_bytes = permute ? 2 * a.G * 4 : (a.G + 1 + (contig ? 0 : a.K)) * 4;
+  // rows per tile: as many as fit; every tile must start 16 B aligned, i.e. R*row_elems % V == 0
+  const uint64_t R = tile_rows_for(row_elems, permute ? (uint64_t)a.perm_pitch * a.inner : row_elems, budget, V);
+  uint64_t tile_max_inner = 128;  // tools/sweep3.py: the LDS form wins up to ~100 cells per row piece
+  if (const char *e = getenv("OLAP_TILE_MAX_INNER")) tile_max_inner = (uint64_t)atoll(e);
+  if (!(a.aligned16 && a.inner < tile_max_inner && R > 0 && csr_bytes <= 16 * 1024 && a.G * a.inner <= 0xFFFFFFFFull)) return false;
+  DrillUpTile &tl = out->tl;
+  tl.rows_per_tile = (uint32_t)R;
+  tl.row_elems = (uint32_t)row_elems;
+  tl.out_row = (uint32_t)(a.G * a.inner);
+  tl.inner = (uint32_t)a.inner;
+  if (permute) {
+    tl.perm_cell = a.perm_cell;
+    tl.perm_grp = a.perm_grp;
+    tl.pitch_cells = (uint32_t)(a.perm_pitch * a.inner);
+    if (!small_div_for(row_elems, budget, &tl.by_row)) return false;  // (row_elems <= 4096: always exact)
+  }
+  out->tiles = (a.outer + tl.rows_per_tile - 1) / tl.rows_per_tile;
+  const bool all = contig && a.G == 1;
+  out->lds = kTileBytes + (has_status ? budget * 4 : 0) + (all ? 0 : csr_bytes);
+  out->mode = all ? 1 : contig ? 2 : permute ? 3 : 0;
+  return out->tiles < 0x7FFFFFFFull;
+}
+
 // Row regime when a row of VEC-slots fills at least one wavefront-sized piece of a workgroup
 // reasonably (>= 128 slots); otherwise the flat regime.  FAST = additive method, zero default, no
 // mask read.  The grid of the row regime is outer*G*blocks_per_row workgroups.
@@ -2839,32 +2910,12 @@ static hipError_t drillup_axis_launch(const Batch<T> &b, unsigned nb, const Dril
   if (!rows) {
     // LDS tile regime for small `inner` (short row pieces make the flat regime's accesses waste much
     // of every cache line): whole rows of K*inner cells staged per workgroup, kTileBytes of cells
-    const uint64_t row_elems = a.K * a.inner;
-    const uint64_t budget = kTileBytes / sizeof(T);
-    constexpr uint64_t V = 16 / sizeof(T);
-    static const bool no_permute = getenv("OLAP_TILE_NO_PERMUTE") != nullptr;
-    // interleaved groups: cells permuted into group order while they are staged (MODE 3, tables from the plan)
-    const bool permute = !contig && a.perm_cell && !no_permute;
-    const uint64_t csr_bytes = permute ? 2 * a.G * 4 : (a.G + 1 + (contig ? 0 : a.K)) * 4;
-    // rows per tile: as many as fit; every tile must start 16 B aligned, i.e. R*row_elems % V == 0
-    const uint64_t R = tile_rows_for(row_elems, permute ? (uint64_t)a.perm_pitch * a.inner : row_elems, budget, V);
-    uint64_t tile_max_inner = 128;  // tools/sweep3.py: the LDS form wins up to ~100 cells per row piece
-    if (const char *e = getenv("OLAP_TILE_MAX_INNER")) tile_max_inner = (uint64_t)atoll(e);
-    if (a.aligned16 && a.inner < tile_max_inner && R > 0 && csr_bytes <= 16 * 1024 && a.G * a.inner <= 0xFFFFFFFFull) {
-      DrillUpTile tl{};
-      tl.rows_per_tile = (uint32_t)R;
-      tl.row_elems = (uint32_t)row_elems;
-      tl.out_row = (uint32_t)(a.G * a.inner);
-      tl.inner = (uint32_t)a.inner;
-      if (permute) {
-        tl.perm_cell = a.perm_cell;
-        tl.perm_grp = a.perm_grp;
-        tl.pitch_cells = (uint32_t)(a.perm_pitch * a.inner);
-        if (!small_div_for(row_elems, budget, &tl.by_row)) return hipErrorInvalidValue;  // (row_elems <= 4096: always exact)
-      }
-      const uint64_t tiles = (a.outer + tl.rows_per_tile - 1) / tl.rows_per_tile;
-      const bool all = contig && a.G == 1;
-      const size_t lds = kTileBytes + (HS ? budget * 4 : 0) + (all ? 0 : csr_bytes);
+    TileGeometry tg;
+    if (tile_geometry<T>(a, HS, &tg)) {
+      const DrillUpTile &tl = tg.tl;
+      const uint64_t tiles = tg.tiles;
+      const size_t lds = tg.lds;
+      const bool all = tg.mode == 1, permute = tg.mode == 3;
       if (tiles < 0x7FFFFFFFull) {
 #define OLAP_TILE(F, M) hipLaunchKernelGGL((drillup_tile_kernel<T, METHOD, HS, F, M>), dim3((unsigned)tiles, nb), kBlock, lds, stream, b, a, tl)
         if constexpr (kAdditive && !HS) {
@@ -3034,7 +3085,30 @@ hipError_t Launch<T>::drillup_rows_mixed(bool has_status, int vec, const Batch<T
   if (a.total == 0 || nb == 0) return hipSuccess;
   // the row regime with 16-byte lanes, or 8-byte lanes of 4-byte cells (rows of an even number of cells: config 5's
   // [120,100,274] -> country); single cells per lane and the other regimes go rule by rule
-  if (!a.aligned16 || a.n_vec < 128) return hipErrorNotSupported;
+  if (!a.aligned16) return hipErrorNotSupported;
+  if (a.n_vec < 128) {  // not the row regime: the row-tile regime takes mixed rules too, the others do not
+    TileGeometry tg;
+    if (!tile_geometry<T>(a, has_status, &tg)) return hipErrorNotSupported;
+    const dim3 grid((unsigned)tg.tiles, nb);
+#define OLAP_TILE_MIXED(HS, M) hipLaunchKernelGGL((drillup_tile_mixed_kernel<T, HS, M>), grid, kBlock, tg.lds, stream, b, a, tg.tl)
+    if (has_status) {
+      switch (tg.mode) {
+        case 1: OLAP_TILE_MIXED(true, 1); break;
+        case 2: OLAP_TILE_MIXED(true, 2); break;
+        case 3: OLAP_TILE_MIXED(true, 3); break;
+        default: OLAP_TILE_MIXED(true, 0); break;
+      }
+    } else {
+      switch (tg.mode) {
+        case 1: OLAP_TILE_MIXED(false, 1); break;
+        case 2: OLAP_TILE_MIXED(false, 2); break;
+        case 3: OLAP_TILE_MIXED(false, 3); break;
+        default: OLAP_TILE_MIXED(false, 0); break;
+      }
+    }
+#undef OLAP_TILE_MIXED
+    return hipGetLastError();
+  }
   if (vec == FULL) return drillup_rows_mixed_vec<T, FULL>(has_status, b, nb, a, deep, stream);
   if constexpr (FULL == 4) {
     if (vec == 2) return drillup_rows_mixed_vec<T, 2>(has_status, b, nb, a, deep, stream);

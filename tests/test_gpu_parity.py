@@ -1338,13 +1338,17 @@ RULES = ["sum", "average", "highest", "lowest", "first", "last", "product"]
     ([12, 31, 520], 1, "contiguous"),     # row regime, four rows in flight
     ([20, 100, 274], 1, "contiguous"),    # rows of an even number of cells: 8-byte lanes (config 5's city -> country)
     ([9, 30, 1027], 1, "interleaved"),    # ragged rows: rule by rule
-    ([300, 100, 3], 1, "interleaved"),    # row tile: rule by rule
+    ([300, 100, 3], 1, "interleaved"),    # row tile, permuted groups: one mixed-rule launch (drillup_tile_mixed_kernel)
+    ([200, 60, 7], 1, "contiguous"),      # row tile, contiguous groups
+    ([500, 12, 9], 1, "all"),             # row tile, one group
+    ([40, 30, 200], 1, "contiguous"),     # flat regime: rule by rule
     ([2, 5000, 2], 1, "all"),             # reduce regime: rule by rule
 ])
 @pytest.mark.parametrize("n", [2, 4, 9])
 def test_drillup_multi_rules_matches_single(lens, axis, kind, type_name, default, n):
-    """olap_store_drillup_multi: n measures with a rule EACH in one call — one mixed-rule launch in the row regime
-    (drillup_rows_mixed_kernel), one launch per rule elsewhere — give exactly the stores n single calls give."""
+    """olap_store_drillup_multi: n measures with a rule EACH in one call — one mixed-rule launch in the row and row-tile
+    regimes (drillup_rows_mixed_kernel, drillup_tile_mixed_kernel), one launch per rule elsewhere — give exactly the
+    stores n single calls give."""
     rng = np.random.default_rng(sum(lens) * 13 + n)
     K = lens[axis]
     amap = {"all": np.zeros(K), "interleaved": np.arange(K) % 7, "contiguous": np.arange(K) // 4}[kind].astype(np.uint32)
