@@ -54,3 +54,27 @@ time('4^10 dice(dimension2, 2 of 4)      [test/cube-benchmark.js:83]', () => sma
 time('4^10 dice(...).getData() -> plain Array of 524288 numbers     ', () => small.dice('dimension2', 'root', ['dimension2-item2', 'dimension2-item3']).getData('measure0').length, 20);
 time('4^10 collapse()                    [test/cube-benchmark.js:59]', () => small.collapse(), 50);
 time('4^10 reorderDimensions(reverse)    [test/cube-benchmark.js:71]', () => small.reorderDimensions(small.dimensionIds.slice().reverse()), 50);
+
+// four stored measures with four rules on a 10^6-cell cube: Cube.drillUp hands them to the device together
+// (HipStore.drillUpMany -> olap_store_drillup_multi: one mixed-rule launch); per-measure store calls for comparison
+{
+  const dims = [];
+  for (let i = 0; i < 6; ++i) dims.push(new GenericDimension(`dimension${i}`, 'root', Array.from({ length: 10 }, (_x, j) => `dimension${i}-item${j}`)));
+  const multi = new Cube(dims);
+  const rules = ['sum', 'average', 'highest', 'lowest'];
+  rules.forEach((rule, m) => {
+    multi.createStoredMeasure(`measure${m}`, Object.fromEntries(dims.map((d) => [d.id, rule])), 'float32', 0);
+    multi.fillData(`measure${m}`, m + 1);
+  });
+  for (const dim of ['dimension0', 'dimension3']) {
+    time(`10^6 cells x 4 measures / 4 rules: cube.drillUp(${dim}, all)`, () => multi.drillUp(dim, 'all'), 200);
+    const rolled = multi.drillUp(dim, 'all');
+    time(`   the same as 4 store.drillUp calls (one launch each)`, () => {
+      let last;
+      rules.forEach((rule, m) => {
+        last = multi.storedMeasures[`measure${m}`].drillUp(multi.dimensions, rolled.dimensions, rule);
+      });
+      return last.getValue(0);
+    }, 200);
+  }
+}
