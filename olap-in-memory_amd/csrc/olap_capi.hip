@@ -1479,9 +1479,12 @@ extern "C" int olap_drilldown_plan(olap_plan **out, int dtype, int default_kind,
 // ---- run ------------------------------------------------------------------------------------
 static bool aligned16(const void *p) { return ((uintptr_t)p & 15u) == 0; }
 
+// `rule` >= 0: the drillUp rule to run with instead of the one the plan was built for (a drillUp plan's tables do not
+// depend on it; nothing in the plan is written, so a cached plan stays shareable)
 template <typename T>
 static int run_typed(olap_plan *p, const void *in_v, const int32_t *in_s, void *out_v, int32_t *out_s,
-                     hipStream_t stream) {
+                     hipStream_t stream, int rule = -1) {
+  const int drillup_method = rule >= 0 ? rule : p->method;
   const T *in = (const T *)in_v;
   T *out = (T *)out_v;
   const bool hs = in_s != nullptr;
@@ -1502,14 +1505,14 @@ static int run_typed(olap_plan *p, const void *in_v, const int32_t *in_s, void *
       a.blocks_per_row = (a.n_vec + kBlock - 1) / kBlock;
       { const char *x = getenv("OLAP_XCD_ORDER"); a.xcd_order = x ? atoi(x) : 1; }  // 0: A/B against the dispatch order
       if (p->reduce.S > 0) {
-        e = Launch<T>::drillup_reduce(p->method, hs, in, in_s, out, out_s, a, p->reduce, stream);
+        e = Launch<T>::drillup_reduce(drillup_method, hs, in, in_s, out, out_s, a, p->reduce, stream);
         break;
       }
-      e = Launch<T>::drillup_axis(p->method, hs, vec, in, in_s, out, out_s, a, stream);
+      e = Launch<T>::drillup_axis(drillup_method, hs, vec, in, in_s, out, out_s, a, stream);
       break;
     }
     case PLAN_DRILLUP_GENERIC:
-      e = Launch<T>::drillup_generic(p->method, hs, in, in_s, out, out_s, p->gen, stream);
+      e = Launch<T>::drillup_generic(drillup_method, hs, in, in_s, out, out_s, p->gen, stream);
       break;
     case PLAN_GATHER: {
       if (p->dice_direct && aligned16(out) && (!out_s || aligned16(out_s))) {
@@ -1583,8 +1586,8 @@ static int run_typed(olap_plan *p, const void *in_v, const int32_t *in_s, void *
   return OLAP_OK;
 }
 
-extern "C" int olap_plan_run(olap_plan *p, const void *in_values, const int32_t *in_status,
-                             void *out_values, int32_t *out_status, void *stream) {
+static int plan_run_rule(olap_plan *p, const void *in_values, const int32_t *in_status, void *out_values, int32_t *out_status, void *stream,
+                         int rule) {
   if (!p) return fail(OLAP_ERR_INVALID_ARGUMENT, "plan is NULL");
   if (plan_dry()) return fail(OLAP_ERR_NO_DEVICE, "OLAP_PLAN_DRY is set: plans are built for inspection only; libolapgpu has no CPU fallback");
   if ((p->in_cells && !in_values) || (p->out_cells && !out_values))
@@ -1598,11 +1601,16 @@ extern "C" int olap_plan_run(olap_plan *p, const void *in_values, const int32_t 
   p->last_stream = s;
   p->ran = true;
   switch (p->dtype) {
-    case OLAP_INT32: return run_typed<int32_t>(p, in_values, in_status, out_values, out_status, s);
-    case OLAP_UINT32: return run_typed<uint32_t>(p, in_values, in_status, out_values, out_status, s);
-    case OLAP_FLOAT32: return run_typed<float>(p, in_values, in_status, out_values, out_status, s);
-    default: return run_typed<double>(p, in_values, in_status, out_values, out_status, s);
+    case OLAP_INT32: return run_typed<int32_t>(p, in_values, in_status, out_values, out_status, s, rule);
+    case OLAP_UINT32: return run_typed<uint32_t>(p, in_values, in_status, out_values, out_status, s, rule);
+    case OLAP_FLOAT32: return run_typed<float>(p, in_values, in_status, out_values, out_status, s, rule);
+    default: return run_typed<double>(p, in_values, in_status, out_values, out_status, s, rule);
   }
+}
+
+extern "C" int olap_plan_run(olap_plan *p, const void *in_values, const int32_t *in_status,
+                             void *out_values, int32_t *out_status, void *stream) {
+  return plan_run_rule(p, in_values, in_status, out_values, out_status, stream, -1);
 }
 
 // One launch for several measures (Batch<T>): drillUp plans of one axis outside the cooperative reduce regime (whose
@@ -1708,13 +1716,9 @@ extern "C" int olap_plan_run_batch_rules(olap_plan *p, int n, const int *methods
     if (rc != OLAP_MIXED_NOT_APPLICABLE) return rc;
   }
   // pair by pair: a drillUp plan's tables do not depend on the rule
-  const int planned = p->method;
   int rc = OLAP_OK;
-  for (int i = 0; i < n && !rc; ++i) {
-    p->method = methods[i];
-    rc = olap_plan_run(p, in_values[i], in_status ? in_status[i] : nullptr, out_values[i], out_status ? out_status[i] : nullptr, stream);
-  }
-  p->method = planned;
+  for (int i = 0; i < n && !rc; ++i)
+    rc = plan_run_rule(p, in_values[i], in_status ? in_status[i] : nullptr, out_values[i], out_status ? out_status[i] : nullptr, stream, methods[i]);
   return rc;
 }
 

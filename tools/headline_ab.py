@@ -18,7 +18,7 @@ from olap_in_memory_amd.sharded import HipEngine  # noqa: E402
 
 eng = HipEngine("cuda:0")
 L = pkg.lib()
-tag = "prev" if ".old_tree" in ROOT else "this"
+tag = "prev" if os.environ.get("OLAP_LIBOLAPGPU") else "this"
 
 
 def run(name, lens, axis, amap, method="sum", iters=300):
