@@ -653,44 +653,6 @@ static napi_value EvalFormula(napi_env env, napi_callback_info info) {
   return ta;
 }
 
-// drillUpBatch(stores: Store[], oldLen, newLen, maps, methodCode) -> Store[]
-// The stored measures of a cube that share a rule: one plan, one launch (olap_store_drillup_batch) instead of the
-// per-measure loop of /root/reference/src/cube.js:1012-1020.
-static napi_value DrillUpBatch(napi_env env, napi_callback_info info) {
-  size_t argc = 5;
-  napi_value argv[5];
-  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
-  OpArgs a;
-  int32_t method = 0;
-  bool is_arr = false;
-  if (argc >= 1) napi_is_array(env, argv[0], &is_arr);
-  if (argc < 5 || !is_arr || !a.decode(env, argv[1], argv[2], argv[3]) || napi_get_value_int32(env, argv[4], &method) != napi_ok)
-    return bad_args(env, "drillUpBatch(stores: Store[], oldLen: Uint32Array, newLen: Uint32Array, maps: Uint32Array[], method: number)");
-  uint32_t n = 0;
-  napi_get_array_length(env, argv[0], &n);
-  std::vector<const olap_store *> stores(n);
-  for (uint32_t i = 0; i < n; ++i) {
-    napi_value e;
-    NAPI_OK(napi_get_element(env, argv[0], i, &e));
-    stores[i] = unwrap(env, e);
-    if (!stores[i]) return nullptr;
-  }
-  std::vector<olap_store *> outs(n, nullptr);
-  int rc = olap_store_drillup_batch((int)n, stores.data(), outs.data(), (int)a.a_len.size(), a.a_len.data(), a.b_len.data(), a.ptrs.data(), method);
-  if (rc) return throw_olap(env, rc);
-  napi_value arr;
-  NAPI_OK(napi_create_array_with_length(env, n, &arr));
-  for (uint32_t i = 0; i < n; ++i) {
-    napi_value w = wrap_new_store(env, outs[i]);
-    if (!w) {
-      for (uint32_t j = i + 1; j < n; ++j) olap_store_destroy(outs[j]);
-      return nullptr;
-    }
-    napi_set_element(env, arr, i, w);
-  }
-  return arr;
-}
-
 // drillUpMulti(stores: Store[], methods: Int32Array, oldLen, newLen, maps) -> Store[]
 // Every stored measure of a cube with its own rule for the rolled-up dimension (olap_store_drillup_multi): one
 // mixed-rule launch where the roll-up allows it, one launch per rule otherwise.
@@ -1247,7 +1209,6 @@ static napi_value Init(napi_env env, napi_value exports) {
       {"shardStore", nullptr, ShardStore, nullptr, nullptr, nullptr, napi_default, nullptr},
       {"evalFormulaSharded", nullptr, EvalFormulaSharded, nullptr, nullptr, nullptr, napi_default, nullptr},
       {"evalFormula", nullptr, EvalFormula, nullptr, nullptr, nullptr, napi_default, nullptr},
-      {"drillUpBatch", nullptr, DrillUpBatch, nullptr, nullptr, nullptr, napi_default, nullptr},
       {"drillUpMulti", nullptr, DrillUpMulti, nullptr, nullptr, nullptr, napi_default, nullptr},
       {"storeFromSparse", nullptr, StoreFromSparse, nullptr, nullptr, nullptr, napi_default, nullptr},
       {"methodFromName", nullptr, MethodFromName, nullptr, nullptr, nullptr, napi_default, nullptr},
