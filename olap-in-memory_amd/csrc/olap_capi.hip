@@ -480,8 +480,28 @@ extern "C" int olap_drillup_plan(olap_plan **out, int dtype, int default_kind, i
         uint64_t S;
         if (a.inner <= 128) {
           const uint64_t groups = a.outer * a.G;
-          // measured (tools/sweep2.py): more, shorter segments lose to the per-unit epilogue, fewer leave CUs idle
-          const uint64_t by_grid = (4096 + groups - 1) / groups;                              // >= ~4 K units
+          // Segments per group.  More, shorter segments lose to the per-unit epilogue and to the partials they write
+          // and the merge reads back ([1e6,100] -> [1,100] with 4 096 units: 81 us; with 512: 65 us); fewer leave CUs
+          // idle.  Workgroup-sized units are few enough to be resident all at once, so what matters is that every CU gets
+          // the same number: k per CU for the smallest k in 2..8 that the groups fill to >= 94 % (1 per CU is slower:
+          // 84-100 us); with more groups than that the dispatcher balances ~4 K units by itself (tools/reduce_units.py).
+          uint64_t by_grid = (4096 + groups - 1) / groups;
+          if (const char *e = getenv("OLAP_REDUCE_UNITS")) {
+            by_grid = std::max<uint64_t>(1, (uint64_t)atoll(e) / groups);
+          } else {
+            int cus = 256;
+            if (!plan_dry()) {
+              int dev = 0, n = 0;
+              if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) cus = n;
+            }
+            for (uint64_t k = 2; k <= 8; ++k) {
+              const uint64_t total = (uint64_t)cus * k, s_k = total / groups;
+              if (s_k >= 1 && groups * s_k * 100 >= total * 94) {
+                by_grid = s_k;
+                break;
+              }
+            }
+          }
           const uint64_t by_work = std::max<uint64_t>(1, (uint64_t)longest * a.inner / 8192);  // >= 8 K cells each
           S = std::max<uint64_t>(1, std::min(by_grid, by_work));
           // short segments: a wavefront per segment; long ones: the whole workgroup
