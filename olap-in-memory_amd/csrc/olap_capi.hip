@@ -536,9 +536,28 @@ extern "C" int olap_drillup_plan(olap_plan **out, int dtype, int default_kind, i
           rd.rows = 0;
           rd.unit = kBlock;
           S = std::max<uint64_t>(1, std::min<uint64_t>((524288 + cells - 1) / cells, longest / 32));
+          // 16-byte lanes (drillup_split4_kernel): four output cells per lane; as many segments as give every CU the same
+          // number of workgroups (k per CU, smallest k in 2..8 filled to >= 94 %), each of at least 32 members
+          if (olap_dtype_size(dtype) == 4 && a.inner % 4 == 0 && !getenv("OLAP_NO_SPLIT4")) {
+            rd.vec4 = 1;
+            int cus = 256;
+            if (!plan_dry()) {
+              int dev = 0, n = 0;
+              if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) cus = n;
+            }
+            const uint64_t lanes_per_seg = cells / 4;
+            uint64_t s_bal = 0;
+            for (uint64_t k = 2; k <= 8 && !s_bal; ++k) {
+              const uint64_t total = (uint64_t)cus * k * kBlock, s_k = total / lanes_per_seg;
+              if (s_k >= 1 && lanes_per_seg * s_k * 100 >= total * 94) s_bal = s_k;
+            }
+            if (!s_bal) s_bal = std::max<uint64_t>(1, (uint64_t)cus * 8 * kBlock / lanes_per_seg);
+            if (const char *e = getenv("OLAP_SPLIT_K")) s_bal = std::max<uint64_t>(1, (uint64_t)cus * (uint64_t)atoll(e) * kBlock / lanes_per_seg);  // developer knob: workgroups per CU
+            S = std::max<uint64_t>(1, std::min<uint64_t>(s_bal, longest / 32));
+          }
         }
         rd.S = (uint32_t)S;
-        if (!rd.vec4) rd.seg_len = (uint32_t)((longest + S - 1) / S);
+        if (!rd.vec4 || rd.rows == 0) rd.seg_len = (uint32_t)((longest + S - 1) / S);
         hipError_t e = dev_alloc(&p->dev_tmp, cells * S * sizeof(Partial));
         if (e != hipSuccess) {
           olap_plan_destroy(p);
@@ -548,9 +567,9 @@ extern "C" int olap_drillup_plan(olap_plan **out, int dtype, int default_kind, i
       }
     }
     if (p->reduce.S > 0)
-      p->kernel_name = p->reduce.vec4   ? (p->reduce.S == 1 ? "drillup_reduce4_kernel" : "drillup_reduce4_kernel+drillup_merge_kernel")
-                       : p->reduce.rows ? "drillup_reduce_kernel+drillup_merge_kernel"
-                                        : "drillup_split_kernel+drillup_merge_kernel";
+      p->kernel_name = p->reduce.rows == 0 ? (p->reduce.vec4 ? "drillup_split4_kernel+drillup_merge_kernel" : "drillup_split_kernel+drillup_merge_kernel")
+                       : p->reduce.vec4    ? (p->reduce.S == 1 ? "drillup_reduce4_kernel" : "drillup_reduce4_kernel+drillup_merge_kernel")
+                                           : "drillup_reduce_kernel+drillup_merge_kernel";
     else if (a.inner / (uint64_t)p->vec >= 128) p->kernel_name = "drillup_rows_kernel";
     else if (gtile_ok) p->kernel_name = "drillup_gtile_kernel";
     else if (a.inner < 128 && a.K * a.inner <= (16 * 1024) / olap_dtype_size(dtype) && a.K * a.inner > 0 &&

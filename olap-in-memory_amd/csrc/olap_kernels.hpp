@@ -345,7 +345,8 @@ __global__ __launch_bounds__(kBlock) void drillup_flat_kernel(const Batch<T> b, 
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       // (cached loads: with short row pieces neighbouring outputs share lines — streaming loads
-      // took [3001,3333,10] from 89 to 159 us)
+      // took [3001,3333,10] from 89 to 159 us.  A 32-bit `member * inner` where rows are short enough, instead of
+      // the 64-bit vector multiply, was measured and is slower here: 75.5 -> 81 us, 85.5 -> 94.4 us.)
       v[u] = load_vec<T, VEC>(base + k[u] * a.inner);
       if constexpr (HAS_STATUS) s[u] = load_vec<int32_t, VEC>(sbase + k[u] * a.inner);
     }
@@ -1305,6 +1306,8 @@ __global__ __launch_bounds__(kBlock) void drillup_split_kernel(const T *__restri
   const uint32_t jend = (uint64_t)j + rd.seg_len < gend ? j + rd.seg_len : gend;
   Partial p = partial_identity<METHOD>();
   constexpr int U = 8;
+  const bool contig = a.order == nullptr;
+  uint64_t at = (uint64_t)j * a.inner;  // (no 64-bit vector multiply per load: see drillup_split4_kernel)
   for (; j < jend; j += U) {
     const uint32_t n = (jend - j) < (uint32_t)U ? (jend - j) : (uint32_t)U;
     T x[U];
@@ -1312,10 +1315,11 @@ __global__ __launch_bounds__(kBlock) void drillup_split_kernel(const T *__restri
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const uint32_t jj = (uint32_t)u < n ? j + u : j;
-      const uint64_t k = a.order ? (uint64_t)a.order[jj] : (uint64_t)jj;
-      x[u] = base[k * a.inner];
-      sx[u] = HAS_STATUS ? sbase[k * a.inner] : OLAP_STATUS_SET;
+      const uint64_t off = contig ? at + ((uint32_t)u < n ? (uint64_t)u * a.inner : 0ull) : (uint64_t)a.order[jj] * a.inner;
+      x[u] = base[off];
+      sx[u] = HAS_STATUS ? sbase[off] : OLAP_STATUS_SET;
     }
+    at += (uint64_t)U * a.inner;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       if constexpr (FAST) {
@@ -1332,6 +1336,72 @@ __global__ __launch_bounds__(kBlock) void drillup_split_kernel(const T *__restri
 }
 
 // One wavefront per output cell merges its S partial states (segments are ascending member ranges).
+// The same with 16-byte lanes (4-byte cells, inner a multiple of 4, aligned buffers): a lane owns FOUR adjacent output
+// cells of one (outer, group, segment) and streams its segment's rows with non-temporal 16-byte loads, four in flight.
+// The scalar form above moves 4 bytes per lane with cached loads: [1e4,1e4] -> [1,1e4] 185 us (0.27), [1e5,1000] ->
+// [1,1000] 128 us (0.39); this one: see DESIGN.md K1r.
+template <typename T, int METHOD, bool HAS_STATUS, bool FAST>
+__global__ __launch_bounds__(kBlock) void drillup_split4_kernel(const T *__restrict__ in, const int32_t *__restrict__ st_in,
+                                                                const DrillUpAxis a, const DrillUpReduce rd) {
+  const uint64_t t = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  const uint64_t n_vec = a.inner / 4;
+  const uint64_t groups = a.outer * a.G;
+  if (t >= groups * n_vec * rd.S) return;
+  const uint64_t iv = t % n_vec;
+  const uint32_t seg = (uint32_t)((t / n_vec) % rd.S);
+  const uint64_t og = t / (n_vec * rd.S);
+  const uint64_t g = og % a.G, o = og / a.G;
+  const bool def_nan = a.def_nan != 0;
+  const T *base = in + (o * a.K) * a.inner + iv * 4;
+  const int32_t *sbase = HAS_STATUS ? st_in + (o * a.K) * a.inner + iv * 4 : nullptr;
+  const uint32_t gend = a.gstart[g + 1];
+  const uint64_t s0 = (uint64_t)a.gstart[g] + (uint64_t)seg * rd.seg_len;
+  uint32_t j = s0 < gend ? (uint32_t)s0 : gend;
+  const uint32_t jend = (uint64_t)j + rd.seg_len < gend ? j + rd.seg_len : gend;
+  Partial p[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) p[e] = partial_identity<METHOD>();
+  constexpr int U = 4;
+  // (a lane's segment is its own, so its row index lives in a vector register: `row * inner` per load is a 64-bit
+  // VECTOR multiply — quarter-rate instructions on every load's critical path with a handful of waves per SIMD.  With
+  // contiguous groups the rows of a segment are consecutive: one multiply per lane, then additions of u * inner, which
+  // is wave-uniform.)
+  const bool contig = a.order == nullptr;
+  uint64_t at = (uint64_t)j * a.inner;  // contiguous groups: first cell of row j
+  for (; j < jend; j += U) {
+    const uint32_t n = (jend - j) < (uint32_t)U ? (jend - j) : (uint32_t)U;
+    Vec<T, 4> x[U];
+    Vec<int32_t, 4> sx[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint32_t jj = (uint32_t)u < n ? j + u : j;  // clamp: re-reads a valid row, result unused
+      const uint64_t off = contig ? at + ((uint32_t)u < n ? (uint64_t)u * a.inner : 0ull) : (uint64_t)a.order[jj] * a.inner;
+      x[u] = load_stream<T, 4>(base + off);
+      if constexpr (HAS_STATUS) sx[u] = load_stream<int32_t, 4>(sbase + off);
+    }
+    at += (uint64_t)U * a.inner;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if constexpr (FAST) {
+          const double v = (uint32_t)u < n ? Cell<T>::to_f64(x[u].v[e]) : 0.0;
+          p[e].acc += v;
+          p[e].meta += (v != 0.0) ? 1u : 0u;
+        } else {
+          const int32_t st = HAS_STATUS ? sx[u].v[e] : OLAP_STATUS_SET;
+          if ((uint32_t)u < n && cell_is_set<T>(x[u].v[e], st, HAS_STATUS, def_nan)) partial_add<METHOD>(p[e], Cell<T>::to_f64(x[u].v[e]), j + u, def_nan);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    if constexpr (FAST) p[e].meta = (p[e].meta & 0x7FFFFFFFu) | ((p[e].meta != 0 && p[e].acc != 0.0) ? 0x80000000u : 0u);
+    rd.part[((o * a.G + g) * a.inner + iv * 4 + e) * rd.S + seg] = p[e];
+  }
+}
+
 template <typename T, int METHOD>
 __global__ __launch_bounds__(kBlock) void drillup_merge_kernel(T *__restrict__ out, int32_t *__restrict__ st_out,
                                                                const DrillUpAxis a, const DrillUpReduce rd) {
@@ -3141,6 +3211,11 @@ static hipError_t drillup_reduce_launch(bool has_status, const T *in, const int3
       else if (kAdditive && fast) hipLaunchKernelGGL((drillup_reduce_kernel<T, METHOD, false, kAdditive>), grid, kBlock, 0, stream, in, st_in, a, r1);
       else hipLaunchKernelGGL((drillup_reduce_kernel<T, METHOD, false, false>), grid, kBlock, 0, stream, in, st_in, a, r1);
     }
+  } else if (rd.vec4 && a.aligned16 && sizeof(T) == 4 && a.inner % 4 == 0) {  // 16-byte lanes
+    const unsigned grid = grid_for(cells / 4 * rd.S);
+    if (has_status) hipLaunchKernelGGL((drillup_split4_kernel<T, METHOD, true, false>), grid, kBlock, 0, stream, in, st_in, a, rd);
+    else if (kAdditive && fast) hipLaunchKernelGGL((drillup_split4_kernel<T, METHOD, false, kAdditive>), grid, kBlock, 0, stream, in, st_in, a, rd);
+    else hipLaunchKernelGGL((drillup_split4_kernel<T, METHOD, false, false>), grid, kBlock, 0, stream, in, st_in, a, rd);
   } else {
     const unsigned grid = grid_for(cells * rd.S);
     if (has_status) hipLaunchKernelGGL((drillup_split_kernel<T, METHOD, true, false>), grid, kBlock, 0, stream, in, st_in, a, rd);

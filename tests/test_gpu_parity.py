@@ -1420,3 +1420,48 @@ def test_drillup_multi_mixed_stores_and_plan_level():
         for i in range(len(srcs)):
             assert same_typed(outs_t[i][off:off + n_out].cpu().numpy(), want[i].get_data()), (off, rules[i])
             assert np.array_equal(sts[i][off:off + n_out].cpu().numpy(), want[i].get_status()), (off, rules[i])
+
+
+@pytest.mark.parametrize("method", ["sum", "average", "highest", "first", "last", "product"])
+@pytest.mark.parametrize("type_name,default", [("float32", 0.0), ("float32", float("nan")), ("int32", 0.0), ("uint32", float("nan")), ("float64", 0.0)])
+@pytest.mark.parametrize("lens,axis,kind", [([3000, 132], 0, "all"), ([2, 1500, 256], 1, "all"), ([2600, 200], 0, "halves"), ([3, 900, 516], 1, "interleaved"),
+                                            ([2100, 250], 0, "all")])
+def test_split_regime_wide_rows(lens, axis, kind, type_name, default, method):
+    """Few output cells, long groups, rows wider than 128 cells: segments of every group are streamed by lanes that own
+    four adjacent output cells (drillup_split4_kernel: 4-byte cells, rows of a multiple of 4 cells) or one
+    (drillup_split_kernel), then merged.  Contiguous groups take incremental addressing, interleaved ones the member list."""
+    rng = np.random.default_rng(sum(lens) + len(method))
+    K = lens[axis]
+    amap = {"all": np.zeros(K), "halves": (np.arange(K) >= K // 3).astype(int), "interleaved": np.arange(K) % 3}[kind].astype(np.uint32)
+    new = list(lens)
+    new[axis] = int(amap.max()) + 1
+    maps = [amap if d == axis else np.arange(l, dtype=np.uint32) for d, l in enumerate(lens)]
+    n = int(np.prod(lens))
+    if method == "product":
+        vals = np.where(rng.random(n) < 0.5, 1.0, -1.0) * np.where(rng.random(n) < 0.004, 2.0, 1.0)
+        if type_name == "uint32":
+            vals = np.abs(vals)
+    else:
+        vals = rng.integers(0 if type_name == "uint32" else -40, 41, size=n).astype(np.float64)
+        if type_name.startswith("float"):
+            vals = vals * 0.25
+    dense = np.where(rng.random(n) < 0.3, default, vals)
+    plan = pkg.Plan.drillup(type_name, default, method, lens, new, maps)
+    assert "split" in plan.kernel_name, plan.kernel_name
+    if type_name != "float64" and lens[-1] % 4 == 0:
+        assert "split4" in plan.kernel_name, plan.kernel_name
+    o = OracleStore(n, type_name, default)
+    typed = to_typed(dense, type_name).astype(np.float64)
+    if type_name in ("int32", "uint32") and default != default:
+        typed = np.where(np.isnan(dense), np.nan, typed)
+    o.set_data(typed)
+    ev, es = expected_typed(o.drill_up(lens, new, maps, method))
+    g = pkg.HipStore(n, type_name, default)
+    g.set_data_f64(dense)
+    out = g.drill_up(lens, new, maps, method)
+    assert np.array_equal(out.get_status(), es)
+    gv = out.get_data()
+    if type_name == "float64" and method in ("sum", "average", "product"):
+        assert np.allclose(gv, ev, rtol=1e-12, atol=0, equal_nan=True)
+    else:
+        assert same_typed(gv, ev)
