@@ -56,6 +56,7 @@ def cases(pkg):
     add("drillUp [1000,1000,100] interleaved (flat)", P.drillup("float32", 0.0, "sum", [1000, 1000, 100], [1000, 10, 100], [ident(1000), (np.arange(1000) % 10).astype(np.uint32), ident(100)]), 10 ** 8, 10 ** 6)
     add("drillUp [10]^8 dim0->all highest", P.drillup("float32", 0.0, "highest", [10] * 8, [1] + [10] * 7, [np.zeros(10, np.uint32)] + [ident(10)] * 7), 10 ** 8, 10 ** 7)
     add("drillUp [1e6,100]->[1,100] (reduce)", P.drillup("float32", 0.0, "sum", [10 ** 6, 100], [1, 100], [np.zeros(10 ** 6, np.uint32), ident(100)]), 10 ** 8, 100)
+    add("drillUp [1e4,1e4]->[1,1e4] (split4)", P.drillup("float32", 0.0, "sum", [10 ** 4, 10 ** 4], [1, 10 ** 4], [np.zeros(10 ** 4, np.uint32), ident(10 ** 4)]), 10 ** 8, 10 ** 4)
     add("drillUp odd location->10 interleaved", P.drillup("float32", 0.0, "sum", odd, [3653, 10, 271], [ident(3653), (np.arange(101) % 10).astype(np.uint32), ident(271)]), n_odd, 3653 * 10 * 271, width="4")
     return out
 

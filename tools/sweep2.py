@@ -53,6 +53,10 @@ run("[1e5,1000] axis1 -> all", [10 ** 5, 1000], 1, np.zeros(1000))
 run("[1e5,1000] axis1 -> 10 interleaved", [10 ** 5, 1000], 1, np.arange(1000) % 10)
 run("[1e8] -> [1]", [10 ** 8], 0, np.zeros(10 ** 8))
 run("[1e7,10] axis0 -> all", [10 ** 7, 10], 0, np.zeros(10 ** 7))
+# few outputs, rows wider than 128 cells: the split regime
+run("[1e4,1e4] axis0 -> all", [10 ** 4, 10 ** 4], 0, np.zeros(10 ** 4))
+run("[1e5,1000] axis0 -> all", [10 ** 5, 1000], 0, np.zeros(10 ** 5))
+run("[4e5,250] axis0 -> all (rows of 250 cells)", [4 * 10 ** 5, 250], 0, np.zeros(4 * 10 ** 5))
 run("[1000,1000,100] axis1 -> 100 groups", [1000, 1000, 100], 1, np.arange(1000) % 100)
 run("[1000,1000,100] axis1 highest", [1000, 1000, 100], 1, np.arange(1000) % 100, "highest")
 run("[1000,1000,100] axis1 product", [1000, 1000, 100], 1, np.arange(1000) % 100, "product")
