@@ -3,7 +3,7 @@
 plan's own choice)."""
 import os, sys
 import numpy as np, torch
-ROOT = os.getcwd(); sys.path.insert(0, ROOT)
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 from __graft_entry__ import load_package
 pkg = load_package()
 from olap_in_memory_amd.sharded import HipEngine

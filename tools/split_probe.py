@@ -2,7 +2,7 @@
 """Developer tool: roll-ups with few output cells, long groups and rows wider than 128 cells (the split regime)."""
 import os, sys
 import numpy as np, torch
-ROOT = os.getcwd(); sys.path.insert(0, ROOT)
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 from __graft_entry__ import load_package
 pkg = load_package()
 from olap_in_memory_amd.sharded import HipEngine
