@@ -2558,33 +2558,37 @@ __global__ __launch_bounds__(kBlock) void total_kernel(const T *values, const in
   double acc = 0.0;
   unsigned long long cnt = 0;
   if constexpr (VECTOR) {
+    // every workgroup streams ONE contiguous range of the buffer (a grid-stride sweep hands it 4 KB pieces 16 MB apart)
     const uint64_t n_groups = n / V;
     constexpr int U = 4;
-    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
-    for (uint64_t q = (uint64_t)blockIdx.x * kBlock + threadIdx.x; q < n_groups; q += stride * U) {
+    const uint64_t chunk = (n_groups + gridDim.x - 1) / gridDim.x;
+    const uint64_t q_begin = (uint64_t)blockIdx.x * chunk;
+    const uint64_t q_end = q_begin + chunk < n_groups ? q_begin + chunk : n_groups;
+    uint32_t cnt32 = 0;  // (at most chunk * V / kBlock cells per lane: the plan keeps it below 2^32)
+    for (uint64_t q = q_begin + threadIdx.x; q < q_end; q += (uint64_t)kBlock * U) {
       Vec<T, V> x[U];
       Vec<int32_t, V> sx[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        const uint64_t qq = q + (uint64_t)u * stride;
-        if (qq < n_groups) {
+        const uint64_t qq = q + (uint64_t)u * kBlock;
+        if (qq < q_end) {
           x[u] = load_stream<T, V>(values + qq * V);
           if (hs) sx[u] = load_stream<int32_t, V>(status + qq * V);
         }
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        if (q + (uint64_t)u * stride < n_groups) {
+        if (q + (uint64_t)u * kBlock < q_end) {
 #pragma unroll
           for (int e = 0; e < V; ++e) {
-            if (cell_is_set<T>(x[u].v[e], hs ? sx[u].v[e] : OLAP_STATUS_SET, hs, def_nan)) {
-              acc += Cell<T>::to_f64(x[u].v[e]);
-              ++cnt;
-            }
+            const bool set = cell_is_set<T>(x[u].v[e], hs ? sx[u].v[e] : OLAP_STATUS_SET, hs, def_nan);
+            acc += set ? Cell<T>::to_f64(x[u].v[e]) : 0.0;
+            cnt32 += set ? 1u : 0u;
           }
         }
       }
     }
+    cnt = cnt32;
     if (blockIdx.x == 0 && threadIdx.x < n - n_groups * V) {  // the last n % V cells
       const uint64_t i = n_groups * V + threadIdx.x;
       if (cell_is_set<T>(values[i], hs ? status[i] : OLAP_STATUS_SET, hs, def_nan)) {
@@ -3504,7 +3508,12 @@ hipError_t Launch<T>::total(const T *values, const int32_t *status, uint64_t n, 
                             unsigned long long *count, hipStream_t stream) {
   // workspace: kTotalBlocks TotalPartial slots
   constexpr uint64_t per_block = (uint64_t)kBlock * (16 / sizeof(T)) * 4;  // cells one sweep of a workgroup covers
-  const unsigned blocks = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(kTotalBlocks, (n + per_block - 1) / per_block));
+  // eight workgroups per CU, each streaming one contiguous range (tools/total_probe.py, 10^8 cells, per call with the
+  // blocking read of the result: the grid-stride sweep of 4 096 workgroups 102 us; contiguous ranges with 512 / 1 024 /
+  // 2 048 / 4 096 workgroups 111 / 94 / 96 / 95 us); more only when a lane's 32-bit count of set cells could overflow
+  static const uint64_t units = getenv("OLAP_TOTAL_BLOCKS") ? std::max<uint64_t>(1, std::min<uint64_t>(kTotalBlocks, (uint64_t)atoll(getenv("OLAP_TOTAL_BLOCKS")))) : 2048;
+  const uint64_t min_blocks = (n >> 40) + 1;
+  const unsigned blocks = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(kTotalBlocks, std::max<uint64_t>(min_blocks, std::min<uint64_t>(units, (n + per_block - 1) / per_block))));
   const bool vector = (((uintptr_t)values | (uintptr_t)status) & 15u) == 0;
   TotalPartial *partial = (TotalPartial *)workspace;
   if (vector) hipLaunchKernelGGL((total_kernel<T, true>), blocks, kBlock, 0, stream, values, status, n, def_nan, partial);
