@@ -2043,9 +2043,23 @@ extern "C" int olap_total(const void *values, const int32_t *status, uint64_t n,
   Acc *dev = nullptr;
   HIP_TRY(dev_alloc((void **)&dev, sizeof(Acc) * (1 + (size_t)kTotalBlocks)));
   hipError_t e = hipSuccess;
-  DISPATCH_DTYPE(dtype, e = Launch<T>::total((const T *)values, status, n, default_kind == OLAP_DEFAULT_NAN, dev + 1, &dev->total, &dev->count, (hipStream_t)stream));
+  // the result pair lands in pinned host memory the finishing kernel writes directly (one per host thread, kept): the
+  // call then costs one stream synchronisation instead of that plus a blocking 16-byte copy
+  static thread_local Acc *pinned = nullptr;
+  static thread_local bool pinned_tried = false;
+  if (!pinned_tried) {
+    pinned_tried = true;
+    void *q = nullptr;
+    if (hipHostMalloc(&q, sizeof(Acc), hipHostMallocPortable | hipHostMallocMapped) == hipSuccess) pinned = (Acc *)q;
+    else (void)hipGetLastError();
+  }
+  Acc *result = pinned ? pinned : dev;
+  DISPATCH_DTYPE(dtype, e = Launch<T>::total((const T *)values, status, n, default_kind == OLAP_DEFAULT_NAN, dev + 1, &result->total, &result->count, (hipStream_t)stream));
   if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
-  if (e == hipSuccess) e = hipMemcpy(&host, dev, sizeof(host), hipMemcpyDeviceToHost);
+  if (e == hipSuccess) {
+    if (pinned) host = *pinned;
+    else e = hipMemcpy(&host, dev, sizeof(host), hipMemcpyDeviceToHost);
+  }
   dev_free(dev);
   if (e != hipSuccess) return hip_fail(e, "total");
   if (total) *total = host.total;
