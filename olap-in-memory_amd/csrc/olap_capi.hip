@@ -2333,16 +2333,35 @@ extern "C" int olap_store_get_value(const olap_store *s, uint64_t index, double 
     return OLAP_OK;
   }
   int32_t st = OLAP_STATUS_SET;
-  if (s->status) HIP_TRY(hipMemcpy(&st, s->status + index, sizeof(st), hipMemcpyDeviceToHost));
   double v = 0;
-  const size_t es = olap_dtype_size(s->dtype);
-  unsigned char raw[8];
-  HIP_TRY(hipMemcpy(raw, (const char *)s->values + index * es, es, hipMemcpyDeviceToHost));
-  switch (s->dtype) {
-    case OLAP_INT32: { int32_t x; memcpy(&x, raw, 4); v = x; break; }
-    case OLAP_UINT32: { uint32_t x; memcpy(&x, raw, 4); v = x; break; }
-    case OLAP_FLOAT32: { float x; memcpy(&x, raw, 4); v = x; break; }
-    default: memcpy(&v, raw, 8);
+  // one lane writes (value, status) into pinned host memory (one slot per host thread, kept) and the call waits for the
+  // stream once — instead of one or two blocking copies; the copies remain as the fallback
+  static thread_local CellOut *pinned = nullptr;
+  static thread_local bool pinned_tried = false;
+  if (!pinned_tried) {
+    pinned_tried = true;
+    void *q = nullptr;
+    if (hipHostMalloc(&q, sizeof(CellOut), hipHostMallocPortable | hipHostMallocMapped) == hipSuccess) pinned = (CellOut *)q;
+    else (void)hipGetLastError();
+  }
+  if (pinned) {
+    hipError_t e = hipSuccess;
+    DISPATCH_DTYPE(s->dtype, e = Launch<T>::get_cell((const T *)s->values, s->status, index, pinned, nullptr));
+    if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
+    if (e != hipSuccess) return hip_fail(e, "getValue");
+    v = pinned->value;
+    st = pinned->status;
+  } else {
+    if (s->status) HIP_TRY(hipMemcpy(&st, s->status + index, sizeof(st), hipMemcpyDeviceToHost));
+    const size_t es = olap_dtype_size(s->dtype);
+    unsigned char raw[8];
+    HIP_TRY(hipMemcpy(raw, (const char *)s->values + index * es, es, hipMemcpyDeviceToHost));
+    switch (s->dtype) {
+      case OLAP_INT32: { int32_t x; memcpy(&x, raw, 4); v = x; break; }
+      case OLAP_UINT32: { uint32_t x; memcpy(&x, raw, 4); v = x; break; }
+      case OLAP_FLOAT32: { float x; memcpy(&x, raw, 4); v = x; break; }
+      default: memcpy(&v, raw, 8);
+    }
   }
   bool set = (st & OLAP_STATUS_SET) != 0;
   if (!mask_is_primary(s)) {  // set <=> value != default

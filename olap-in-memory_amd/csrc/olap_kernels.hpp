@@ -2662,6 +2662,19 @@ __global__ __launch_bounds__(kBlock) void total_finish_kernel(const TotalPartial
 }
 
 // single-cell access for getValue / setValue on a handle store
+// getValue (in-memory.js:118-120) without a blocking copy: one lane writes the cell (as a JS number) and its status word
+// into pinned host memory; the caller waits for the stream once.
+struct CellOut {
+  double value;
+  int32_t status;
+  int32_t pad;
+};
+template <typename T>
+__global__ void get_cell_kernel(const T *values, const int32_t *status, uint64_t index, CellOut *out) {
+  out->value = Cell<T>::to_f64(values[index]);
+  out->status = status ? status[index] : OLAP_STATUS_SET;
+}
+
 template <typename T>
 __global__ void set_cell_kernel(T *values, int32_t *status, uint64_t index, double value, int is_null, int def_nan_i) {
   const bool def_nan = def_nan_i != 0;
@@ -2895,6 +2908,7 @@ struct Launch {
                                   hipStream_t stream);
   static hipError_t scatter_sparse(T *values, const uint32_t *idx, const T *vals, uint64_t n_set, uint64_t size,
                                    hipStream_t stream);
+  static hipError_t get_cell(const T *values, const int32_t *status, uint64_t index, CellOut *out, hipStream_t stream);
   static hipError_t set_cell(T *values, int32_t *status, uint64_t index, double value, int is_null, int def_nan,
                              hipStream_t stream);
 };
@@ -3544,6 +3558,12 @@ hipError_t Launch<T>::scatter_sparse(T *values, const uint32_t *idx, const T *va
                                      hipStream_t stream) {
   if (n_set == 0) return hipSuccess;
   hipLaunchKernelGGL((scatter_sparse_kernel<T>), grid_stride_for(n_set), kBlock, 0, stream, values, idx, vals, n_set, size);
+  return hipGetLastError();
+}
+
+template <typename T>
+hipError_t Launch<T>::get_cell(const T *values, const int32_t *status, uint64_t index, CellOut *out, hipStream_t stream) {
+  hipLaunchKernelGGL((get_cell_kernel<T>), 1, 1, 0, stream, values, status, index, out);
   return hipGetLastError();
 }
 
