@@ -53,9 +53,13 @@ typedef enum {
   OLAP_FIRST = 4,
   OLAP_LAST = 5,
   OLAP_PRODUCT = 6,
-  /* Not a reference method.  The shard-local half of `average` for a cube partitioned across
-   * GPUs: out_values receives the (undivided) float64 sum of the set cells, out_status receives
-   * the NUMBER of contributions (not a mask).  Ranks add both and call olap_average_finish(). */
+  /* Not a reference method.  The shard-local half of `sum` / `average` for a cube partitioned across GPUs
+   * (drillUp plans only).  out_values is a FLOAT64 buffer whatever the cell type: it receives the float64
+   * accumulator itself — the undivided, unrounded sum of the set cells, 0 where nothing contributed (never
+   * NaN) — because the reference adds all contributions of a cell in float64 and rounds never
+   * (in-memory.js:282-290); out_status (optional) receives the NUMBER of contributions, not a mask.  Ranks add
+   * both; the sums are rounded to the cell type once, after the division for `average`
+   * (olap_shard_recipe: OLAP_FINISH_ROUND / OLAP_FINISH_AVERAGE). */
   OLAP_PARTIAL_AVERAGE = 7
 } olap_method;
 
@@ -390,7 +394,11 @@ typedef enum {
   OLAP_FINISH_NONE = 0,     /* sum over a 0 default: the reduced values ARE the result (set <=> != 0) */
   OLAP_FINISH_RESTORE = 1,  /* sum over a NaN default: cells no rank contributed to get the default back */
   OLAP_FINISH_AVERAGE = 2,  /* (sum, contribution count) -> in-memory.js:323-331, count modulo 65536 */
-  OLAP_FINISH_COMBINE = 3   /* highest/lowest/first/last/product: the same drillUp over the rank axis */
+  OLAP_FINISH_COMBINE = 3,  /* highest/lowest/first/last/product: the same drillUp over the rank axis */
+  OLAP_FINISH_ROUND = 4     /* sum of Float32 cells: the float64 partial sums, added in float64, are rounded to the cell
+                             * type ONCE (as the one-device kernels round their float64 accumulator); a cell is set iff
+                             * somebody contributed (NaN default: contribution counts travel too) and the rounded sum
+                             * is not the default */
 } olap_shard_finish;
 typedef enum {
   OLAP_PLACE_SCATTER = 0,   /* additive methods: rank r keeps flat cells [r*per, (r+1)*per), per = ceil(n_out/world) */
@@ -401,9 +409,11 @@ typedef enum {
 } olap_shard_placement;
 typedef struct {
   int local_method;     /* olap_method run by each rank over its own rows */
-  int zero_unset;       /* float cells over a NaN default: unset partial cells are shipped as 0, never as NaN */
+  int zero_unset;       /* float64 cells over a NaN default, `sum`: unset partial cells are shipped as 0, never as NaN */
   int n_payloads;       /* 1 or 2 */
-  int payload_dtype[2]; /* [0]: the cell type; [1]: OLAP_INT32 (mask, or contribution counts for average) */
+  int payload_dtype[2]; /* [0]: the cell type — OLAP_FLOAT64 for `average` and for `sum` of Float32 cells, whose partials
+                         * are the float64 accumulators (twice the bytes on the wire); [1]: OLAP_INT32 (mask, or
+                         * contribution counts) */
   int payload_op[2];    /* olap_xchg_op; masks are combined with MAX (an OR of 0 / 0x2), never added */
   int finish;           /* olap_shard_finish */
 } olap_shard_recipe;

@@ -171,7 +171,7 @@ class ShardRecipe(C.Structure):
 
 
 XCHG_SUM, XCHG_MAX, XCHG_GATHER = 0, 1, 2
-FINISH_NONE, FINISH_RESTORE, FINISH_AVERAGE, FINISH_COMBINE = 0, 1, 2, 3
+FINISH_NONE, FINISH_RESTORE, FINISH_AVERAGE, FINISH_COMBINE, FINISH_ROUND = 0, 1, 2, 3, 4
 PLACE_SCATTER, PLACE_ALL, PLACE_ROOT, PLACE_SCATTER_ROWS = 0, 1, 2, 3
 UNIQUE_ID_BYTES = 128
 

@@ -305,7 +305,13 @@ extern "C" void olap_plan_destroy(olap_plan *p) {
   if (!p) return;
   // the tables go back to the pool and may be handed out again at once: wait for the launches
   // that still read them (hipFree used to imply this)
-  if (p->ran) (void)hipStreamSynchronize(p->last_stream);
+  // (on the plan's OWN device: the plan cache may evict a plan of device A while device B is current, and a null
+  // last_stream would then name B's null stream)
+  if (p->ran && !plan_dry()) {
+    DeviceGuard guard;
+    if (p->device >= 0) (void)hipSetDevice(p->device);
+    (void)hipStreamSynchronize(p->last_stream);
+  }
   for (void *q : p->owned) dev_free(q);
   if (p->dev_tab) dev_free(p->dev_tab);
   if (p->dev_tab2) dev_free(p->dev_tab2);

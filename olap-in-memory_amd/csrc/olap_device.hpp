@@ -152,10 +152,17 @@ __device__ __forceinline__ Vec<T, N> load_stream_cell_aligned(const T *p) {
 
 template <typename T, int N>
 __device__ __forceinline__ void store_stream_cell_aligned(T *p, const Vec<T, N> &x) {
-  typedef typename RawVecAt<sizeof(T) * N, sizeof(T)>::type R;
-  union U { typename RawVec<sizeof(T) * N>::type r; Vec<T, N> v; __device__ U() {} } u;
-  u.v = x;
-  __builtin_nontemporal_store(u.r, reinterpret_cast<R *>(p));
+  if constexpr (sizeof(T) * N > 16) {  // four float64 partials: two 16-byte halves
+    union H { Vec<T, N / 2> h[2]; Vec<T, N> v; __device__ H() {} } u;
+    u.v = x;
+    store_stream_cell_aligned<T, N / 2>(p, u.h[0]);
+    store_stream_cell_aligned<T, N / 2>(p + N / 2, u.h[1]);
+  } else {
+    typedef typename RawVecAt<sizeof(T) * N, sizeof(T)>::type R;
+    union U { typename RawVec<sizeof(T) * N>::type r; Vec<T, N> v; __device__ U() {} } u;
+    u.v = x;
+    __builtin_nontemporal_store(u.r, reinterpret_cast<R *>(p));
+  }
 }
 
 // ---------------------------------------------------------------- the per-output-cell aggregate
@@ -266,6 +273,27 @@ __device__ __forceinline__ void emit_cell(double acc, bool has, bool def_nan, T 
   bool set = has && !Cell<T>::is_default(tv, def_nan);
   value = set ? tv : Cell<T>::default_value(def_nan);
   status = set ? OLAP_STATUS_SET : 0;
+}
+
+// OLAP_PARTIAL_AVERAGE (the shard-local half of a sharded sum / average, olap_sharded.hip) hands out the float64
+// ACCUMULATOR itself, whatever the cell type, and the number of contributions in the status slot: the reference adds
+// every contribution of an output cell in float64 and never rounds in between (in-memory.js:282-290, :311-318), so a
+// partial rounded to Float32 before the ranks are added loses that (2^24 + 1 - 2^24 = 0 instead of 1).  A cell nobody
+// contributed to ships 0, the neutral element — never the NaN default.
+template <int METHOD> struct IsPartial { static constexpr bool value = (METHOD == OLAP_PARTIAL_AVERAGE); };
+template <typename T, int METHOD> struct OutCell { typedef T type; };
+template <typename T> struct OutCell<T, OLAP_PARTIAL_AVERAGE> { typedef double type; };
+
+// One output cell of a kernel instantiated for METHOD: the typed cell and its mask, or the float64 partial and its count.
+template <typename T, int METHOD>
+__device__ __forceinline__ void emit_out(double acc, bool has, uint32_t count, bool def_nan, typename OutCell<T, METHOD>::type &value,
+                                         int32_t &status) {
+  if constexpr (IsPartial<METHOD>::value) {
+    value = has ? acc : 0.0;
+    status = (int32_t)count;
+  } else {
+    emit_cell<T>(acc, has, def_nan, value, status);
+  }
 }
 
 template <typename T>

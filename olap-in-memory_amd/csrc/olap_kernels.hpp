@@ -102,7 +102,10 @@ struct Lane {
     }
   }
 
-  __device__ __forceinline__ void finish(bool def_nan, Vec<T, VEC> &ov, Vec<int32_t, VEC> &os) {
+  // what this METHOD writes: the typed cell, or the float64 partial of OLAP_PARTIAL_AVERAGE (olap_device.hpp: OutCell)
+  typedef typename OutCell<T, METHOD>::type O;
+
+  __device__ __forceinline__ void finish(bool def_nan, Vec<O, VEC> &ov, Vec<int32_t, VEC> &os) {
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
       if constexpr (kPick) {
@@ -116,22 +119,23 @@ struct Lane {
           if constexpr (METHOD == OLAP_AVERAGE || METHOD == OLAP_PARTIAL_AVERAGE) agg[e].has = agg[e].has && agg[e].count != 0;
         }
         agg[e].finish(def_nan);
-        emit_cell<T>(agg[e].acc, agg[e].has, def_nan, ov.v[e], os.v[e]);
-        if constexpr (METHOD == OLAP_PARTIAL_AVERAGE) os.v[e] = (int32_t)agg[e].count;  // count, not a mask
+        emit_out<T, METHOD>(agg[e].acc, agg[e].has, agg[e].count, def_nan, ov.v[e], os.v[e]);
       }
     }
   }
 
+  // `out` is the launch's value buffer: cells of T, or float64 partials under OLAP_PARTIAL_AVERAGE
   template <bool NT>
   __device__ __forceinline__ void finish_and_store(bool def_nan, T *out, int32_t *st_out, uint64_t oidx) {
-    Vec<T, VEC> ov;
+    Vec<O, VEC> ov;
     Vec<int32_t, VEC> os;
     finish(def_nan, ov, os);
+    O *dst = reinterpret_cast<O *>(out) + oidx;
     if constexpr (NT) {
-      store_stream<T, VEC>(out + oidx, ov);
+      store_stream<O, VEC>(dst, ov);
       if (st_out) store_stream<int32_t, VEC>(st_out + oidx, os);
     } else {
-      store_vec<T, VEC>(out + oidx, ov);
+      store_vec<O, VEC>(dst, ov);
       if (st_out) store_vec<int32_t, VEC>(st_out + oidx, os);
     }
   }
@@ -253,17 +257,19 @@ __device__ __forceinline__ void drillup_rows_body(const T *__restrict__ in, cons
   if constexpr (!RAGGED) {
     lane.template finish_and_store<NT>(def_nan, out, st_out, oidx);
   } else {
-    Vec<T, VEC> ov;
+    typedef typename OutCell<T, METHOD>::type O;
+    Vec<O, VEC> ov;
     Vec<int32_t, VEC> os;
     lane.finish(def_nan, ov, os);
+    O *dst = reinterpret_cast<O *>(out) + oidx;
     if (valid == (uint32_t)VEC) {
-      store_stream_cell_aligned<T, VEC>(out + oidx, ov);
+      store_stream_cell_aligned<O, VEC>(dst, ov);
       if (st_out) store_stream_cell_aligned<int32_t, VEC>(st_out + oidx, os);
     } else {
 #pragma unroll
       for (int e = 0; e < VEC; ++e)
         if ((uint32_t)e < valid) {
-          out[oidx + e] = ov.v[e];
+          dst[e] = ov.v[e];
           if (st_out) st_out[oidx + e] = os.v[e];
         }
     }
@@ -617,7 +623,8 @@ __device__ __forceinline__ void drillup_tile_body(const T *__restrict__ in, cons
   // (starting the reducing lanes at a wavefront that differs from workgroup to workgroup — with fewer outputs than
   // lanes only the first wavefront reduces — was measured and is slower: 69 -> 77 us on 4 rows x 10 runs of 100)
   const uint32_t tid = threadIdx.x;
-  T *dst = out + row0 * tl.out_row;
+  typedef typename OutCell<T, METHOD>::type O;  // float64 partials under OLAP_PARTIAL_AVERAGE
+  O *dst = reinterpret_cast<O *>(out) + row0 * tl.out_row;
   int32_t *sdst = st_out ? st_out + row0 * tl.out_row : nullptr;
   if constexpr (ALL && FAST) {  // (FAST: sum / average over a 0 default without a mask)
     // one long row per output (rolling up a last dimension of 256..4096 items): a tile holds a dozen
@@ -658,10 +665,9 @@ __device__ __forceinline__ void drillup_tile_body(const T *__restrict__ in, cons
           agg.count = cnt;
           agg.has = acc != 0.0 && (METHOD == OLAP_SUM || cnt != 0);
           agg.finish(def_nan);
-          T ov;
+          O ov;
           int32_t os;
-          emit_cell<T>(agg.acc, agg.has, def_nan, ov, os);
-          if constexpr (METHOD == OLAP_PARTIAL_AVERAGE) os = (int32_t)agg.count;
+          emit_out<T, METHOD>(agg.acc, agg.has, agg.count, def_nan, ov, os);
           dst[r] = ov;
           if (sdst) sdst[r] = os;
         }
@@ -717,7 +723,7 @@ __device__ __forceinline__ void drillup_tile_body(const T *__restrict__ in, cons
       sx[0].v[0] = HAS_STATUS ? stile[base + k * tl.inner] : OLAP_STATUS_SET;
       lane.add_row(x[0], sx[0], def_nan);
     }
-    lane.template finish_and_store<false>(def_nan, dst, sdst, idx);
+    lane.template finish_and_store<false>(def_nan, reinterpret_cast<T *>(dst), sdst, idx);
     if (idx == 0) g_probe3(blockIdx.x);
   }
 }
@@ -824,7 +830,8 @@ __global__ __launch_bounds__(kBlock) void drillup_gtile_kernel(const Batch<T> b,
   __syncthreads();
 
   const uint32_t n_out = ng * inner;
-  T *dst = out + (o * a.G + g0) * a.inner;
+  // (finish_and_store indexes the buffer in units of what METHOD writes: float64 partials under OLAP_PARTIAL_AVERAGE)
+  T *dst = reinterpret_cast<T *>(reinterpret_cast<typename OutCell<T, METHOD>::type *>(out) + (o * a.G + g0) * a.inner);
   int32_t *sdst = st_out ? st_out + (o * a.G + g0) * a.inner : nullptr;
   for (uint32_t idx = threadIdx.x; idx < n_out; idx += kBlock) {
     const uint32_t g = idx / inner;
@@ -930,14 +937,13 @@ struct DrillUpReduce {
 
 // Partial state -> output cell (what drillup_merge_kernel does after merging the segments).
 template <typename T, int METHOD>
-__device__ __forceinline__ void partial_finish(const Partial &p, bool def_nan, T &ov, int32_t &os) {
+__device__ __forceinline__ void partial_finish(const Partial &p, bool def_nan, typename OutCell<T, METHOD>::type &ov, int32_t &os) {
   Agg<METHOD> agg;
   agg.acc = p.acc;
   agg.has = (p.meta & 0x80000000u) != 0;
   agg.count = p.meta & 0x7FFFFFFFu;
   agg.finish(def_nan);
-  emit_cell<T>(agg.acc, agg.has, def_nan, ov, os);
-  if constexpr (METHOD == OLAP_PARTIAL_AVERAGE) os = (int32_t)agg.count;
+  emit_out<T, METHOD>(agg.acc, agg.has, agg.count, def_nan, ov, os);
 }
 
 // Lane-to-lane merge step of the reduce regime.  FAST (sum / average over a 0 default, no mask): the
@@ -1062,6 +1068,8 @@ __global__ __launch_bounds__(kBlock) void drillup_reduce4_kernel(const T *__rest
                                                                  T *__restrict__ out, int32_t *__restrict__ st_out,
                                                                  const DrillUpAxis a, const DrillUpReduce rd) {
   __shared__ Partial lds[kBlock * 4];
+  typedef typename OutCell<T, METHOD>::type O;  // float64 partials under OLAP_PARTIAL_AVERAGE
+  O *outp = reinterpret_cast<O *>(out);
   const uint32_t inner = (uint32_t)a.inner;
   const uint32_t units_per_block = kBlock / rd.unit;
   const uint64_t unit_id = (uint64_t)blockIdx.x * units_per_block + threadIdx.x / rd.unit;
@@ -1215,20 +1223,20 @@ __global__ __launch_bounds__(kBlock) void drillup_reduce4_kernel(const T *__rest
     if (live && lane * 4 < inner) {
       if (rd.S == 1) {
         if (inner % 4 == 0) {
-          Vec<T, 4> ov;
+          Vec<O, 4> ov;
           Vec<int32_t, 4> os;
 #pragma unroll
           for (int e = 0; e < 4; ++e) partial_finish<T, METHOD>(p[e], def_nan, ov.v[e], os.v[e]);
-          store_vec<T, 4>(out + o * a.inner + lane * 4, ov);
+          store_vec<O, 4>(outp + o * a.inner + lane * 4, ov);
           if (st_out) store_vec<int32_t, 4>(st_out + o * a.inner + lane * 4, os);
         } else {
 #pragma unroll
           for (int e = 0; e < 2; ++e) {  // constant indices: p[] must stay in registers
             if ((uint32_t)e < inner) {
-              T ov;
+              O ov;
               int32_t os;
               partial_finish<T, METHOD>(p[e], def_nan, ov, os);
-              out[o * a.inner + e] = ov;
+              outp[o * a.inner + e] = ov;
               if (st_out) st_out[o * a.inner + e] = os;
             }
           }
@@ -1273,10 +1281,10 @@ __global__ __launch_bounds__(kBlock) void drillup_reduce4_kernel(const T *__rest
       Partial x = lds[lds_base + i];
       if constexpr (FAST) partial_seal(x);
       if (rd.S == 1) {
-        T ov;
+        O ov;
         int32_t os;
         partial_finish<T, METHOD>(x, def_nan, ov, os);
-        out[o * a.inner + i] = ov;
+        outp[o * a.inner + i] = ov;
         if (st_out) st_out[o * a.inner + i] = os;
       } else {
         rd.part[(o * a.inner + i) * rd.S + seg] = x;
@@ -1423,10 +1431,10 @@ __global__ __launch_bounds__(kBlock) void drillup_merge_kernel(T *__restrict__ o
     partial_merge<METHOD>(p, q, def_nan);
   }
   if (lane == 0) {
-    T ov;
+    typename OutCell<T, METHOD>::type ov;
     int32_t os;
     partial_finish<T, METHOD>(p, def_nan, ov, os);
-    out[cell] = ov;
+    reinterpret_cast<typename OutCell<T, METHOD>::type *>(out)[cell] = ov;
     if (st_out) st_out[cell] = os;
   }
 }
@@ -1462,10 +1470,10 @@ __global__ __launch_bounds__(kBlock) void drillup_merge_block_kernel(T *__restri
   if (threadIdx.x == 0) {
 #pragma unroll
     for (uint32_t w = 1; w < kBlock / 64; ++w) partial_merge<METHOD>(p, wave_part[w], def_nan);
-    T ov;
+    typename OutCell<T, METHOD>::type ov;
     int32_t os;
     partial_finish<T, METHOD>(p, def_nan, ov, os);
-    out[cell] = ov;
+    reinterpret_cast<typename OutCell<T, METHOD>::type *>(out)[cell] = ov;
     if (st_out) st_out[cell] = os;
   }
 }
@@ -1479,10 +1487,10 @@ __global__ __launch_bounds__(kBlock) void drillup_merge_few_kernel(T *__restrict
   const bool def_nan = a.def_nan != 0;
   Partial p = rd.part[cell * rd.S];
   for (uint32_t s = 1; s < rd.S; ++s) partial_merge<METHOD>(p, rd.part[cell * rd.S + s], def_nan);
-  T ov;
+  typename OutCell<T, METHOD>::type ov;
   int32_t os;
   partial_finish<T, METHOD>(p, def_nan, ov, os);
-  out[cell] = ov;
+  reinterpret_cast<typename OutCell<T, METHOD>::type *>(out)[cell] = ov;
   if (st_out) st_out[cell] = os;
 }
 
@@ -1549,11 +1557,10 @@ __global__ __launch_bounds__(kBlock) void drillup_generic_kernel(const T *__rest
     if (d < 0) break;
   }
   agg.finish(def_nan);
-  T ov;
+  typename OutCell<T, METHOD>::type ov;
   int32_t os;
-  emit_cell<T>(agg.acc, agg.has, def_nan, ov, os);
-  if constexpr (METHOD == OLAP_PARTIAL_AVERAGE) os = (int32_t)agg.count;
-  out[t] = ov;
+  emit_out<T, METHOD>(agg.acc, agg.has, agg.count, def_nan, ov, os);
+  reinterpret_cast<typename OutCell<T, METHOD>::type *>(out)[t] = ov;
   if (st_out) st_out[t] = os;
 }
 

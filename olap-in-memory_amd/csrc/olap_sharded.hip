@@ -52,13 +52,23 @@ Rccl *rccl() {
   std::lock_guard<std::mutex> lock(mu);
   if (r) return r;
   r = new Rccl();
+  // OLAP_RCCL_LIB names the library to bind instead of the default sonames (a site with its own build; the test of
+  // the "RCCL cannot be loaded" path points it at a file that does not exist)
+  const char *forced = getenv("OLAP_RCCL_LIB");
   const char *names[] = {"librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"};
-  for (const char *n : names) {
-    r->handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
-    if (r->handle) break;
+  const char *msg = nullptr;
+  if (forced && *forced) {
+    r->handle = dlopen(forced, RTLD_NOW | RTLD_GLOBAL);
+    if (!r->handle) msg = dlerror();  // (read once: dlerror() clears the message it returns)
+  } else {
+    for (const char *n : names) {
+      r->handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+      if (r->handle) break;
+      if (!msg) msg = dlerror();
+    }
   }
   if (!r->handle) {
-    r->error = std::string("cannot load RCCL: ") + (dlerror() ? dlerror() : "librccl.so.1 not found");
+    r->error = std::string("cannot load RCCL: ") + (msg ? msg : "librccl.so.1 not found");
     return r;
   }
 #define OLAP_BIND(name)                                                              \
@@ -99,6 +109,9 @@ ncclDataType_t nccl_type(int dtype) {
     default: return ncclFloat64;
   }
 }
+// Integer partial sums are added modulo 2^32 (the typed result of the one-device kernel is the exact float64 sum
+// modulo 2^32 as well, Cell<int32_t>::from_f64): as UNSIGNED words, whose wrap-around is defined.
+ncclDataType_t nccl_sum_type(int dtype) { return dtype == OLAP_INT32 ? ncclUint32 : nccl_type(dtype); }
 
 enum Transport { TRANSPORT_RCCL = 0, TRANSPORT_DIRECT = 1, TRANSPORT_DETACHED = 2 };
 }  // namespace
@@ -316,7 +329,19 @@ extern "C" int olap_shard_recipe_get(int dtype, int default_kind, int method, ol
   const bool primary = def_nan && !is_float_dtype(dtype);  // the mask carries information the values cannot
   rc->payload_dtype[0] = dtype;
   rc->payload_dtype[1] = OLAP_INT32;
-  if (method == OLAP_SUM) {
+  if (method == OLAP_SUM && dtype == OLAP_FLOAT32) {
+    // The reference adds every contribution of an output cell in float64 and never rounds in between
+    // (in-memory.js:282-290, :311-318); so do the one-device kernels.  A partial rounded to Float32 before the ranks
+    // are added breaks that under cancellation ([2^24, 1 | -2^24] -> 0 and unset instead of 1 and set), so each rank
+    // ships its float64 ACCUMULATOR, the ranks are added in float64 and the sum is rounded to the cell type ONCE.
+    rc->local_method = OLAP_PARTIAL_AVERAGE;  // (float64 sum of the set cells, contribution count)
+    rc->payload_dtype[0] = OLAP_FLOAT64;
+    rc->payload_op[0] = OLAP_XCHG_SUM;
+    rc->payload_op[1] = OLAP_XCHG_SUM;
+    rc->n_payloads = def_nan ? 2 : 1;  // 0 default: set <=> the rounded sum != 0; NaN default: somebody contributed
+    rc->finish = OLAP_FINISH_ROUND;
+  } else if (method == OLAP_SUM) {
+    // float64 cells are their own accumulator; integer cells are added modulo 2^32 on every path (exact)
     rc->local_method = OLAP_SUM;
     rc->payload_op[0] = OLAP_XCHG_SUM;
     if (!def_nan) {  // set <=> value != 0: a rank without contributions ships 0, the neutral element
@@ -329,11 +354,11 @@ extern "C" int olap_shard_recipe_get(int dtype, int default_kind, int method, ol
       rc->finish = OLAP_FINISH_RESTORE;
     }
   } else if (method == OLAP_AVERAGE) {
-    rc->local_method = OLAP_PARTIAL_AVERAGE;  // (sum, contribution count) in one local pass
+    rc->local_method = OLAP_PARTIAL_AVERAGE;  // (float64 sum, contribution count) in one local pass; unset cells ship 0
+    rc->payload_dtype[0] = OLAP_FLOAT64;      // every cell type: an Int32 sum may pass 2^31 before it is divided
     rc->n_payloads = 2;
     rc->payload_op[0] = OLAP_XCHG_SUM;
     rc->payload_op[1] = OLAP_XCHG_SUM;
-    rc->zero_unset = def_nan && is_float_dtype(dtype);
     rc->finish = OLAP_FINISH_AVERAGE;
   } else {
     // highest / lowest / first / last / product are associative in rank order (ranks own ascending
@@ -364,6 +389,32 @@ __global__ __launch_bounds__(kBlock) void restore_default_kernel(T *values, int3
     const bool set = (flags[i] & OLAP_STATUS_SET) != 0 && !Cell<T>::is_default(values[i], def_nan != 0);
     if (!set) values[i] = Cell<T>::default_value(def_nan != 0);
     flags[i] = set ? OLAP_STATUS_SET : 0;
+  }
+}
+// float64 partial sums (+ contribution counts) added over the ranks -> typed cells, rounded ONCE.  Mirrors what the
+// one-device kernels do with their accumulator: Agg::finish (in-memory.js:323-331: divide by the Uint16 counter unless
+// it wrapped to 0) and emit_cell.  counts == nullptr: a sum over a 0 default, where "somebody contributed" does not
+// matter (set <=> the rounded sum is not 0).
+template <typename T>
+__global__ __launch_bounds__(kBlock) void partial_round_kernel(const double *sums, const int32_t *counts, T *values, int32_t *status,
+                                                               uint64_t n, int def_nan_i, int average) {
+  const bool def_nan = def_nan_i != 0;
+  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kBlock) {
+    double r = sums[i];
+    const uint32_t c = counts ? (uint32_t)counts[i] : 1u;
+    bool has = c != 0 && !is_default_f64(r, def_nan);
+    if (average) {
+      const uint32_t c16 = c & 0xFFFFu;  // Uint16Array counter
+      if (c16) {
+        r = (has ? r : (def_nan ? __builtin_nan("") : 0.0)) / (double)c16;
+        has = !is_default_f64(r, def_nan);
+      }
+    }
+    T ov;
+    int32_t os;
+    emit_cell<T>(r, has, def_nan, ov, os);
+    values[i] = ov;
+    status[i] = os;
   }
 }
 template <typename T>
@@ -410,7 +461,7 @@ namespace {
 struct BufSet {
   void *send[2] = {nullptr, nullptr};      // partial values / partial mask-or-counts
   void *recv[2] = {nullptr, nullptr};      // combined (or gathered) payloads
-  void *result = nullptr;                  // FINISH_COMBINE only (else the result is recv[0] in place)
+  void *result = nullptr;                  // FINISH_COMBINE / _ROUND / _AVERAGE (else the result is recv[0] in place)
   int32_t *result_status = nullptr;
   const void **peers[2] = {nullptr, nullptr};  // direct transport: device table of every rank's send[p]
   hipEvent_t local_done = nullptr, xchg_done = nullptr;
@@ -433,6 +484,9 @@ struct olap_shard_drillup {
   int cur = 0;       // buffer set of the last step
   std::vector<RankState> ranks;
 };
+
+// the typed result lives in a buffer of its own (gathered partials; float64 partials rounded once at the end)
+static bool separate_result(int finish) { return finish == OLAP_FINISH_COMBINE || finish == OLAP_FINISH_ROUND || finish == OLAP_FINISH_AVERAGE; }
 
 static bool is_scatter(int placement) { return placement == OLAP_PLACE_SCATTER || placement == OLAP_PLACE_SCATTER_ROWS; }
 
@@ -566,14 +620,15 @@ extern "C" int olap_shard_drillup_create(olap_shard_drillup **out, olap_comm *co
         if (e == hipSuccess && needs_recv) e = dev_alloc(&b.recv[p], std::max<uint64_t>(recv_cells(op, p), 1) * es);
         if (e != hipSuccess) rc = hip_fail(e, "hipMalloc(sharded drillUp buffers)");
       }
-      if (!rc && rs.local_cells == 0 && def_nan && is_float_dtype(dtype) && !recipe.zero_unset) {
+      if (!rc && rs.local_cells == 0 && def_nan && is_float_dtype(dtype) && recipe.payload_op[0] == OLAP_XCHG_GATHER) {
         // a rank without rows ships "unset everywhere": the canonical default
         SHARD_DISPATCH(dtype, hipLaunchKernelGGL((fill_default_kernel<T>), grid_for_n(n_out), kBlock, 0, nullptr, (T *)b.send[0], n_out, 1));
         rc = launch_check("fill_default_kernel");
       }
-      if (!rc && recipe.finish == OLAP_FINISH_COMBINE) {
-        e = dev_alloc(&b.result, std::max<uint64_t>(n_out, 1) * olap_dtype_size(dtype));
-        if (e == hipSuccess) e = dev_alloc((void **)&b.result_status, std::max<uint64_t>(n_out, 1) * sizeof(int32_t));
+      if (!rc && separate_result(recipe.finish) && !(op->placement == OLAP_PLACE_ROOT && l.rank != 0)) {
+        const uint64_t cells = recipe.finish == OLAP_FINISH_COMBINE ? n_out : recv_cells(op, 0);
+        e = dev_alloc(&b.result, std::max<uint64_t>(cells, 1) * olap_dtype_size(dtype));
+        if (e == hipSuccess) e = dev_alloc((void **)&b.result_status, std::max<uint64_t>(cells, 1) * sizeof(int32_t));
         if (e != hipSuccess) rc = hip_fail(e, "hipMalloc(sharded drillUp result)");
       }
       if (!rc) {
@@ -666,8 +721,13 @@ static int shard_finish(olap_shard_drillup *op, int local, int k, hipStream_t st
                                                    (int32_t *)b.recv[1], n, op->default_kind == OLAP_DEFAULT_NAN));
       rc = launch_check("restore_default_kernel");
       break;
+    case OLAP_FINISH_ROUND:
     case OLAP_FINISH_AVERAGE:
-      rc = olap_average_finish(b.recv[0], (const int32_t *)b.recv[1], (int32_t *)b.recv[1], n, op->dtype, op->default_kind, stream);
+      SHARD_DISPATCH(op->dtype, hipLaunchKernelGGL((partial_round_kernel<T>), grid_for_n(n), kBlock, 0, stream, (const double *)b.recv[0],
+                                                   op->recipe.n_payloads > 1 ? (const int32_t *)b.recv[1] : nullptr, (T *)b.result,
+                                                   b.result_status, n, op->default_kind == OLAP_DEFAULT_NAN,
+                                                   op->recipe.finish == OLAP_FINISH_AVERAGE));
+      rc = launch_check("partial_round_kernel");
       break;
     case OLAP_FINISH_COMBINE:
       rc = olap_plan_run(rs.combine_plan, b.recv[0], op->recipe.n_payloads > 1 ? (const int32_t *)b.recv[1] : nullptr, b.result,
@@ -699,7 +759,7 @@ static int shard_exchange(olap_shard_drillup *op, int k, const std::vector<hipSt
       BufSet &b = op->ranks[i].set[k];
       const auto &l = c->local[i];
       for (int p = 0; p < rp.n_payloads && res == ncclSuccess; ++p) {
-        const ncclDataType_t ty = nccl_type(rp.payload_dtype[p]);
+        const ncclDataType_t ty = rp.payload_op[p] == OLAP_XCHG_SUM ? nccl_sum_type(rp.payload_dtype[p]) : nccl_type(rp.payload_dtype[p]);
         if (rp.payload_op[p] == OLAP_XCHG_GATHER) {
           res = r->AllGather(b.send[p], b.recv[p], op->n_out, ty, l.nccl, xs[i]);
           continue;
@@ -740,7 +800,10 @@ static int shard_exchange(olap_shard_drillup *op, int k, const std::vector<hipSt
                             (const T *const *)b.peers[p], c->world, (T *)b.recv[p], first, n);                               \
   } while (0)
       switch (rp.payload_dtype[p]) {
-        case OLAP_INT32: DIRECT_LAUNCH(int32_t); break;
+        case OLAP_INT32:
+          if (sum) DIRECT_LAUNCH(uint32_t);  // modulo 2^32, like nccl_sum_type
+          else DIRECT_LAUNCH(int32_t);
+          break;
         case OLAP_UINT32: DIRECT_LAUNCH(uint32_t); break;
         case OLAP_FLOAT32: DIRECT_LAUNCH(float); break;
         default: DIRECT_LAUNCH(double); break;
@@ -863,7 +926,7 @@ extern "C" int olap_shard_drillup_result(const olap_shard_drillup *op, int local
   }
   void *v = nullptr;
   int32_t *s = nullptr;
-  if (op->recipe.finish == OLAP_FINISH_COMBINE) {
+  if (separate_result(op->recipe.finish)) {
     v = b.result;
     s = b.result_status;
   } else {
@@ -946,7 +1009,7 @@ OpCache &op_cache() {
 size_t op_bytes(const olap_shard_drillup *op) {
   size_t total = 0;
   for (int p = 0; p < op->recipe.n_payloads; ++p) total += (size_t)(op->n_send + recv_cells(op, p)) * payload_size(op, p);
-  if (op->recipe.finish == OLAP_FINISH_COMBINE) total += (size_t)op->n_out * (olap_dtype_size(op->dtype) + 4);
+  if (separate_result(op->recipe.finish)) total += (size_t)op->n_out * (olap_dtype_size(op->dtype) + 4);
   return total * op->depth * op->ranks.size();
 }
 }  // namespace

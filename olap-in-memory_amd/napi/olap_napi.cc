@@ -139,10 +139,12 @@ static napi_value StoreNew(napi_env env, napi_callback_info info) {
   napi_valuetype t;
   NAPI_OK(napi_typeof(env, argv[0], &t));
   olap_store *s = nullptr;
+  bool adopted = false;  // the handle came from wrap_new_store(), which destroys it itself when this constructor fails
   if (argc == 1 && t == napi_external) {
     void *p;
     NAPI_OK(napi_get_value_external(env, argv[0], &p));
     s = (olap_store *)p;
+    adopted = true;
   } else {
     double size = 0;
     int32_t dtype = 0, def = 0;
@@ -159,7 +161,7 @@ static napi_value StoreNew(napi_env env, napi_callback_info info) {
   }
   StoreBox *box = new StoreBox{s, nullptr, false};
   if (napi_wrap(env, self, box, finalize_store, nullptr, &box->ref) != napi_ok) {
-    olap_store_destroy(s);
+    if (!adopted) olap_store_destroy(s);
     delete box;
     napi_throw_error(env, nullptr, "napi_wrap failed");
     return nullptr;
@@ -771,11 +773,13 @@ static napi_value ShardedNew(napi_env env, napi_callback_info info) {
   NAPI_OK(napi_typeof(env, argv[0], &t));
   olap_sharded_store *s = nullptr;
   CommRef *comm = nullptr;
+  bool adopted = false;  // the handle came from wrap_new_sharded(), which destroys it itself when this constructor fails
   if (argc == 1 && t == napi_external) {
     void *p;
     NAPI_OK(napi_get_value_external(env, argv[0], &p));
     s = ((ShardedInit *)p)->store;
     comm = ((ShardedInit *)p)->comm;
+    adopted = true;
   } else {
     if (!g_comm) {
       napi_throw_error(env, nullptr, "sharded: no device list; call setDevices([...]) first");
@@ -795,7 +799,7 @@ static napi_value ShardedNew(napi_env env, napi_callback_info info) {
   ShardedBox *box = new ShardedBox{s, comm, sharded_bytes(s)};
   comm->refs++;
   if (napi_wrap(env, self, box, finalize_sharded, nullptr, nullptr) != napi_ok) {
-    olap_sharded_store_destroy(s);
+    if (!adopted) olap_sharded_store_destroy(s);
     comm_release(comm);
     delete box;
     napi_throw_error(env, nullptr, "napi_wrap failed");

@@ -26,6 +26,7 @@ from .capi import check
 from .hipstore import HipStore, Plan, _default_kind, _method_code, _tables, _u32
 
 NP_OF_DTYPE = {0: np.int32, 1: np.uint32, 2: np.float32, 3: np.float64}
+NAME_OF_DTYPE = {0: "int32", 1: "uint32", 2: "float32", 3: "float64"}
 
 
 def partition_rows(n_rows, world):

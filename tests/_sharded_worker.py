@@ -86,14 +86,21 @@ def rehearse_dim0_drillup(full, lens, dtype, default, row_map, n_groups, method,
     if hi > lo:
         o = oracle_of(slab, dtype, default)
         if rec["local_method"] == capi.PARTIAL_AVERAGE:
-            tv, ts = o.drill_up(local_lens, new_len, maps, "sum").typed()
-            ones = oracle_of(np.where(o.dense()[1], 1.0, 0.0), "float64", 0.0)
+            # the float64 ACCUMULATOR of the rank (never rounded to the cell type), 0 where nothing contributed
+            cells, present = o.dense()
+            acc = oracle_of(np.where(present, cells, default), "float64", default)
+            pv, pset = acc.drill_up(local_lens, new_len, maps, "sum").dense()
+            tv = np.where(pset, pv, 0.0)
+            ones = oracle_of(np.where(present, 1.0, 0.0), "float64", 0.0)
             flag = ones.drill_up(local_lens, new_len, maps, "sum").dense()[0].astype(np.int32)  # contribution counts
         else:
             names = {v: k for k, v in capi.METHODS.items()}
             tv, flag = o.drill_up(local_lens, new_len, maps, names[rec["local_method"]]).typed()
+    elif rec["local_method"] == capi.PARTIAL_AVERAGE:
+        tv, flag = np.zeros(n_out, np.float64), np.zeros(n_out, np.int32)
     else:
         tv, flag = np.full(n_out, default_typed(dtype, default_nan)), np.zeros(n_out, np.int32)
+    assert tv.dtype == NP[sharded.NAME_OF_DTYPE[rec["payload_dtype"][0]]], (tv.dtype, rec)
     if rec["zero_unset"]:
         tv = np.where((flag != 0) & ~np.isnan(tv.astype(np.float64)), tv, NP[dtype](0)).astype(NP[dtype])
     payloads = [tv, flag][: rec["n_payloads"]]
@@ -114,14 +121,19 @@ def rehearse_dim0_drillup(full, lens, dtype, default, row_map, n_groups, method,
         is_set = ((fl & 2) != 0) & ~is_default(v, dtype, default_nan)
         v = np.where(is_set, v, default_typed(dtype, default_nan)).astype(NP[dtype])
         st = np.where(is_set, 2, 0).astype(np.int32)
-    elif rec["finish"] == capi.FINISH_AVERAGE:
-        v, counts = got[0].astype(np.float64), got[1]
-        c16 = counts & 0xFFFF
-        has = (counts != 0) & ~is_default(got[0], dtype, default_nan)
+    elif rec["finish"] in (capi.FINISH_AVERAGE, capi.FINISH_ROUND):
+        # float64 sums added over the ranks (+ contribution counts), rounded to the cell type ONCE
+        r = got[0]
+        assert r.dtype == np.float64
+        counts = got[1] if rec["n_payloads"] > 1 else np.ones(r.size, np.int32)
         d = np.nan if default_nan else 0.0
-        with np.errstate(invalid="ignore", divide="ignore"):
-            r = np.where(c16 != 0, np.where(has, v, d) / np.maximum(c16, 1), v)
-        has = np.where(c16 != 0, ~(np.isnan(r) if default_nan else (r == 0)), has)
+        def64 = (lambda x: np.isnan(x)) if default_nan else (lambda x: x == 0)
+        has = (counts != 0) & ~def64(r)
+        if rec["finish"] == capi.FINISH_AVERAGE:
+            c16 = counts & 0xFFFF
+            with np.errstate(invalid="ignore", divide="ignore"):
+                r = np.where(c16 != 0, np.where(has, r, d) / np.maximum(c16, 1), r)
+            has = np.where(c16 != 0, ~def64(r), has)
         tvv = to_typed(np.where(has, r, d), dtype)
         is_set = has & ~is_default(tvv, dtype, default_nan)
         v = np.where(is_set, tvv, default_typed(dtype, default_nan)).astype(NP[dtype])

@@ -23,6 +23,25 @@ CASES = {
                              literal=[1, np.nan, 2, np.nan, np.nan, np.nan, np.nan, 3, np.nan, np.nan, 4, 3]),
     # more ranks than rows on some worlds; one group per row pair
     "f32_zero_short": dict(lens=[2, 5], dtype="float32", default=0.0, row_map=[0, 0], groups=1, frac=0.8, seed=18),
+    # the round-2 failure: cancellation ACROSS ranks.  The reference adds every contribution in
+    # float64 (in-memory.js:282-290), so 2^24 + 1 - 2^24 = 1 and the cell is set; partials rounded to Float32 per rank
+    # gave 0 and unset (2^24 + 1 rounds to 2^24).  Rows split 2 + 2 (two ranks) and 2 + 1 + 1 (three).
+    "f32_cancel": dict(lens=[4, 1], dtype="float32", default=0.0, row_map=[0, 0, 0, 0], groups=1,
+                       literal=[16777216.0, 1.0, -16777216.0, 0.0]),
+    "f32_cancel_nan": dict(lens=[4, 3], dtype="float32", default=float("nan"), row_map=[0, 0, 0, 0], groups=1,
+                           literal=[16777216.0, np.nan, 3.0, 1.0, np.nan, 2.0 ** -30, -16777216.0, np.nan, -3.0, np.nan, np.nan, np.nan]),
+    # integer sums pass 2^32 inside the float64 accumulator: `sum` wraps modulo 2^32 at storage on every path, `average`
+    # divides the exact sum first (4e9 + 4e9 over two cells is 4e9, not (8e9 mod 2^32) / 2)
+    "u32_average_overflow": dict(lens=[4, 2], dtype="uint32", default=0.0, row_map=[0, 0, 0, 0], groups=1,
+                                 literal=[4e9, 1.0, 4e9, 0.0, 4e9, 3.0, 0.0, 7.0], skip=("product",)),
+    # a wide cube: the row regime with 16-byte lanes writes its float64 partials as two 16-byte stores per lane
+    "f32_zero_wide": dict(lens=[6, 1024], dtype="float32", default=0.0, row_map=[0, 1, 0, 1, 1, 0], groups=2, frac=0.9, seed=19,
+                          only=("sum", "average")),
+    "f32_nan_ragged": dict(lens=[5, 1031], dtype="float32", default=float("nan"), row_map=[0, 0, 1, 0, 1], groups=2, frac=0.7, seed=20,
+                           only=("sum", "average")),
+    # few outputs, long groups: the cooperative reduce regime emits the partials from its merge kernels
+    "f32_zero_tall": dict(lens=[3000, 3], dtype="float32", default=0.0, row_map=[0] * 3000, groups=1, frac=0.9, seed=21,
+                          only=("sum", "average")),
 }
 
 
@@ -40,10 +59,19 @@ def case_data(case):
         lo = 0 if case["dtype"] == "uint32" else -4
         v = rng.integers(lo, 6, size=n).astype(np.float64)
     else:
-        v = rng.integers(-8, 9, size=n).astype(np.float64) / 4.0  # sums are exact in float32 whatever the order
+        # Float32-representable cells of mixed sign and magnitude, m * 2^-e with |m| < 2^24 and e in 0..20: their sums are
+        # NOT exact in Float32 (the partials of a rank round differently from the whole), but every sum of fewer than 2^8
+        # of them is a multiple of 2^-20 below 2^32 — exact in float64 in ANY order.  So a sharded sum / average that
+        # keeps float64 partials and rounds once agrees with the one-device result and the oracle BIT FOR BIT.
+        m = rng.integers(-(2 ** 24) + 1, 2 ** 24, size=n).astype(np.float64)
+        e = rng.integers(0, 21, size=n)
+        if n > 10000:  # (tall cubes add thousands of cells per output: keep |sum| * 2^20 < 2^53)
+            m = rng.integers(-(2 ** 16) + 1, 2 ** 16, size=n).astype(np.float64)
+        v = m * np.exp2(-e.astype(np.float64))
+        assert np.array_equal(v.astype(np.float32).astype(np.float64), v)
     keep = rng.random(n) < case["frac"]
     return np.where(keep, v, np.nan if default_nan else 0.0)
 
 
 def methods_of(case):
-    return [m for m in METHODS if m not in case.get("skip", ())]
+    return [m for m in METHODS if m not in case.get("skip", ()) and m in case.get("only", METHODS)]

@@ -205,3 +205,28 @@ def test_sharded_entry_points_validate_before_the_device():
     if L.olap_device_count() == 0:
         expect(capi.ERR_NO_DEVICE, "no CPU fallback", sharded.Comm.init_all, [0, 0])
         expect(capi.ERR_NO_DEVICE, "no CPU fallback", sharded.Comm.detached, 2, 0, 0)
+
+
+def test_rccl_that_cannot_be_loaded_is_an_error_not_a_crash():
+    """ADVICE r02 (medium): the loader read dlerror() twice — the second call returns NULL — and built a std::string from
+    it: a host without librccl crashed inside olap_comm_unique_id instead of reporting OLAP_ERR_NO_DEVICE, which is what
+    Comm.from_process_group and bench.py's labelled gloo rehearsal rely on.  OLAP_RCCL_LIB names the library to bind."""
+    import subprocess
+    import sys
+    code = (
+        "import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "from conftest import load_package\n"
+        "pkg = load_package(); capi = pkg.capi\n"
+        "from olap_in_memory_amd.sharded import Comm\n"
+        "for attempt in range(2):\n"  # the failure is remembered, not re-raised as a crash the second time
+        "    try:\n"
+        "        Comm.unique_id()\n"
+        "        print('no error'); break\n"
+        "    except capi.OlapError as e:\n"
+        "        print('code', e.code, str(e))\n"
+    ) % (os.path.join(ROOT, "tests"), ROOT)
+    env = dict(os.environ, OLAP_RCCL_LIB="/nonexistent/librccl.so.1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout
+    lines = [l for l in r.stdout.splitlines() if l.startswith("code")]
+    assert len(lines) == 2 and all(("code %d " % capi.ERR_NO_DEVICE) in l and "cannot load RCCL" in l and "/nonexistent/librccl.so.1" in l for l in lines), r.stdout

@@ -67,14 +67,27 @@ def check_dim0(results):
             assert np.array_equal(gs, es), what + ": status mask (must be 0 / 0x2 everywhere, OR-ed across ranks)"
             assert set(np.unique(gs)) <= {0, 2}, what
             e64 = ev.astype(np.float64)
-            if method in ("sum", "average", "product") and case["dtype"].startswith("float"):
-                # partials are rounded to the cell type per rank and combined in another order: 1e-5 relative (north star)
+            if method == "product" and case["dtype"].startswith("float"):
+                # the gathered partial products are rounded to the cell type per rank: 1e-5 relative (north star)
                 assert np.allclose(gv, e64, rtol=1e-5, atol=0, equal_nan=True), what
             else:
+                # sum / average: float64 partials, added in float64, rounded ONCE — and the case data are chosen so that
+                # float64 addition is exact in any order (sharded_cases.case_data): bit for bit the one-device result
                 assert np.array_equal(gv, e64, equal_nan=True), what
     # the round-1 failure, spelled out
     gv, gs = assemble(results, "f32_nan_disjoint/sum", 3)
     assert gv.tolist() == [1.0, 7.0, 5.0] and gs.tolist() == [2, 2, 2]
+    # the round-2 failure, spelled out: [2^24, 1 | -2^24, unset] must give 1 / set, its average 1/3 / set
+    gv, gs = assemble(results, "f32_cancel/sum", 1)
+    assert gv.tolist() == [1.0] and gs.tolist() == [2]
+    gv, gs = assemble(results, "f32_cancel/average", 1)
+    assert gv.tolist() == [float(np.float32(1.0 / 3.0))] and gs.tolist() == [2]
+    gv, gs = assemble(results, "f32_cancel_nan/sum", 3)
+    assert gv[0] == 1.0 and np.isnan(gv[1]) and gv[2] == 2.0 ** -30 and gs.tolist() == [2, 0, 2]
+    gv, gs = assemble(results, "u32_average_overflow/average", 2)
+    assert gv.tolist() == [4e9, float(np.uint32(11 / 3))] and gs.tolist() == [2, 2]
+    gv, gs = assemble(results, "u32_average_overflow/sum", 2)
+    assert gv.tolist() == [float(np.uint32(12e9 % 2 ** 32)), 11.0]
 
 
 def test_partition_and_recipe_host_only():
@@ -88,14 +101,25 @@ def test_partition_and_recipe_host_only():
     with pytest.raises(capi.OlapError, match="sharded:"):
         dice_bounds([0, 4, 7], [2, 1])
     nan = float("nan")
+    f32, f64 = capi.DTYPES["float32"], capi.DTYPES["float64"]
+    # Float32 sums ship the rank's float64 accumulator and are rounded once (in-memory.js:282-290 never rounds in between)
     r = recipe("float32", 0.0, "sum")
-    assert (r["n_payloads"], r["payload_op"][0], r["finish"], r["zero_unset"]) == (1, capi.XCHG_SUM, capi.FINISH_NONE, False)
-    r = recipe("float32", nan, "sum")  # NaN never enters an additive collective; masks are OR-ed, not added
+    assert (r["local_method"], r["n_payloads"], r["payload_dtype"][0], r["payload_op"][0], r["finish"], r["zero_unset"]) == \
+        (capi.PARTIAL_AVERAGE, 1, f64, capi.XCHG_SUM, capi.FINISH_ROUND, False)
+    r = recipe("float32", nan, "sum")  # NaN never enters an additive collective: unset partial cells ship 0, counts say who contributed
+    assert (r["local_method"], r["n_payloads"], r["payload_dtype"], r["payload_op"], r["finish"], r["zero_unset"]) == \
+        (capi.PARTIAL_AVERAGE, 2, [f64, capi.DTYPES["int32"]], [capi.XCHG_SUM, capi.XCHG_SUM], capi.FINISH_ROUND, False)
+    r = recipe("float64", 0.0, "sum")  # float64 cells are their own accumulator
+    assert (r["local_method"], r["n_payloads"], r["payload_dtype"][0], r["finish"]) == (capi.METHODS["sum"], 1, f64, capi.FINISH_NONE)
+    r = recipe("float64", nan, "sum")  # masks are OR-ed (MAX), not added
     assert (r["n_payloads"], r["payload_op"], r["finish"], r["zero_unset"]) == (2, [capi.XCHG_SUM, capi.XCHG_MAX], capi.FINISH_RESTORE, True)
-    r = recipe("int32", nan, "sum")
-    assert (r["n_payloads"], r["payload_op"][1], r["zero_unset"]) == (2, capi.XCHG_MAX, False)
-    r = recipe("float32", nan, "average")
-    assert (r["local_method"], r["payload_op"], r["finish"], r["zero_unset"]) == (capi.PARTIAL_AVERAGE, [capi.XCHG_SUM, capi.XCHG_SUM], capi.FINISH_AVERAGE, True)
+    r = recipe("int32", nan, "sum")  # integer sums are exact modulo 2^32 on every path
+    assert (r["n_payloads"], r["payload_dtype"][0], r["payload_op"][1], r["zero_unset"]) == (2, capi.DTYPES["int32"], capi.XCHG_MAX, False)
+    for dt in ("float32", "float64", "int32", "uint32"):
+        r = recipe(dt, nan, "average")
+        assert (r["local_method"], r["payload_dtype"][0], r["payload_op"], r["finish"], r["zero_unset"]) == \
+            (capi.PARTIAL_AVERAGE, f64, [capi.XCHG_SUM, capi.XCHG_SUM], capi.FINISH_AVERAGE, False)
+    assert f32 != f64
     for m in ("highest", "lowest", "first", "last", "product"):
         assert recipe("float32", nan, m)["n_payloads"] == 1 and recipe("int32", nan, m)["n_payloads"] == 2
         assert recipe("float32", 0.0, m)["finish"] == capi.FINISH_COMBINE
@@ -128,9 +152,9 @@ def test_sharded_store_shared_gpu(tmp_path, world):
     results = run_workers("hip", tmp_path, world)
     check_dim0(results)
     case = CASES["f32_zero"]
-    for method in ("sum", "average"):  # the whole-result placement agrees with the scattered one
+    for method in ("sum", "average"):  # the whole-result placement agrees with the scattered one, bit for bit
         ev, _ = expected_dim0(case, method)
-        assert np.allclose(results[0]["f32_zero/%s/all" % method]["values"], ev.astype(np.float64), rtol=1e-5, atol=0)
+        assert np.array_equal(np.asarray(results[0]["f32_zero/%s/all" % method]["values"]), ev.astype(np.float64))
     lens = case["lens"]
     o = OracleStore(420, "float32", 0.0)
     o.set_data(case_data(case))
