@@ -1315,11 +1315,12 @@ extern "C" int olap_load_plan(olap_plan **out, int dtype, int my_default_kind, i
     }
     stride *= my_len[d];
   }
-  if ((rc = finish_remap(p, dims, p->in_cells, false))) {
+  // (16-byte lanes when the innermost merged run is contiguous in both stores: finish_remap checks it)
+  if ((rc = finish_remap(p, dims, p->in_cells, true))) {
     olap_plan_destroy(p);
     return rc;
   }
-  p->kernel_name = "load_scatter";
+  p->kernel_name = p->vec > 1 ? "load_scatter (16-byte lanes)" : "load_scatter";
   *out = p;
   return OLAP_OK;
 }
@@ -1573,9 +1574,16 @@ static int run_typed(olap_plan *p, const void *in_v, const int32_t *in_s, void *
       e = Launch<T>::gather(hs, vec, in, in_s, out, out_s, r, stream);
       break;
     }
-    case PLAN_LOAD:
-      e = Launch<T>::load_scatter(hs, in, in_s, out, out_s, p->remap, stream);
+    case PLAN_LOAD: {
+      Remap r = p->remap;
+      int vec = p->vec;
+      if (vec > 1 && !(aligned16(in) && aligned16(out) && (!in_s || aligned16(in_s)) && (!out_s || aligned16(out_s)))) {
+        r.total *= (uint64_t)vec;
+        vec = 1;
+      }
+      e = Launch<T>::load_scatter(hs, vec, in, in_s, out, out_s, r, stream);
       break;
+    }
     case PLAN_BRICK:
       e = Launch<T>::reorder_brick(hs, in, in_s, out, out_s, p->brick, p->n_bricks, stream);
       break;

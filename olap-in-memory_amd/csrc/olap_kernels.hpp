@@ -1701,8 +1701,11 @@ __global__ __launch_bounds__(kBlock) void gather_reduce_kernel(const T *__restri
 
 // load (in-memory.js:139-176): iterate the SOURCE (the other store, dense over all its cells,
 // see the comment at :152-158), scatter into this store with setValue semantics:
-// mine.setValue(myIdx, his.getValue(hisIdx)).
-template <typename T, bool HAS_STATUS>
+// mine.setValue(myIdx, his.getValue(hisIdx)).  The plan merges the dimensions the load leaves alone into arithmetic
+// strides; a lane moves VEC cells (16 bytes) when the innermost merged run is contiguous on both sides, the source is
+// streamed (every cell is read exactly once), and the index is decoded in 32-bit arithmetic when the other cube has
+// fewer than 2^32 cells (a 64-bit division is a long software sequence on CDNA).
+template <typename T, bool HAS_STATUS, int VEC, typename IDX>
 __global__ __launch_bounds__(kBlock) void load_scatter_kernel(const T *__restrict__ his,
                                                               const int32_t *__restrict__ his_st,
                                                               T *__restrict__ mine,
@@ -1710,13 +1713,15 @@ __global__ __launch_bounds__(kBlock) void load_scatter_kernel(const T *__restric
   const uint64_t t = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
   if (t >= r.total) return;
   const bool def_nan = r.def_nan != 0, his_nan = r.src_def_nan != 0;
-  uint64_t c = t, dst = 0;
+  IDX c = (IDX)(t * VEC);
+  uint64_t dst = 0;
   bool ok = true;
 #pragma unroll
   for (int d = kMaxDims - 1; d >= 0; --d) {
     if (d < r.nd) {
-      const uint32_t digit = (uint32_t)(c % r.len[d]);
-      c /= r.len[d];
+      const IDX q = c / (IDX)r.len[d];
+      const uint32_t digit = (uint32_t)(c - q * (IDX)r.len[d]);
+      c = q;
       if (r.tab_off[d] < 0) {
         dst += (uint64_t)digit * r.stride[d];
       } else {
@@ -1726,25 +1731,34 @@ __global__ __launch_bounds__(kBlock) void load_scatter_kernel(const T *__restric
       }
     }
   }
-  if (!ok) return;
-  const T x = his[t];
-  const bool his_set = cell_is_set<T>(x, HAS_STATUS ? his_st[t] : OLAP_STATUS_SET, HAS_STATUS, his_nan);
-  // getValue: the stored value or HIS default; then setValue against MY default.  For integer
-  // cells a NaN default has no typed representation: an unset source cell unsets the target.
-  bool set;
-  T v;
-  if (his_set) {
-    v = x;
-    set = !Cell<T>::is_default(v, def_nan);
-  } else {
-    // his.getValue() hands out HIS default (:119), which my setValue keeps unless it is MY default
-    // (:122-133): 0 under my NaN default is a set cell; NaN under my 0 default is one for float cells
-    v = Cell<T>::default_value(his_nan);
-    constexpr bool is_float = (Cell<T>::dtype == OLAP_FLOAT32 || Cell<T>::dtype == OLAP_FLOAT64);
-    set = his_nan ? (is_float && !def_nan) : def_nan;
+  if (!ok) return;  // an item this store does not have: its cells are not loaded
+  const Vec<T, VEC> x = load_stream<T, VEC>(his + t * VEC);
+  Vec<int32_t, VEC> xs;
+  if constexpr (HAS_STATUS) xs = load_stream<int32_t, VEC>(his_st + t * VEC);
+  Vec<T, VEC> ov;
+  Vec<int32_t, VEC> os;
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) {
+    const bool his_set = cell_is_set<T>(x.v[e], HAS_STATUS ? xs.v[e] : OLAP_STATUS_SET, HAS_STATUS, his_nan);
+    // getValue: the stored value or HIS default; then setValue against MY default.  For integer
+    // cells a NaN default has no typed representation: an unset source cell unsets the target.
+    bool set;
+    T v;
+    if (his_set) {
+      v = x.v[e];
+      set = !Cell<T>::is_default(v, def_nan);
+    } else {
+      // his.getValue() hands out HIS default (:119), which my setValue keeps unless it is MY default
+      // (:122-133): 0 under my NaN default is a set cell; NaN under my 0 default is one for float cells
+      v = Cell<T>::default_value(his_nan);
+      constexpr bool is_float = (Cell<T>::dtype == OLAP_FLOAT32 || Cell<T>::dtype == OLAP_FLOAT64);
+      set = his_nan ? (is_float && !def_nan) : def_nan;
+    }
+    ov.v[e] = set ? v : Cell<T>::default_value(def_nan);
+    os.v[e] = set ? OLAP_STATUS_SET : 0;
   }
-  mine[dst] = set ? v : Cell<T>::default_value(def_nan);
-  if (mine_st) mine_st[dst] = set ? OLAP_STATUS_SET : 0;
+  store_stream<T, VEC>(mine + dst, ov);
+  if (mine_st) store_stream<int32_t, VEC>(mine_st + dst, os);
 }
 
 // ======================================================================= K4: reorder as a brick transpose
@@ -2885,7 +2899,7 @@ struct Launch {
                                   int32_t *st_out, const GatherReduce &a, hipStream_t stream);
   static hipError_t reorder_brick(bool has_status, const T *in, const int32_t *st_in, T *out, int32_t *st_out,
                                   const Brick &b, uint64_t n_bricks, hipStream_t stream);
-  static hipError_t load_scatter(bool has_status, const T *his, const int32_t *his_st, T *mine, int32_t *mine_st,
+  static hipError_t load_scatter(bool has_status, int vec, const T *his, const int32_t *his_st, T *mine, int32_t *mine_st,
                                  const Remap &r, hipStream_t stream);
   static hipError_t drilldown(bool has_status, const T *in, const int32_t *st_in, T *out, int32_t *st_out,
                               const DrillDown &a, hipStream_t stream);
@@ -3422,12 +3436,22 @@ hipError_t Launch<T>::reorder_brick(bool has_status, const T *in, const int32_t 
 }
 
 template <typename T>
-hipError_t Launch<T>::load_scatter(bool has_status, const T *his, const int32_t *his_st, T *mine, int32_t *mine_st,
+hipError_t Launch<T>::load_scatter(bool has_status, int vec, const T *his, const int32_t *his_st, T *mine, int32_t *mine_st,
                                    const Remap &r, hipStream_t stream) {
   if (r.total == 0) return hipSuccess;
   const unsigned grid = grid_for(r.total);
-  if (has_status) hipLaunchKernelGGL((load_scatter_kernel<T, true>), grid, kBlock, 0, stream, his, his_st, mine, mine_st, r);
-  else hipLaunchKernelGGL((load_scatter_kernel<T, false>), grid, kBlock, 0, stream, his, his_st, mine, mine_st, r);
+  const bool idx32 = r.total * (uint64_t)vec < 0xFFFFFFFFull;
+#define OLAP_LD(HS, V)                                                                                                              \
+  do {                                                                                                                              \
+    if (idx32) hipLaunchKernelGGL((load_scatter_kernel<T, HS, V, uint32_t>), grid, kBlock, 0, stream, his, his_st, mine, mine_st, r); \
+    else hipLaunchKernelGGL((load_scatter_kernel<T, HS, V, uint64_t>), grid, kBlock, 0, stream, his, his_st, mine, mine_st, r);       \
+  } while (0)
+  if (has_status) {
+    if (vec == 4) OLAP_LD(true, 4); else if (vec == 2) OLAP_LD(true, 2); else OLAP_LD(true, 1);
+  } else {
+    if (vec == 4) OLAP_LD(false, 4); else if (vec == 2) OLAP_LD(false, 2); else OLAP_LD(false, 1);
+  }
+#undef OLAP_LD
   return hipGetLastError();
 }
 

@@ -14,9 +14,14 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cmath>
+#include <condition_variable>
 #include <cstring>
+#include <functional>
 #include <mutex>
+#include <thread>
 #include <new>
 #include <string>
 #include <unordered_map>
@@ -116,6 +121,8 @@ ncclDataType_t nccl_sum_type(int dtype) { return dtype == OLAP_INT32 ? ncclUint3
 enum Transport { TRANSPORT_RCCL = 0, TRANSPORT_DIRECT = 1, TRANSPORT_DETACHED = 2 };
 }  // namespace
 
+struct ShardWorkers;  // one issuing thread per local rank (below)
+
 struct olap_comm {
   struct Local {
     int rank = 0;
@@ -126,7 +133,10 @@ struct olap_comm {
   int world = 1;
   int transport = TRANSPORT_DETACHED;
   std::vector<Local> local;
+  ShardWorkers *workers = nullptr;  // one process, several devices: who issues each rank's part of a step
 };
+static void comm_start_workers(olap_comm *c);
+static void comm_stop_workers(olap_comm *c);
 
 static int comm_make_streams(olap_comm *c) {
   DeviceGuard guard;
@@ -237,6 +247,7 @@ extern "C" int olap_comm_init_all(olap_comm **comm, const int *devices, int n) {
     olap_comm_destroy(c);
     return rc;
   }
+  comm_start_workers(c);
   *comm = c;
   return OLAP_OK;
 }
@@ -267,6 +278,7 @@ static void drop_cached_steps(const olap_comm *comm);
 extern "C" void olap_comm_destroy(olap_comm *c) {
   if (!c) return;
   drop_cached_steps(c);  // steps the store handles keep for this communicator
+  comm_stop_workers(c);
   DeviceGuard guard;
   Rccl *r = c->transport == TRANSPORT_RCCL ? rccl() : nullptr;
   for (auto &l : c->local) {
@@ -329,7 +341,7 @@ extern "C" int olap_shard_recipe_get(int dtype, int default_kind, int method, ol
   const bool primary = def_nan && !is_float_dtype(dtype);  // the mask carries information the values cannot
   rc->payload_dtype[0] = dtype;
   rc->payload_dtype[1] = OLAP_INT32;
-  if (method == OLAP_SUM && dtype == OLAP_FLOAT32) {
+  if (method == OLAP_SUM && is_float_dtype(dtype)) {
     // The reference adds every contribution of an output cell in float64 and never rounds in between
     // (in-memory.js:282-290, :311-318); so do the one-device kernels.  A partial rounded to Float32 before the ranks
     // are added breaks that under cancellation ([2^24, 1 | -2^24] -> 0 and unset instead of 1 and set), so each rank
@@ -341,16 +353,15 @@ extern "C" int olap_shard_recipe_get(int dtype, int default_kind, int method, ol
     rc->n_payloads = def_nan ? 2 : 1;  // 0 default: set <=> the rounded sum != 0; NaN default: somebody contributed
     rc->finish = OLAP_FINISH_ROUND;
   } else if (method == OLAP_SUM) {
-    // float64 cells are their own accumulator; integer cells are added modulo 2^32 on every path (exact)
+    // integer cells are added modulo 2^32 on every path (exact): the typed partials travel
     rc->local_method = OLAP_SUM;
     rc->payload_op[0] = OLAP_XCHG_SUM;
     if (!def_nan) {  // set <=> value != 0: a rank without contributions ships 0, the neutral element
       rc->n_payloads = 1;
       rc->finish = OLAP_FINISH_NONE;
-    } else {  // NaN must never enter an additive collective; the masks are OR-ed (MAX of 0 / 0x2)
+    } else {  // the mask is primary (no integer equals NaN): the masks are OR-ed (MAX of 0 / 0x2), never added
       rc->n_payloads = 2;
       rc->payload_op[1] = OLAP_XCHG_MAX;
-      rc->zero_unset = is_float_dtype(dtype);
       rc->finish = OLAP_FINISH_RESTORE;
     }
   } else if (method == OLAP_AVERAGE) {
@@ -374,47 +385,53 @@ extern "C" int olap_shard_recipe_get(int dtype, int default_kind, int method, ol
 
 // ------------------------------------------------------------------ small kernels of the exchange
 namespace {
-// unset partial cells are shipped as 0 (float cells over a NaN default would poison a sum)
+// after a SUM of partials + MAX of masks (integer cells over a NaN default): cells nobody contributed to get the
+// default back.  flags == nullptr: the mask is a function of the values (set <=> value != default).  In place
+// (src == dst, flags == dst_status) or into a destination of its own.
 template <typename T>
-__global__ __launch_bounds__(kBlock) void zero_unset_kernel(T *values, const int32_t *flags, uint64_t n) {
+__global__ __launch_bounds__(kBlock) void restore_default_kernel(const T *src, const int32_t *flags, T *dst, int32_t *dst_status, uint64_t n,
+                                                                 int def_nan) {
   for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kBlock) {
-    const T v = values[i];
-    values[i] = (flags[i] != 0 && v == v) ? v : T(0);
+    const T v = src[i];
+    const bool set = (!flags || (flags[i] & OLAP_STATUS_SET) != 0) && !Cell<T>::is_default(v, def_nan != 0);
+    dst[i] = set ? v : Cell<T>::default_value(def_nan != 0);
+    if (dst_status) dst_status[i] = set ? OLAP_STATUS_SET : 0;
   }
 }
-// after a SUM of zeroed partials + MAX of masks: cells nobody contributed to get the default back
-template <typename T>
-__global__ __launch_bounds__(kBlock) void restore_default_kernel(T *values, int32_t *flags, uint64_t n, int def_nan) {
-  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kBlock) {
-    const bool set = (flags[i] & OLAP_STATUS_SET) != 0 && !Cell<T>::is_default(values[i], def_nan != 0);
-    if (!set) values[i] = Cell<T>::default_value(def_nan != 0);
-    flags[i] = set ? OLAP_STATUS_SET : 0;
-  }
-}
-// float64 partial sums (+ contribution counts) added over the ranks -> typed cells, rounded ONCE.  Mirrors what the
-// one-device kernels do with their accumulator: Agg::finish (in-memory.js:323-331: divide by the Uint16 counter unless
-// it wrapped to 0) and emit_cell.  counts == nullptr: a sum over a 0 default, where "somebody contributed" does not
-// matter (set <=> the rounded sum is not 0).
-template <typename T>
-__global__ __launch_bounds__(kBlock) void partial_round_kernel(const double *sums, const int32_t *counts, T *values, int32_t *status,
-                                                               uint64_t n, int def_nan_i, int average) {
-  const bool def_nan = def_nan_i != 0;
-  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kBlock) {
-    double r = sums[i];
-    const uint32_t c = counts ? (uint32_t)counts[i] : 1u;
+// One output cell from the payloads added over the ranks.  FINISH_ROUND / _AVERAGE: float64 partial sums (+ contribution
+// counts) -> typed cell, rounded ONCE — what the one-device kernels do with their accumulator: Agg::finish
+// (in-memory.js:323-331: divide by the Uint16 counter unless it wrapped to 0), then emit_cell.  Without counts (a sum
+// over a 0 default) "somebody contributed" does not matter: set <=> the rounded sum is not 0.
+template <typename T, typename P>
+__device__ __forceinline__ void finish_cell(int finish, P a, uint32_t b, bool has_b, bool def_nan, T &ov, int32_t &os) {
+  if (finish == OLAP_FINISH_ROUND || finish == OLAP_FINISH_AVERAGE) {
+    double r = (double)a;
+    const uint32_t c = has_b ? b : 1u;
     bool has = c != 0 && !is_default_f64(r, def_nan);
-    if (average) {
+    if (finish == OLAP_FINISH_AVERAGE) {
       const uint32_t c16 = c & 0xFFFFu;  // Uint16Array counter
       if (c16) {
         r = (has ? r : (def_nan ? __builtin_nan("") : 0.0)) / (double)c16;
         has = !is_default_f64(r, def_nan);
       }
     }
+    emit_cell<T>(r, has, def_nan, ov, os);
+  } else {  // FINISH_NONE / FINISH_RESTORE: the payload is the typed cell (b: the OR of the masks)
+    const T v = (T)a;
+    const bool set = (!has_b || (b & OLAP_STATUS_SET) != 0) && !Cell<T>::is_default(v, def_nan);
+    ov = set ? v : Cell<T>::default_value(def_nan);
+    os = set ? OLAP_STATUS_SET : 0;
+  }
+}
+template <typename T>
+__global__ __launch_bounds__(kBlock) void partial_round_kernel(const double *sums, const int32_t *counts, T *values, int32_t *status,
+                                                               uint64_t n, int def_nan_i, int finish) {
+  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kBlock) {
     T ov;
     int32_t os;
-    emit_cell<T>(r, has, def_nan, ov, os);
+    finish_cell<T, double>(finish, sums[i], counts ? (uint32_t)counts[i] : 0u, counts != nullptr, def_nan_i != 0, ov, os);
     values[i] = ov;
-    status[i] = os;
+    if (status) status[i] = os;
   }
 }
 template <typename T>
@@ -422,17 +439,62 @@ __global__ __launch_bounds__(kBlock) void fill_default_kernel(T *values, uint64_
   for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kBlock)
     values[i] = Cell<T>::default_value(def_nan != 0);
 }
+// Integer partial sums are added modulo 2^32, as unsigned words (see nccl_sum_type)
+template <typename P> struct SumWord { typedef P type; };
+template <> struct SumWord<int32_t> { typedef uint32_t type; };
+
 // direct transport: dst[i] = op over the ranks q of src[q][first + i]
 template <typename T, int OP>
 __global__ __launch_bounds__(kBlock) void direct_combine_kernel(const T *const *src, int n_src, T *dst, uint64_t first, uint64_t n) {
+  typedef typename SumWord<T>::type W;
   for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kBlock) {
     T acc = src[0][first + i];
     for (int q = 1; q < n_src; ++q) {
       const T v = src[q][first + i];
-      if constexpr (OP == OLAP_XCHG_SUM) acc = acc + v;
+      if constexpr (OP == OLAP_XCHG_SUM) acc = (T)((W)acc + (W)v);
       else acc = v > acc ? v : acc;
     }
     dst[i] = acc;
+  }
+}
+
+// Direct transport, every rank on ONE device: the exchange and the finishing kernel of ALL ranks as one launch.  A
+// cell's payloads are added over the ranks in rank order (float64 partials: in float64), finished once, and written to
+// every destination whose block holds it (SCATTER: the owner's; ALL: everybody's; ROOT: rank 0's).
+constexpr int kFusedMaxRanks = 16;
+constexpr int kMaxBatchRanks = 8;  // pairs olap_plan_run_batch puts into one launch
+struct FusedDests {
+  int n;
+  void *values[kFusedMaxRanks];
+  int32_t *status[kFusedMaxRanks];
+  uint64_t first[kFusedMaxRanks], count[kFusedMaxRanks];
+};
+template <typename T, typename P>
+__global__ __launch_bounds__(kBlock) void direct_fused_kernel(const P *const *src0, const int32_t *const *src1, int world, int op1, uint64_t n_out,
+                                                              int finish, int def_nan, const FusedDests d) {
+  typedef typename SumWord<P>::type W;
+  for (uint64_t c = (uint64_t)blockIdx.x * kBlock + threadIdx.x; c < n_out; c += (uint64_t)gridDim.x * kBlock) {
+    W a = (W)src0[0][c];
+    for (int q = 1; q < world; ++q) a = a + (W)src0[q][c];
+    uint32_t b = 0;
+    if (src1) {
+      int32_t m = src1[0][c];
+      for (int q = 1; q < world; ++q) {
+        const int32_t v = src1[q][c];
+        m = op1 == OLAP_XCHG_SUM ? (int32_t)((uint32_t)m + (uint32_t)v) : (v > m ? v : m);
+      }
+      b = (uint32_t)m;
+    }
+    T ov;
+    int32_t os;
+    finish_cell<T, P>(finish, (P)a, b, src1 != nullptr, def_nan != 0, ov, os);
+    for (int j = 0; j < d.n; ++j) {
+      const uint64_t rel = c - d.first[j];
+      if (c >= d.first[j] && rel < d.count[j]) {
+        ((T *)d.values[j])[rel] = ov;
+        if (d.status[j]) d.status[j][rel] = os;
+      }
+    }
   }
 }
 
@@ -456,10 +518,138 @@ int launch_check(const char *what) {
 }
 }  // namespace
 
+// ------------------------------------------------------------------ one issuing thread per device
+// One process that drives n devices (the Node.js host: olap_comm_init_all) would otherwise issue every device's part
+// of a step from ONE thread — device switch, launch, collective, launch, n times over: at 8 devices several hundred
+// microseconds of host time against an 80 us slab.  Each local rank gets a worker thread that
+// made its device current once and issues its own rank's sequence; the caller's thread only hands the step over and
+// waits until every worker has ISSUED (not finished) its part.  Workers spin briefly after a step before they
+// sleep, so a burst of queries does not pay a wake-up per step.  OLAP_SHARD_THREADS=0 turns them off (everything is
+// issued by the calling thread), =1 also gives the ranks of the direct transport workers (tests: the hand-over, the
+// barrier and the error relay run on a one-GPU box).
+namespace {
+inline void cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+  __builtin_ia32_pause();
+#endif
+}
+}  // namespace
+
+struct ShardWorkers {
+  struct Slot {
+    int rc = 0;
+    std::string err;
+  };
+  int n = 0;
+  std::vector<std::thread> threads;
+  std::vector<Slot> slots;
+  std::mutex mu;
+  std::condition_variable cv_go, cv_done;
+  std::atomic<uint64_t> gen{0};
+  std::atomic<int> done{0};
+  std::atomic<int> arrived{0};
+  std::atomic<uint64_t> barrier_gen{0};
+  std::atomic<bool> stop{false};
+  const std::function<int(int)> *job = nullptr;
+  static constexpr int64_t kSpinNs = 200 * 1000;  // how long a worker (and the caller) spins before it sleeps
+
+  static int64_t now_ns() { return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+  void start(const std::vector<int> &devices) {
+    n = (int)devices.size();
+    slots.resize(n);
+    for (int i = 0; i < n; ++i) threads.emplace_back([this, i, dev = devices[i]] { loop(i, dev); });
+  }
+  ~ShardWorkers() {
+    {
+      std::lock_guard<std::mutex> lock(mu);
+      stop.store(true);
+      gen.fetch_add(1);
+    }
+    cv_go.notify_all();
+    for (auto &t : threads) t.join();
+  }
+  void loop(int i, int device) {
+    (void)hipSetDevice(device);
+    uint64_t seen = 0;
+    for (;;) {
+      const int64_t t0 = now_ns();
+      int polls = 0;
+      while (gen.load(std::memory_order_acquire) == seen) {
+        cpu_relax();
+        if ((++polls & 63) == 0 && now_ns() - t0 > kSpinNs) {
+          std::unique_lock<std::mutex> lock(mu);
+          cv_go.wait(lock, [&] { return gen.load(std::memory_order_acquire) != seen; });
+        }
+      }
+      if (stop.load()) return;
+      seen = gen.load(std::memory_order_acquire);
+      const int rc = (*job)(i);
+      slots[i].rc = rc;
+      if (rc) slots[i].err = olap_last_error();
+      if (done.fetch_add(1, std::memory_order_acq_rel) + 1 == n) {
+        std::lock_guard<std::mutex> lock(mu);
+        cv_done.notify_one();
+      }
+    }
+  }
+  // runs fn(local rank) on every worker; returns the first failure (its message becomes the caller's olap_last_error())
+  int run(const std::function<int(int)> &fn) {
+    job = &fn;
+    done.store(0, std::memory_order_relaxed);
+    for (auto &s : slots) s.rc = 0;
+    {
+      std::lock_guard<std::mutex> lock(mu);
+      gen.fetch_add(1, std::memory_order_release);
+    }
+    cv_go.notify_all();
+    const int64_t t0 = now_ns();
+    int polls = 0;
+    while (done.load(std::memory_order_acquire) != n) {
+      cpu_relax();
+      if ((++polls & 63) == 0 && now_ns() - t0 > kSpinNs) {
+        std::unique_lock<std::mutex> lock(mu);
+        cv_done.wait(lock, [&] { return done.load(std::memory_order_acquire) == n; });
+      }
+    }
+    job = nullptr;
+    for (auto &s : slots)
+      if (s.rc) return fail(s.rc, "%s", s.err.c_str());
+    return OLAP_OK;
+  }
+  // all workers of the current step meet here (they are all running: a spin barrier)
+  void barrier() {
+    const uint64_t g = barrier_gen.load(std::memory_order_acquire);
+    if (arrived.fetch_add(1, std::memory_order_acq_rel) + 1 == n) {
+      arrived.store(0, std::memory_order_relaxed);
+      barrier_gen.fetch_add(1, std::memory_order_release);
+    } else {
+      while (barrier_gen.load(std::memory_order_acquire) == g) cpu_relax();
+    }
+  }
+};
+
+static void comm_start_workers(olap_comm *c) {
+  if (c->local.size() < 2) return;
+  const char *e = getenv("OLAP_SHARD_THREADS");
+  const int forced = e ? atoi(e) : -1;
+  if (forced == 0) return;
+  if (c->transport != TRANSPORT_RCCL && forced != 1) return;  // ranks on one device: one fused launch instead (step_direct_fused)
+  std::vector<int> devices;
+  for (auto &l : c->local) devices.push_back(l.device);
+  c->workers = new ShardWorkers();
+  c->workers->start(devices);
+}
+static void comm_stop_workers(olap_comm *c) {
+  delete c->workers;
+  c->workers = nullptr;
+}
+
 // ------------------------------------------------------------------ sharded drillUp of dimension 0
 namespace {
 struct BufSet {
-  void *send[2] = {nullptr, nullptr};      // partial values / partial mask-or-counts
+  void *send[2] = {nullptr, nullptr};      // partial values / partial mask-or-counts (direct transport: slices of send_base)
+  void *send_base[2] = {nullptr, nullptr}; // direct transport, local rank 0 only: every rank's partial, rank after rank
   void *recv[2] = {nullptr, nullptr};      // combined (or gathered) payloads
   void *result = nullptr;                  // FINISH_COMBINE / _ROUND / _AVERAGE (else the result is recv[0] in place)
   int32_t *result_status = nullptr;
@@ -473,6 +663,13 @@ struct RankState {
   uint64_t local_cells = 0;
   BufSet set[2];
 };
+// where a rank's finished cells go when the caller provides the buffers (the store handles: straight into the
+// result store, no copy): global output cells [first, first + count), inside the rank's block
+struct StepDest {
+  void *values = nullptr;
+  int32_t *status = nullptr;
+  uint64_t first = 0, count = 0;
+};
 }  // namespace
 
 struct olap_shard_drillup {
@@ -481,6 +678,8 @@ struct olap_shard_drillup {
   int dtype = 0, default_kind = 0, method = 0, placement = 0, depth = 1;
   uint64_t n_out = 0, per = 0, n_send = 0;
   bool mask_primary = false;
+  bool fused = false;  // direct transport with few ranks: exchange + finish of all ranks is one launch
+  bool same_plans = false;  // ... and every rank's slab has the same rows-to-groups map: the local passes are one launch too
   int cur = 0;       // buffer set of the last step
   std::vector<RankState> ranks;
 };
@@ -498,19 +697,35 @@ static uint64_t recv_cells(const olap_shard_drillup *op, int p) {
   return is_scatter(op->placement) ? op->per : op->n_out;
 }
 
+// global output cells [first, first + count) that `rank` holds after a step
+static void rank_block(const olap_shard_drillup *op, int rank, uint64_t *first, uint64_t *count) {
+  uint64_t f = 0, n = op->n_out;
+  if (is_scatter(op->placement)) {
+    f = std::min<uint64_t>((uint64_t)rank * op->per, op->n_out);
+    n = std::min<uint64_t>(op->per, op->n_out - f);
+  } else if (op->placement == OLAP_PLACE_ROOT && rank != 0) {
+    n = 0;
+  }
+  *first = f;
+  *count = n;
+}
+
 extern "C" void olap_shard_drillup_destroy(olap_shard_drillup *op) {
   if (!op) return;
   DeviceGuard guard;
+  const bool direct = op->comm->transport == TRANSPORT_DIRECT;
   for (size_t i = 0; i < op->ranks.size(); ++i) {
     const auto &l = op->comm->local[i];
     (void)hipSetDevice(l.device);
     (void)hipStreamSynchronize(l.xstream);
+    (void)hipStreamSynchronize(nullptr);
     RankState &rs = op->ranks[i];
     if (rs.local_plan) olap_plan_destroy(rs.local_plan);
     if (rs.combine_plan) olap_plan_destroy(rs.combine_plan);
     for (BufSet &b : rs.set) {
       for (int p = 0; p < 2; ++p) {
-        if (b.send[p]) dev_free(b.send[p]);
+        if (b.send[p] && !direct) dev_free(b.send[p]);
+        if (b.send_base[p]) dev_free(b.send_base[p]);
         if (b.recv[p]) dev_free(b.recv[p]);
         if (b.peers[p]) dev_free((void *)b.peers[p]);
       }
@@ -569,6 +784,8 @@ extern "C" int olap_shard_drillup_create(olap_shard_drillup **out, olap_comm *co
   }
   op->n_send = is_scatter(op->placement) ? op->per * (uint64_t)world : n_out;  // padded so that it divides
   op->ranks.resize(comm->local.size());
+  const bool direct = comm->transport == TRANSPORT_DIRECT;
+  op->fused = direct && world <= kFusedMaxRanks && !comm->workers && !getenv("OLAP_SHARD_NO_FUSED");
 
   DeviceGuard guard;
   const bool def_nan = default_kind == OLAP_DEFAULT_NAN;
@@ -614,9 +831,22 @@ extern "C" int olap_shard_drillup_create(olap_shard_drillup **out, olap_comm *co
       BufSet &b = rs.set[k];
       for (int p = 0; p < recipe.n_payloads && !rc; ++p) {
         const size_t es = payload_size(op, p);
-        e = dev_alloc(&b.send[p], std::max<uint64_t>(op->n_send, 1) * es);
-        if (e == hipSuccess) e = hipMemsetAsync(b.send[p], 0, std::max<uint64_t>(op->n_send, 1) * es, nullptr);
-        const bool needs_recv = !(op->placement == OLAP_PLACE_ROOT && l.rank != 0 && recipe.payload_op[p] != OLAP_XCHG_GATHER);
+        const uint64_t cells = std::max<uint64_t>(op->n_send, 1);
+        if (direct) {
+          // every rank's partial in ONE block, rank after rank (the ranks share the device): gathered partials need no
+          // copy at all, and one table names them for the fused kernel
+          if (i == 0) {
+            e = dev_alloc(&b.send_base[p], cells * es * (size_t)world);
+            if (e == hipSuccess) e = hipMemsetAsync(b.send_base[p], 0, cells * es * (size_t)world, nullptr);
+          }
+          b.send[p] = (char *)op->ranks[0].set[k].send_base[p] + (size_t)l.rank * cells * es;
+        } else {
+          e = dev_alloc(&b.send[p], cells * es);
+          if (e == hipSuccess) e = hipMemsetAsync(b.send[p], 0, cells * es, nullptr);
+        }
+        // (fused direct steps read the partials where they lie; gathered partials of the direct transport too)
+        const bool needs_recv = !(op->placement == OLAP_PLACE_ROOT && l.rank != 0 && recipe.payload_op[p] != OLAP_XCHG_GATHER) &&
+                                !(direct && (op->fused || recipe.payload_op[p] == OLAP_XCHG_GATHER));
         if (e == hipSuccess && needs_recv) e = dev_alloc(&b.recv[p], std::max<uint64_t>(recv_cells(op, p), 1) * es);
         if (e != hipSuccess) rc = hip_fail(e, "hipMalloc(sharded drillUp buffers)");
       }
@@ -625,7 +855,7 @@ extern "C" int olap_shard_drillup_create(olap_shard_drillup **out, olap_comm *co
         SHARD_DISPATCH(dtype, hipLaunchKernelGGL((fill_default_kernel<T>), grid_for_n(n_out), kBlock, 0, nullptr, (T *)b.send[0], n_out, 1));
         rc = launch_check("fill_default_kernel");
       }
-      if (!rc && separate_result(recipe.finish) && !(op->placement == OLAP_PLACE_ROOT && l.rank != 0)) {
+      if (!rc && (separate_result(recipe.finish) || op->fused) && !(op->placement == OLAP_PLACE_ROOT && l.rank != 0)) {
         const uint64_t cells = recipe.finish == OLAP_FINISH_COMBINE ? n_out : recv_cells(op, 0);
         e = dev_alloc(&b.result, std::max<uint64_t>(cells, 1) * olap_dtype_size(dtype));
         if (e == hipSuccess) e = dev_alloc((void **)&b.result_status, std::max<uint64_t>(cells, 1) * sizeof(int32_t));
@@ -642,9 +872,18 @@ extern "C" int olap_shard_drillup_create(olap_shard_drillup **out, olap_comm *co
       if (e != hipSuccess) rc = hip_fail(e, "hipStreamSynchronize");
     }
   }
+  if (!rc && op->fused && world <= kMaxBatchRanks) {
+    // equal slabs with equal row maps (the '-> all' roll-ups of a balanced partition): one plan serves every rank
+    bool same = true;
+    const uint32_t rows = bounds[1] - bounds[0];
+    for (int r = 1; r < world && same; ++r)
+      same = bounds[r + 1] - bounds[r] == rows && std::equal(maps[0] + bounds[r], maps[0] + bounds[r + 1], maps[0] + bounds[0]);
+    op->same_plans = same && rows > 0;
+  }
   // direct transport: every rank's table of its peers' send buffers
-  if (!rc && comm->transport == TRANSPORT_DIRECT) {
+  if (!rc && direct) {
     for (size_t i = 0; i < op->ranks.size() && !rc; ++i) {
+      if (op->fused && i != 0) break;  // one table serves the fused launch
       (void)hipSetDevice(comm->local[i].device);
       for (int k = 0; k < depth && !rc; ++k)
         for (int p = 0; p < recipe.n_payloads && !rc; ++p) {
@@ -681,6 +920,7 @@ static int check_local(const olap_shard_drillup *op, int local) {
   return OLAP_OK;
 }
 
+// ---- the three phases of one rank (the rank's device is current) ------------------------------------------------------
 // local phase into buffer set k
 static int shard_local(olap_shard_drillup *op, int local, int k, const void *in_values, const int32_t *in_status, hipStream_t stream) {
   RankState &rs = op->ranks[local];
@@ -688,14 +928,7 @@ static int shard_local(olap_shard_drillup *op, int local, int k, const void *in_
   if (!rs.local_plan) return OLAP_OK;  // no rows: the buffers hold "unset" since creation
   if (op->mask_primary && !in_status)
     return fail(OLAP_ERR_INVALID_ARGUMENT, "integer cells over a NaN default: the status mask is required");
-  int rc = olap_plan_run(rs.local_plan, in_values, in_status, b.send[0], op->recipe.n_payloads > 1 ? (int32_t *)b.send[1] : nullptr, stream);
-  if (rc) return rc;
-  if (op->recipe.zero_unset) {
-    SHARD_DISPATCH(op->dtype, hipLaunchKernelGGL((zero_unset_kernel<T>), grid_for_n(op->n_out), kBlock, 0, stream, (T *)b.send[0],
-                                                 (const int32_t *)b.send[1], op->n_out));
-    if ((rc = launch_check("zero_unset_kernel"))) return rc;
-  }
-  return OLAP_OK;
+  return olap_plan_run(rs.local_plan, in_values, in_status, b.send[0], op->recipe.n_payloads > 1 ? (int32_t *)b.send[1] : nullptr, stream);
 }
 
 extern "C" int olap_shard_drillup_local(olap_shard_drillup *op, int local, const void *in_values, const int32_t *in_status, void *stream) {
@@ -706,33 +939,65 @@ extern "C" int olap_shard_drillup_local(olap_shard_drillup *op, int local, const
   return shard_local(op, local, op->cur, in_values, in_status, (hipStream_t)stream);
 }
 
-// finishing kernels of buffer set k on `stream`
-static int shard_finish(olap_shard_drillup *op, int local, int k, hipStream_t stream) {
+// finishing kernels of buffer set k on `stream`; dest (optional): the caller's buffers instead of the op's own
+static int shard_finish(olap_shard_drillup *op, int local, int k, hipStream_t stream, const StepDest *dest) {
   RankState &rs = op->ranks[local];
   BufSet &b = rs.set[k];
   const auto &l = op->comm->local[local];
-  if (op->placement == OLAP_PLACE_ROOT && l.rank != 0) return OLAP_OK;  // nothing arrived here
-  const uint64_t n = recv_cells(op, 0);
+  uint64_t first = 0, n = 0;
+  rank_block(op, l.rank, &first, &n);
+  if (n == 0) return OLAP_OK;  // nothing arrived here
+  if (dest && !dest->values) return OLAP_OK;  // the caller does not want this rank's copy
+  const bool def_nan = op->default_kind == OLAP_DEFAULT_NAN;
+  const size_t es = olap_dtype_size(op->dtype);
+  // where the finished cells go, and which of the rank's cells
+  uint64_t off = 0, cnt = is_scatter(op->placement) ? op->per : op->n_out;  // (in place: the whole padded block)
+  void *ov = nullptr;
+  int32_t *os = nullptr;
+  if (dest) {
+    if (dest->first < first || dest->first + dest->count > first + n)
+      return fail(OLAP_ERR_INVALID_ARGUMENT, "sharded: the result block of a rank is not where it was expected");
+    off = dest->first - first;
+    cnt = dest->count;
+    ov = dest->values;
+    os = dest->status;
+    if (cnt == 0) return OLAP_OK;
+  }
   int rc = OLAP_OK;
   switch (op->recipe.finish) {
-    case OLAP_FINISH_NONE: break;
+    case OLAP_FINISH_NONE:
+      if (!dest) break;  // the reduced values are the result where they lie
+      SHARD_DISPATCH(op->dtype, hipLaunchKernelGGL((restore_default_kernel<T>), grid_for_n(cnt), kBlock, 0, stream, (const T *)b.recv[0] + off,
+                                                   (const int32_t *)nullptr, (T *)ov, os, cnt, def_nan));
+      rc = launch_check("restore_default_kernel");
+      break;
     case OLAP_FINISH_RESTORE:
-      SHARD_DISPATCH(op->dtype, hipLaunchKernelGGL((restore_default_kernel<T>), grid_for_n(n), kBlock, 0, stream, (T *)b.recv[0],
-                                                   (int32_t *)b.recv[1], n, op->default_kind == OLAP_DEFAULT_NAN));
+      SHARD_DISPATCH(op->dtype, hipLaunchKernelGGL((restore_default_kernel<T>), grid_for_n(cnt), kBlock, 0, stream, (const T *)b.recv[0] + off,
+                                                   (const int32_t *)b.recv[1] + off, dest ? (T *)ov : (T *)b.recv[0],
+                                                   dest ? os : (int32_t *)b.recv[1], cnt, def_nan));
       rc = launch_check("restore_default_kernel");
       break;
     case OLAP_FINISH_ROUND:
     case OLAP_FINISH_AVERAGE:
-      SHARD_DISPATCH(op->dtype, hipLaunchKernelGGL((partial_round_kernel<T>), grid_for_n(n), kBlock, 0, stream, (const double *)b.recv[0],
-                                                   op->recipe.n_payloads > 1 ? (const int32_t *)b.recv[1] : nullptr, (T *)b.result,
-                                                   b.result_status, n, op->default_kind == OLAP_DEFAULT_NAN,
-                                                   op->recipe.finish == OLAP_FINISH_AVERAGE));
+      SHARD_DISPATCH(op->dtype, hipLaunchKernelGGL((partial_round_kernel<T>), grid_for_n(cnt), kBlock, 0, stream, (const double *)b.recv[0] + off,
+                                                   op->recipe.n_payloads > 1 ? (const int32_t *)b.recv[1] + off : nullptr,
+                                                   dest ? (T *)ov : (T *)b.result, dest ? os : b.result_status, cnt, def_nan, op->recipe.finish));
       rc = launch_check("partial_round_kernel");
       break;
-    case OLAP_FINISH_COMBINE:
-      rc = olap_plan_run(rs.combine_plan, b.recv[0], op->recipe.n_payloads > 1 ? (const int32_t *)b.recv[1] : nullptr, b.result,
-                         b.result_status, stream);
+    case OLAP_FINISH_COMBINE: {
+      // (the gathered partials of the direct transport lie rank after rank in the shared block: no copy)
+      const bool direct = op->comm->transport == TRANSPORT_DIRECT;
+      const void *gv = direct ? op->ranks[0].set[k].send_base[0] : b.recv[0];
+      const int32_t *gs = op->recipe.n_payloads > 1 ? (const int32_t *)(direct ? op->ranks[0].set[k].send_base[1] : b.recv[1]) : nullptr;
+      const bool whole = dest && off == 0 && cnt == op->n_out;
+      rc = olap_plan_run(rs.combine_plan, gv, gs, whole ? ov : b.result, whole ? os : b.result_status, stream);
+      if (!rc && dest && !whole) {  // a result that stays sharded: this rank keeps its rows of the combined cube
+        hipError_t e = hipMemcpyAsync(ov, (const char *)b.result + off * es, cnt * es, hipMemcpyDeviceToDevice, stream);
+        if (e == hipSuccess && os) e = hipMemcpyAsync(os, b.result_status + off, cnt * sizeof(int32_t), hipMemcpyDeviceToDevice, stream);
+        if (e != hipSuccess) rc = hip_fail(e, "sharded drillUp result");
+      }
       break;
+    }
   }
   return rc;
 }
@@ -740,36 +1005,75 @@ static int shard_finish(olap_shard_drillup *op, int local, int k, hipStream_t st
 extern "C" int olap_shard_drillup_finish(olap_shard_drillup *op, int local, void *stream) {
   int rc = check_local(op, local);
   if (rc) return rc;
+  if (op->fused) return fail(OLAP_ERR_INVALID_ARGUMENT, "sharded: the ranks of this communicator share a device and finish in one launch (olap_shard_drillup_step)");
   DeviceGuard guard;
   HIP_TRY(hipSetDevice(op->comm->local[local].device));
-  return shard_finish(op, local, op->cur, (hipStream_t)stream);
+  return shard_finish(op, local, op->cur, (hipStream_t)stream, nullptr);
 }
 
-// exchange of buffer set k; xs[i] = the stream rank i's collective is enqueued on
-static int shard_exchange(olap_shard_drillup *op, int k, const std::vector<hipStream_t> &xs) {
+// RCCL collectives of local rank i for buffer set k on stream x (the caller opens / closes the group)
+static ncclResult_t rank_collectives(olap_shard_drillup *op, size_t i, int k, hipStream_t x) {
+  Rccl *r = rccl();
+  const olap_shard_recipe &rp = op->recipe;
+  BufSet &b = op->ranks[i].set[k];
+  const auto &l = op->comm->local[i];
+  ncclResult_t res = ncclSuccess;
+  for (int p = 0; p < rp.n_payloads && res == ncclSuccess; ++p) {
+    const ncclDataType_t ty = rp.payload_op[p] == OLAP_XCHG_SUM ? nccl_sum_type(rp.payload_dtype[p]) : nccl_type(rp.payload_dtype[p]);
+    if (rp.payload_op[p] == OLAP_XCHG_GATHER) {
+      res = r->AllGather(b.send[p], b.recv[p], op->n_out, ty, l.nccl, x);
+      continue;
+    }
+    const ncclRedOp_t red = rp.payload_op[p] == OLAP_XCHG_SUM ? ncclSum : ncclMax;
+    if (is_scatter(op->placement)) res = r->ReduceScatter(b.send[p], b.recv[p], op->per, ty, red, l.nccl, x);
+    else if (op->placement == OLAP_PLACE_ALL) res = r->AllReduce(b.send[p], b.recv[p], op->n_out, ty, red, l.nccl, x);
+    else res = r->Reduce(b.send[p], b.recv[p] ? b.recv[p] : b.send[p], op->n_out, ty, red, 0, l.nccl, x);
+  }
+  return res;
+}
+
+// direct transport, rank i: its block of every payload combined from the peers' partials (the rank's device is current)
+static int rank_direct_combine(olap_shard_drillup *op, size_t i, int k, hipStream_t x) {
   olap_comm *c = op->comm;
   const olap_shard_recipe &rp = op->recipe;
+  BufSet &b = op->ranks[i].set[k];
+  const auto &l = c->local[i];
+  for (int p = 0; p < rp.n_payloads; ++p) {
+    if (rp.payload_op[p] == OLAP_XCHG_GATHER) continue;  // read in place by the combine plan (shared block)
+    if (op->placement == OLAP_PLACE_ROOT && l.rank != 0) continue;
+    const uint64_t first = is_scatter(op->placement) ? (uint64_t)l.rank * op->per : 0;
+    const uint64_t n = is_scatter(op->placement) ? op->per : op->n_out;
+    const bool sum = rp.payload_op[p] == OLAP_XCHG_SUM;
+#define DIRECT_LAUNCH(T)                                                                                                     \
+  do {                                                                                                                       \
+    if (sum) hipLaunchKernelGGL((direct_combine_kernel<T, OLAP_XCHG_SUM>), grid_for_n(n), kBlock, 0, x,                       \
+                                (const T *const *)b.peers[p], c->world, (T *)b.recv[p], first, n);                           \
+    else hipLaunchKernelGGL((direct_combine_kernel<T, OLAP_XCHG_MAX>), grid_for_n(n), kBlock, 0, x,                           \
+                            (const T *const *)b.peers[p], c->world, (T *)b.recv[p], first, n);                               \
+  } while (0)
+    switch (rp.payload_dtype[p]) {
+      case OLAP_INT32: DIRECT_LAUNCH(int32_t); break;
+      case OLAP_UINT32: DIRECT_LAUNCH(uint32_t); break;
+      case OLAP_FLOAT32: DIRECT_LAUNCH(float); break;
+      default: DIRECT_LAUNCH(double); break;
+    }
+#undef DIRECT_LAUNCH
+    int rc = launch_check("direct_combine_kernel");
+    if (rc) return rc;
+  }
+  return OLAP_OK;
+}
+
+// exchange of buffer set k for every local rank from ONE thread; xs[i] = the stream rank i's collective is enqueued on
+static int shard_exchange(olap_shard_drillup *op, int k, const std::vector<hipStream_t> &xs) {
+  olap_comm *c = op->comm;
   if (c->transport == TRANSPORT_DETACHED)
     return fail(OLAP_ERR_INVALID_ARGUMENT, "sharded: a detached communicator has no transport; move the payloads yourself (olap_shard_drillup_payload)");
   if (c->transport == TRANSPORT_RCCL) {
     Rccl *r = rccl();
     RCCL_TRY(r->GroupStart());
     ncclResult_t res = ncclSuccess;
-    for (size_t i = 0; i < op->ranks.size() && res == ncclSuccess; ++i) {
-      BufSet &b = op->ranks[i].set[k];
-      const auto &l = c->local[i];
-      for (int p = 0; p < rp.n_payloads && res == ncclSuccess; ++p) {
-        const ncclDataType_t ty = rp.payload_op[p] == OLAP_XCHG_SUM ? nccl_sum_type(rp.payload_dtype[p]) : nccl_type(rp.payload_dtype[p]);
-        if (rp.payload_op[p] == OLAP_XCHG_GATHER) {
-          res = r->AllGather(b.send[p], b.recv[p], op->n_out, ty, l.nccl, xs[i]);
-          continue;
-        }
-        const ncclRedOp_t red = rp.payload_op[p] == OLAP_XCHG_SUM ? ncclSum : ncclMax;
-        if (is_scatter(op->placement)) res = r->ReduceScatter(b.send[p], b.recv[p], op->per, ty, red, l.nccl, xs[i]);
-        else if (op->placement == OLAP_PLACE_ALL) res = r->AllReduce(b.send[p], b.recv[p], op->n_out, ty, red, l.nccl, xs[i]);
-        else res = r->Reduce(b.send[p], b.recv[p] ? b.recv[p] : b.send[p], op->n_out, ty, red, 0, l.nccl, xs[i]);
-      }
-    }
+    for (size_t i = 0; i < op->ranks.size() && res == ncclSuccess; ++i) res = rank_collectives(op, i, k, xs[i]);
     ncclResult_t end = r->GroupEnd();
     if (res != ncclSuccess) return rccl_fail(res, "RCCL collective");
     if (end != ncclSuccess) return rccl_fail(end, "ncclGroupEnd");
@@ -777,47 +1081,16 @@ static int shard_exchange(olap_shard_drillup *op, int k, const std::vector<hipSt
   }
   // direct: all ranks live on one device; each destination reads its peers' partials
   for (size_t i = 0; i < op->ranks.size(); ++i) {
-    BufSet &b = op->ranks[i].set[k];
-    const auto &l = c->local[i];
-    HIP_TRY(hipSetDevice(l.device));
-    for (int p = 0; p < rp.n_payloads; ++p) {
-      const size_t es = payload_size(op, p);
-      if (rp.payload_op[p] == OLAP_XCHG_GATHER) {
-        for (int q = 0; q < c->world; ++q)
-          HIP_TRY(hipMemcpyAsync((char *)b.recv[p] + (size_t)q * op->n_out * es, op->ranks[q].set[k].send[p], op->n_out * es,
-                                 hipMemcpyDeviceToDevice, xs[i]));
-        continue;
-      }
-      if (op->placement == OLAP_PLACE_ROOT && l.rank != 0) continue;
-      const uint64_t first = is_scatter(op->placement) ? (uint64_t)l.rank * op->per : 0;
-      const uint64_t n = is_scatter(op->placement) ? op->per : op->n_out;
-      const bool sum = rp.payload_op[p] == OLAP_XCHG_SUM;
-#define DIRECT_LAUNCH(T)                                                                                                     \
-  do {                                                                                                                       \
-    if (sum) hipLaunchKernelGGL((direct_combine_kernel<T, OLAP_XCHG_SUM>), grid_for_n(n), kBlock, 0, xs[i],                   \
-                                (const T *const *)b.peers[p], c->world, (T *)b.recv[p], first, n);                           \
-    else hipLaunchKernelGGL((direct_combine_kernel<T, OLAP_XCHG_MAX>), grid_for_n(n), kBlock, 0, xs[i],                       \
-                            (const T *const *)b.peers[p], c->world, (T *)b.recv[p], first, n);                               \
-  } while (0)
-      switch (rp.payload_dtype[p]) {
-        case OLAP_INT32:
-          if (sum) DIRECT_LAUNCH(uint32_t);  // modulo 2^32, like nccl_sum_type
-          else DIRECT_LAUNCH(int32_t);
-          break;
-        case OLAP_UINT32: DIRECT_LAUNCH(uint32_t); break;
-        case OLAP_FLOAT32: DIRECT_LAUNCH(float); break;
-        default: DIRECT_LAUNCH(double); break;
-      }
-#undef DIRECT_LAUNCH
-      int rc = launch_check("direct_combine_kernel");
-      if (rc) return rc;
-    }
+    HIP_TRY(hipSetDevice(c->local[i].device));
+    int rc = rank_direct_combine(op, i, k, xs[i]);
+    if (rc) return rc;
   }
   return OLAP_OK;
 }
 
 extern "C" int olap_shard_drillup_exchange(olap_shard_drillup *op, void *const *streams) {
   if (!op) return fail(OLAP_ERR_INVALID_ARGUMENT, "op is NULL");
+  if (op->fused) return fail(OLAP_ERR_INVALID_ARGUMENT, "sharded: the ranks of this communicator share a device and exchange in one launch (olap_shard_drillup_step)");
   DeviceGuard guard;
   std::vector<hipStream_t> xs(op->ranks.size());
   for (size_t i = 0; i < xs.size(); ++i) xs[i] = streams ? (hipStream_t)streams[i] : nullptr;
@@ -829,12 +1102,161 @@ extern "C" int olap_shard_drillup_exchange(olap_shard_drillup *op, void *const *
   return shard_exchange(op, op->cur, xs);
 }
 
-extern "C" int olap_shard_drillup_step(olap_shard_drillup *op, const void *const *in_values, const int32_t *const *in_status,
-                                       void *const *streams) {
-  if (!op || !in_values) return fail(OLAP_ERR_INVALID_ARGUMENT, "op/in_values is NULL");
-  DeviceGuard guard;
+// ---- one step, three ways -----------------------------------------------------------------------------------------------
+// (a) ranks share one device (direct transport, few ranks): n local launches and ONE launch that adds the partials,
+//     finishes and places every rank's block; no events when the callers' streams are one stream.
+static int step_direct_fused(olap_shard_drillup *op, int k, const void *const *in_values, const int32_t *const *in_status,
+                             void *const *streams, const StepDest *dest) {
   olap_comm *c = op->comm;
-  const int k = op->depth == 2 ? (op->cur ^ 1) : 0;
+  const size_t nl = op->ranks.size();
+  const olap_shard_recipe &rp = op->recipe;
+  BufSet &b0 = op->ranks[0].set[k];
+  HIP_TRY(hipSetDevice(c->local[0].device));
+  bool one_stream = true;
+  for (size_t i = 1; i < nl; ++i) one_stream = one_stream && (!streams || streams[i] == streams[0]);
+  hipStream_t s0 = streams ? (hipStream_t)streams[0] : nullptr;
+  hipStream_t x = one_stream ? s0 : c->local[0].xstream;
+  int rc;
+  bool locals_done = false;
+  if (one_stream && op->same_plans) {
+    // every rank's local pass in ONE launch (the same plan over n slabs: blockIdx.y picks the rank)
+    if (b0.in_flight) HIP_TRY(hipStreamWaitEvent(s0, b0.xchg_done, 0));
+    if (op->mask_primary && !in_status) return fail(OLAP_ERR_INVALID_ARGUMENT, "integer cells over a NaN default: the status mask is required");
+    void *outs[kMaxBatchRanks];
+    int32_t *couts[kMaxBatchRanks];
+    for (size_t i = 0; i < nl; ++i) {
+      outs[i] = op->ranks[i].set[k].send[0];
+      couts[i] = rp.n_payloads > 1 ? (int32_t *)op->ranks[i].set[k].send[1] : nullptr;
+    }
+    if ((rc = olap_plan_run_batch(op->ranks[0].local_plan, (int)nl, in_values, in_status, outs, rp.n_payloads > 1 ? couts : nullptr, s0))) return rc;
+    locals_done = true;
+  }
+  for (size_t i = 0; i < nl && !locals_done; ++i) {
+    hipStream_t s = streams ? (hipStream_t)streams[i] : nullptr;
+    if (b0.in_flight) HIP_TRY(hipStreamWaitEvent(s, b0.xchg_done, 0));  // the set's previous exchange (on a stream of its own) read these partials
+    if ((rc = shard_local(op, (int)i, k, in_values[i], in_status ? in_status[i] : nullptr, s))) return rc;
+    if (!one_stream) {
+      HIP_TRY(hipEventRecord(op->ranks[i].set[k].local_done, s));
+      HIP_TRY(hipStreamWaitEvent(x, op->ranks[i].set[k].local_done, 0));
+    }
+  }
+  op->cur = k;
+  if (rp.finish == OLAP_FINISH_COMBINE) {
+    // the partials lie rank after rank in one block: the same drillUp over the rank axis reads them in place
+    for (size_t i = 0; i < nl; ++i) {
+      if (dest && !dest[i].values) continue;
+      if ((rc = shard_finish(op, (int)i, k, x, dest ? &dest[i] : nullptr))) return rc;
+    }
+  } else {
+    FusedDests d{};
+    for (size_t i = 0; i < nl; ++i) {
+      uint64_t first = 0, n = 0;
+      rank_block(op, c->local[i].rank, &first, &n);
+      if (n == 0) continue;
+      StepDest want;
+      if (dest) {
+        want = dest[i];
+        if (!want.values || want.count == 0) continue;
+        if (want.first < first || want.first + want.count > first + n)
+          return fail(OLAP_ERR_INVALID_ARGUMENT, "sharded: the result block of a rank is not where it was expected");
+      } else {
+        want.values = op->ranks[i].set[k].result;
+        want.status = op->ranks[i].set[k].result_status;
+        want.first = first;
+        want.count = n;
+      }
+      d.values[d.n] = want.values;
+      d.status[d.n] = want.status;
+      d.first[d.n] = want.first;
+      d.count[d.n] = want.count;
+      ++d.n;
+    }
+    if (d.n > 0) {
+      const int32_t *const *src1 = rp.n_payloads > 1 ? (const int32_t *const *)b0.peers[1] : nullptr;
+      const int dn = op->default_kind == OLAP_DEFAULT_NAN;
+      const unsigned grid = grid_for_n(op->n_out);
+      if (rp.payload_dtype[0] == OLAP_FLOAT64 && op->dtype != OLAP_FLOAT64) {
+        SHARD_DISPATCH(op->dtype, hipLaunchKernelGGL((direct_fused_kernel<T, double>), grid, kBlock, 0, x, (const double *const *)b0.peers[0], src1,
+                                                     c->world, rp.payload_op[1], op->n_out, rp.finish, dn, d));
+      } else {
+        SHARD_DISPATCH(op->dtype, hipLaunchKernelGGL((direct_fused_kernel<T, T>), grid, kBlock, 0, x, (const T *const *)b0.peers[0], src1, c->world,
+                                                     rp.payload_op[1], op->n_out, rp.finish, dn, d));
+      }
+      if ((rc = launch_check("direct_fused_kernel"))) return rc;
+    }
+  }
+  if (!one_stream) {
+    HIP_TRY(hipEventRecord(b0.xchg_done, x));
+    b0.in_flight = true;
+    for (size_t i = 0; i < nl; ++i) {
+      op->ranks[i].set[k].in_flight = true;
+      if (op->depth == 1) HIP_TRY(hipStreamWaitEvent(streams ? (hipStream_t)streams[i] : nullptr, b0.xchg_done, 0));
+    }
+  }
+  return OLAP_OK;
+}
+
+// (b) one rank's whole sequence, issued by the thread that owns the rank's device (a worker, or the caller when the
+//     process drives a single rank): no device switch; at depth 1 everything rides the caller's stream — launch,
+//     collective, launch, no event at all.
+static int step_rank_sequence(olap_shard_drillup *op, size_t i, int k, const void *in_values, const int32_t *in_status, hipStream_t s,
+                              const StepDest *dest, ShardWorkers *w) {
+  olap_comm *c = op->comm;
+  BufSet &b = op->ranks[i].set[k];
+  const auto &l = c->local[i];
+  const bool direct = c->transport == TRANSPORT_DIRECT;
+  const bool pipelined = op->depth == 2 || direct;  // a stream of its own for the exchange
+  hipStream_t x = pipelined ? l.xstream : s;
+  int rc = OLAP_OK;
+  hipError_t e = hipSuccess;
+  if (b.in_flight && pipelined) e = hipStreamWaitEvent(s, b.xchg_done, 0);
+  if (e == hipSuccess) rc = shard_local(op, (int)i, k, in_values, in_status, s);
+  if (!rc && e == hipSuccess && pipelined) {
+    e = hipEventRecord(b.local_done, s);
+    if (e == hipSuccess && !direct) e = hipStreamWaitEvent(x, b.local_done, 0);
+  }
+  if (direct && w) {
+    // a rank of the direct transport reads EVERY peer's partial: all of them must have been recorded before anybody waits
+    w->barrier();
+    for (size_t j = 0; j < op->ranks.size() && e == hipSuccess; ++j) e = hipStreamWaitEvent(x, op->ranks[j].set[k].local_done, 0);
+  }
+  if (e != hipSuccess) rc = hip_fail(e, "sharded step (events)");
+  if (!rc) {
+    if (direct) {
+      rc = rank_direct_combine(op, i, k, x);
+    } else {
+      Rccl *r = rccl();
+      ncclResult_t res = r->GroupStart();
+      if (res == ncclSuccess) res = rank_collectives(op, i, k, x);
+      const ncclResult_t end = r->GroupEnd();
+      if (res != ncclSuccess) rc = rccl_fail(res, "RCCL collective");
+      else if (end != ncclSuccess) rc = rccl_fail(end, "ncclGroupEnd");
+    }
+  }
+  if (!rc) rc = shard_finish(op, (int)i, k, x, dest);
+  if (!rc && pipelined) {
+    e = hipEventRecord(b.xchg_done, x);
+    b.in_flight = true;
+    if (e != hipSuccess) rc = hip_fail(e, "hipEventRecord");
+  }
+  if (direct && w) {
+    // a peer's next local pass overwrites a partial that THIS rank's exchange reads: every caller stream waits for every exchange
+    w->barrier();
+    for (size_t j = 0; j < op->ranks.size() && !rc; ++j) {
+      e = hipStreamWaitEvent(s, op->ranks[j].set[k].xchg_done, 0);
+      if (e != hipSuccess) rc = hip_fail(e, "hipStreamWaitEvent");
+    }
+  } else if (!rc && pipelined && op->depth == 1) {
+    e = hipStreamWaitEvent(s, b.xchg_done, 0);
+    if (e != hipSuccess) rc = hip_fail(e, "hipStreamWaitEvent");
+  }
+  return rc;
+}
+
+// (c) every local rank from the calling thread: all local passes, ONE group of collectives, all finishes
+static int step_inline(olap_shard_drillup *op, int k, const void *const *in_values, const int32_t *const *in_status, void *const *streams,
+                       const StepDest *dest) {
+  olap_comm *c = op->comm;
   const size_t nl = op->ranks.size();
   std::vector<hipStream_t> xs(nl);
   int rc;
@@ -865,14 +1287,13 @@ extern "C" int olap_shard_drillup_step(olap_shard_drillup *op, const void *const
     const auto &l = c->local[i];
     BufSet &b = op->ranks[i].set[k];
     HIP_TRY(hipSetDevice(l.device));
-    if ((rc = shard_finish(op, (int)i, k, xs[i]))) return rc;
+    if ((rc = shard_finish(op, (int)i, k, xs[i], dest ? &dest[i] : nullptr))) return rc;
     HIP_TRY(hipEventRecord(b.xchg_done, xs[i]));
     b.in_flight = true;
   }
   if (c->transport == TRANSPORT_DIRECT) {
     // a peer's next local pass overwrites a partial that THIS rank's exchange reads: every caller stream waits for
-    // every exchange of this set before it may reuse it (recorded above; enforced at the next use of set k) —
-    // with one shared device the simplest correct order is to chain them all now
+    // every exchange of this set before it may reuse it
     for (size_t i = 0; i < nl; ++i) {
       hipStream_t s = streams ? (hipStream_t)streams[i] : nullptr;
       for (size_t j = 0; j < nl; ++j) HIP_TRY(hipStreamWaitEvent(s, op->ranks[j].set[k].xchg_done, 0));
@@ -886,13 +1307,46 @@ extern "C" int olap_shard_drillup_step(olap_shard_drillup *op, const void *const
   return OLAP_OK;
 }
 
+static int shard_step(olap_shard_drillup *op, const void *const *in_values, const int32_t *const *in_status, void *const *streams,
+                      const StepDest *dest) {
+  if (!op || !in_values) return fail(OLAP_ERR_INVALID_ARGUMENT, "op/in_values is NULL");
+  olap_comm *c = op->comm;
+  const int k = op->depth == 2 ? (op->cur ^ 1) : 0;
+  DeviceGuard guard;
+  if (op->fused) return step_direct_fused(op, k, in_values, in_status, streams, dest);
+  if (c->transport == TRANSPORT_DETACHED)
+    return fail(OLAP_ERR_INVALID_ARGUMENT, "sharded: a detached communicator has no transport; move the payloads yourself (olap_shard_drillup_payload)");
+  if (c->workers) {
+    op->cur = k;
+    const std::function<int(int)> job = [&](int i) -> int {
+      return step_rank_sequence(op, (size_t)i, k, in_values[i], in_status ? in_status[i] : nullptr, streams ? (hipStream_t)streams[i] : nullptr,
+                                dest ? &dest[i] : nullptr, c->workers);
+    };
+    return c->workers->run(job);
+  }
+  if (op->ranks.size() == 1 && c->transport == TRANSPORT_RCCL) {  // one process per GPU: the caller's thread owns the device
+    HIP_TRY(hipSetDevice(c->local[0].device));
+    op->cur = k;
+    return step_rank_sequence(op, 0, k, in_values[0], in_status ? in_status[0] : nullptr, streams ? (hipStream_t)streams[0] : nullptr,
+                              dest ? &dest[0] : nullptr, nullptr);
+  }
+  return step_inline(op, k, in_values, in_status, streams, dest);
+}
+
+extern "C" int olap_shard_drillup_step(olap_shard_drillup *op, const void *const *in_values, const int32_t *const *in_status,
+                                       void *const *streams) {
+  return shard_step(op, in_values, in_status, streams, nullptr);
+}
+
 extern "C" int olap_shard_drillup_wait(olap_shard_drillup *op, void *const *streams) {
   if (!op) return fail(OLAP_ERR_INVALID_ARGUMENT, "op is NULL");
   DeviceGuard guard;
   for (size_t i = 0; i < op->ranks.size(); ++i) {
     HIP_TRY(hipSetDevice(op->comm->local[i].device));
-    for (int k = 0; k < op->depth; ++k)
-      if (op->ranks[i].set[k].in_flight) HIP_TRY(hipStreamWaitEvent(streams ? (hipStream_t)streams[i] : nullptr, op->ranks[i].set[k].xchg_done, 0));
+    for (int k = 0; k < op->depth; ++k) {
+      const BufSet &b = op->fused ? op->ranks[0].set[k] : op->ranks[i].set[k];  // (a fused step records one event for all ranks)
+      if (b.in_flight) HIP_TRY(hipStreamWaitEvent(streams ? (hipStream_t)streams[i] : nullptr, b.xchg_done, 0));
+    }
   }
   return OLAP_OK;
 }
@@ -916,17 +1370,11 @@ extern "C" int olap_shard_drillup_result(const olap_shard_drillup *op, int local
   int rc = check_local(op, local);
   if (rc) return rc;
   const BufSet &b = op->ranks[local].set[op->cur];
-  const int rank = op->comm->local[local].rank;
-  uint64_t f = 0, n = op->n_out;
-  if (is_scatter(op->placement)) {
-    f = std::min<uint64_t>((uint64_t)rank * op->per, op->n_out);
-    n = std::min<uint64_t>(op->per, op->n_out - f);
-  } else if (op->placement == OLAP_PLACE_ROOT && rank != 0) {
-    n = 0;
-  }
+  uint64_t f = 0, n = 0;
+  rank_block(op, op->comm->local[local].rank, &f, &n);
   void *v = nullptr;
   int32_t *s = nullptr;
-  if (separate_result(op->recipe.finish)) {
+  if (separate_result(op->recipe.finish) || op->fused) {
     v = b.result;
     s = b.result_status;
   } else {
@@ -1149,7 +1597,8 @@ extern "C" int olap_sharded_store_fill_seeded(olap_sharded_store *s, uint32_t se
     }
     int rc = olap_fill_seeded(sh->values, st, n, slab_first(s, i), sh->dtype, seed, frac, nullptr);
     if (!rc && fnan) {  // the generator leaves 0 in dropped cells; under a NaN default they hold NaN
-      SHARD_DISPATCH(sh->dtype, hipLaunchKernelGGL((restore_default_kernel<T>), grid_for_n(n), kBlock, 0, nullptr, (T *)sh->values, st, n, 1));
+      SHARD_DISPATCH(sh->dtype, hipLaunchKernelGGL((restore_default_kernel<T>), grid_for_n(n), kBlock, 0, nullptr, (const T *)sh->values, (const int32_t *)st,
+                                                   (T *)sh->values, st, n, 1));
       rc = launch_check("restore_default_kernel");
     }
     hipError_t e = hipStreamSynchronize(nullptr);
@@ -1443,45 +1892,37 @@ extern "C" int olap_sharded_store_drillup(const olap_sharded_store *s, olap_shar
     if (rc) return rc;
     op_cache().insert(key, op, op_bytes(op));
   }
-  std::vector<const void *> vals(s->shard.size());
-  std::vector<const int32_t *> stat(s->shard.size());
-  for (size_t i = 0; i < s->shard.size(); ++i) {
+  const size_t nl = s->shard.size();
+  std::vector<const void *> vals(nl);
+  std::vector<const int32_t *> stat(nl);
+  for (size_t i = 0; i < nl; ++i) {
     vals[i] = s->shard[i]->values;
     stat[i] = mask_needed(s->shard[i]);
   }
-  if ((rc = olap_shard_drillup_step(op, vals.data(), stat.data(), nullptr))) return rc;
-  const size_t es = olap_dtype_size(s->dtype);
-  // copies `count` cells of local rank i's result, starting at global output cell `from`, into a new store on its device
-  auto take = [&](int i, uint64_t from, uint64_t count, olap_store **dst) -> int {
+  // The result stores come first: the finishing kernels write straight into them (no copy out of the step's buffers,
+  // and the cached step can run again at once).  Pool memory is recycled in null-stream order and every path of the
+  // step orders its finishing kernel behind the rank's null stream.
+  std::vector<StepDest> dest(nl);
+  auto result_store = [&](int i, uint64_t from, uint64_t count, olap_store **dst) -> int {
     DeviceGuard guard;
     HIP_TRY(hipSetDevice(c->local[i].device));
     olap_store *w = nullptr;
     int r2 = store_alloc(&w, count, s->dtype, s->default_kind);
     if (r2) return r2;
-    void *rv = nullptr;
-    int32_t *rs = nullptr;
-    uint64_t first = 0, have = 0;
-    r2 = olap_shard_drillup_result(op, i, &rv, &rs, &first, &have);
-    if (!r2 && count && (from < first || from + count > first + have)) r2 = fail(OLAP_ERR_INVALID_ARGUMENT, "sharded: the result block of a rank is not where it was expected");
-    if (!r2 && count) {
-      // (the null stream is already ordered behind the step; the cached step's next run is enqueued behind these copies)
-      hipError_t e = hipMemcpyAsync(w->values, (const char *)rv + (from - first) * es, count * es, hipMemcpyDeviceToDevice, nullptr);
-      if (e == hipSuccess && w->status) {
-        if (rs) e = hipMemcpyAsync(w->status, rs + (from - first), count * sizeof(int32_t), hipMemcpyDeviceToDevice, nullptr);
-        else r2 = olap_canonicalize(w->values, w->status, count, s->dtype, s->default_kind, 0, nullptr);
-      }
-      if (e != hipSuccess) r2 = hip_fail(e, "sharded drillUp result");
-    }
-    if (r2) {
-      olap_store_destroy(w);
-      return r2;
-    }
+    dest[i].values = w->values;
+    dest[i].status = w->status;  // (only where the mask is primary: integer cells over a NaN default)
+    dest[i].first = from;
+    dest[i].count = count;
     *dst = w;
     return OLAP_OK;
   };
   if (!keep_sharded) {
     olap_store *w = nullptr;
-    if ((rc = take(0, 0, op->n_out, &w))) return rc;
+    if ((rc = result_store(0, 0, op->n_out, &w))) return rc;
+    if ((rc = shard_step(op, vals.data(), stat.data(), nullptr, dest.data()))) {
+      olap_store_destroy(w);
+      return rc;
+    }
     *out_whole = w;
     return OLAP_OK;
   }
@@ -1490,10 +1931,11 @@ extern "C" int olap_sharded_store_drillup(const olap_sharded_store *s, olap_shar
   for (int r = 0; r <= c->world; ++r) nb[r] = (uint32_t)std::min<uint64_t>((uint64_t)r * per_rows, new_len[0]);
   olap_sharded_store *o = nullptr;
   if ((rc = sharded_frame(&o, c, ndim, new_len, s->dtype, s->default_kind, nb.data()))) return rc;
-  for (size_t i = 0; i < s->shard.size() && !rc; ++i) {
+  for (size_t i = 0; i < nl && !rc; ++i) {
     const int r = c->local[i].rank;
-    rc = take((int)i, (uint64_t)nb[r] * row, (uint64_t)(nb[r + 1] - nb[r]) * row, &o->shard[i]);
+    rc = result_store((int)i, (uint64_t)nb[r] * row, (uint64_t)(nb[r + 1] - nb[r]) * row, &o->shard[i]);
   }
+  if (!rc) rc = shard_step(op, vals.data(), stat.data(), nullptr, dest.data());
   if (rc) {
     olap_sharded_store_destroy(o);
     return rc;

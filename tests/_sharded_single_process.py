@@ -169,6 +169,31 @@ for devices in ([0, 0, 0], [0, 0]):
     c.destroy()
 print("direct transport ok", flush=True)
 
+# The same ranks with one ISSUING THREAD per rank (what a process that drives several devices over RCCL uses; here
+# forced onto the direct transport so that the hand-over, the barriers between the workers and the relay of a worker's
+# error run on a one-GPU box), and the unfused direct path issued by the calling thread.
+for env, tag in (("OLAP_SHARD_THREADS", "threads"), ("OLAP_SHARD_NO_FUSED", "unfused")):
+    os.environ[env] = "1"
+    for devices in ([0, 0, 0], [0, 0]):
+        c = Comm.init_all(devices)
+        run_steps(c, "%s%d" % (tag, len(devices)))
+        run_store_api(c, "%s%d" % (tag, len(devices)))
+        if env == "OLAP_SHARD_THREADS":  # a failure inside a worker reaches the caller as an ordinary error, and the workers live on
+            bad = ShardedStore(c, [4, 3], "int32", float("nan")).set_data_f64(np.arange(12, dtype=np.float64))
+            opb = bad.plan_drillup_dim0([0, 0, 0, 0], 1, "sum")
+            vals, _ = bad.step_inputs()
+            try:
+                opb.step(vals, None)  # integer cells over a NaN default: the mask is required
+                raise AssertionError("expected the workers to refuse a step without the mask")
+            except capi.OlapError as e:
+                assert "status mask is required" in str(e), str(e)
+            opb.destroy()
+            ok = ShardedStore(c, [4, 3], "float32", 0.0).set_data_f64(np.arange(12, dtype=np.float64))
+            assert ok.drill_up([1, 3], [np.zeros(4, np.uint32), np.arange(3, dtype=np.uint32)], "sum").get_data().tolist() == [18.0, 22.0, 26.0]
+        c.destroy()
+    del os.environ[env]
+    print("direct transport, %s ok" % tag, flush=True)
+
 c = Comm.init_all([0])
 assert c.transport == "rccl" and c.world == 1
 run_steps(c, "rccl-all")

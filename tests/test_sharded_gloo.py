@@ -109,12 +109,13 @@ def test_partition_and_recipe_host_only():
     r = recipe("float32", nan, "sum")  # NaN never enters an additive collective: unset partial cells ship 0, counts say who contributed
     assert (r["local_method"], r["n_payloads"], r["payload_dtype"], r["payload_op"], r["finish"], r["zero_unset"]) == \
         (capi.PARTIAL_AVERAGE, 2, [f64, capi.DTYPES["int32"]], [capi.XCHG_SUM, capi.XCHG_SUM], capi.FINISH_ROUND, False)
-    r = recipe("float64", 0.0, "sum")  # float64 cells are their own accumulator
-    assert (r["local_method"], r["n_payloads"], r["payload_dtype"][0], r["finish"]) == (capi.METHODS["sum"], 1, f64, capi.FINISH_NONE)
-    r = recipe("float64", nan, "sum")  # masks are OR-ed (MAX), not added
-    assert (r["n_payloads"], r["payload_op"], r["finish"], r["zero_unset"]) == (2, [capi.XCHG_SUM, capi.XCHG_MAX], capi.FINISH_RESTORE, True)
-    r = recipe("int32", nan, "sum")  # integer sums are exact modulo 2^32 on every path
-    assert (r["n_payloads"], r["payload_dtype"][0], r["payload_op"][1], r["zero_unset"]) == (2, capi.DTYPES["int32"], capi.XCHG_MAX, False)
+    r = recipe("float64", nan, "sum")  # the same for Float64 cells (rounding is the identity there)
+    assert (r["local_method"], r["n_payloads"], r["payload_dtype"][0], r["finish"], r["zero_unset"]) == (capi.PARTIAL_AVERAGE, 2, f64, capi.FINISH_ROUND, False)
+    r = recipe("int32", 0.0, "sum")  # integer sums are exact modulo 2^32 on every path: the typed partials travel
+    assert (r["local_method"], r["n_payloads"], r["payload_dtype"][0], r["finish"]) == (capi.METHODS["sum"], 1, capi.DTYPES["int32"], capi.FINISH_NONE)
+    r = recipe("int32", nan, "sum")  # the mask is primary: masks are OR-ed (MAX), not added
+    assert (r["n_payloads"], r["payload_dtype"][0], r["payload_op"], r["finish"], r["zero_unset"]) == \
+        (2, capi.DTYPES["int32"], [capi.XCHG_SUM, capi.XCHG_MAX], capi.FINISH_RESTORE, False)
     for dt in ("float32", "float64", "int32", "uint32"):
         r = recipe(dt, nan, "average")
         assert (r["local_method"], r["payload_dtype"][0], r["payload_op"], r["finish"], r["zero_unset"]) == \

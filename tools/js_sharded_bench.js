@@ -1,6 +1,9 @@
 'use strict';
 // Developer tool: cube.drillUp of the SHARDED dimension from Node (setDevices; on a one-GPU box the device is
 // named several times and the shards exchange directly), against the same cube on one device.
+//   OLAP_BENCH_DEVICES=0,0,0,0,0,0,0,0 OLAP_BENCH_SHAPE=320,5,5,5,5,5,5,10,20 node tools/js_sharded_bench.js
+// Per call it prints the SUSTAINED time (a loop closed by a one-cell read: what the GPU needs when the host keeps up)
+// and the ISSUE time (how long the calls take to return, device idle in between: what the host needs per step).
 const olap = require('../olap-in-memory_amd/js');
 const { Cube, GenericDimension } = olap;
 
@@ -10,30 +13,49 @@ function build(devices, shape) {
   const cube = new Cube(dims);
   cube.createStoredMeasure('measure0', {}, 'float32', 0);
   const n = shape.reduce((a, b) => a * b, 1);
-  const data = new Float32Array(n);
-  for (let i = 0; i < n; ++i) data[i] = 0.5 + (i % 97) / 97;
-  cube.setData('measure0', data);
+  if (n <= 2e7) {
+    const data = new Float32Array(n);
+    for (let i = 0; i < n; ++i) data[i] = 0.5 + (i % 97) / 97;
+    cube.setData('measure0', data);
+  } else {
+    cube.storedMeasures.measure0.fill(1); // large cubes: filled on the device(s)
+  }
   olap.setDevices(null);
   return cube;
 }
 
-function time(label, fn, reps = 200) {
-  for (let i = 0; i < 10; ++i) fn();
+function wait(cube) {
+  return cube.storedMeasures.measure0.getValue(0); // closes the loop: waits for the device
+}
+
+function time(label, cube, fn, reps) {
+  for (let i = 0; i < 5; ++i) fn();
+  wait(fn());
   const t0 = process.hrtime.bigint();
   let last;
   for (let i = 0; i < reps; ++i) last = fn();
-  last.getSingleData ? null : null;
-  const v = last.storedMeasures.measure0.getValue(0); // closes the loop: waits for the device
-  const us = Number(process.hrtime.bigint() - t0) / 1e3 / reps;
-  console.log(`${label.padEnd(64)} ${us.toFixed(1).padStart(9)} us   (cell 0 = ${v})`);
+  const v = wait(last);
+  const sustained = Number(process.hrtime.bigint() - t0) / 1e3 / reps;
+  // issue time: each call starts on an idle device and is timed until it RETURNS (nothing is waited for inside)
+  let issue = 0;
+  for (let i = 0; i < reps; ++i) {
+    const t1 = process.hrtime.bigint();
+    last = fn();
+    issue += Number(process.hrtime.bigint() - t1) / 1e3;
+    wait(last);
+  }
+  console.log(`${label.padEnd(66)} sustained ${sustained.toFixed(1).padStart(8)} us   issue ${(issue / reps).toFixed(1).padStart(7)} us   (cell 0 = ${v})`);
 }
 
-const shape = [320, 50, 625]; // 10^7 cells
+const shape = (process.env.OLAP_BENCH_SHAPE || '320,50,625').split(',').map(Number); // default 10^7 cells
 const devices = (process.env.OLAP_BENCH_DEVICES || '0,0').split(',').map(Number);
+const cells = shape.reduce((a, b) => a * b, 1);
+const reps = cells > 2e8 ? 30 : 200;
+const last = `dimension${shape.length - 1}`;
 const plain = build(null, shape);
+time(`one device:  cube.drillUp(dimension0, all)`, plain, () => plain.drillUp('dimension0', 'all'), reps);
+time(`one device:  cube.drillUp(${last}, all)`, plain, () => plain.drillUp(last, 'all'), reps);
 const sharded = build(devices, shape);
-console.log(`shape [${shape}] sharded over devices [${devices}] (${sharded.storedMeasures.measure0._native.isSharded ? 'sharded' : 'NOT sharded'})`);
-time('one device:  cube.drillUp(dimension0, all)', () => plain.drillUp('dimension0', 'all'));
-time('sharded:     cube.drillUp(dimension0, all)   partial + collective', () => sharded.drillUp('dimension0', 'all'));
-time('one device:  cube.drillUp(dimension2, all)', () => plain.drillUp('dimension2', 'all'));
-time('sharded:     cube.drillUp(dimension2, all)   per shard', () => sharded.drillUp('dimension2', 'all'));
+console.log(`shape [${shape}] sharded over devices [${devices}] (${sharded.storedMeasures.measure0._native.isSharded ? 'sharded' : 'NOT sharded'}; OLAP_SHARD_THREADS=${process.env.OLAP_SHARD_THREADS || ''} OLAP_SHARD_NO_FUSED=${process.env.OLAP_SHARD_NO_FUSED || ''})`);
+time(`sharded:     cube.drillUp(dimension0, all)   partial + collective`, sharded, () => sharded.drillUp('dimension0', 'all'), reps);
+time(`sharded:     cube.drillUp(${last}, all)   per shard`, sharded, () => sharded.drillUp(last, 'all'), reps);
