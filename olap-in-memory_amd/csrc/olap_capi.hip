@@ -1320,7 +1320,7 @@ extern "C" int olap_load_plan(olap_plan **out, int dtype, int my_default_kind, i
     olap_plan_destroy(p);
     return rc;
   }
-  p->kernel_name = p->vec > 1 ? "load_scatter (16-byte lanes)" : "load_scatter";
+  p->kernel_name = p->vec > 1 ? "load_scatter (16-byte lanes)" : "load_scatter (16-byte runs of the other store)";
   *out = p;
   return OLAP_OK;
 }

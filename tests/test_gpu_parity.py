@@ -831,6 +831,50 @@ def test_load_randomized(seed):
     assert same_typed(gm.get_data(), ev)
 
 
+@pytest.mark.parametrize("case", range(16))
+def test_load_lane_forms(case):
+    """The two wide forms of load: 16-byte lanes when the trailing dimensions are left alone (contiguous on both sides),
+    and 16 bytes of the OTHER store per lane with one index decode when the innermost dimension itself is remapped
+    (rows that end inside a lane's run, a cube that ends inside one, items this store lacks, 8-byte cells)."""
+    rng = np.random.default_rng(7700 + case)
+    shapes = [([6, 8, 12], [4, 8, 12], "outer"), ([3, 40], [5, 40], "outer"), ([9, 4, 4], [9, 4, 4], "none"), ([5, 7], [5, 7], "inner"),
+              ([4, 10], [6, 10], "inner"), ([3, 3, 5], [3, 2, 6], "all"), ([37], [41], "inner"), ([2, 1000], [2, 1000], "inner")]
+    my_len, his_len, what = shapes[case % 8]
+    maps = []
+    for d, (ml, hl) in enumerate(zip(my_len, his_len)):
+        remap = ml != hl or what == "all" or (what == "outer" and d == 0) or (what == "inner" and d == len(my_len) - 1)
+        if remap:
+            m_ = rng.permutation(max(ml, hl))[:hl]
+            m_ = np.where(m_ < ml, m_, -1)
+        else:
+            m_ = np.arange(hl)
+        maps.append(m_.astype(np.int32))
+    type_name = ["float32", "float64", "int32", "uint32"][(case // 8 + case) % 4]
+    my_default = float("nan") if case % 3 == 0 else 0.0
+    his_default = float("nan") if case % 2 else 0.0
+    n_my, n_his = int(np.prod(my_len)), int(np.prod(his_len))
+    mine = np.where(rng.random(n_my) < 0.5, my_default, rng.integers(1, 50, size=n_my).astype(np.float64))
+    his = np.where(rng.random(n_his) < 0.4, his_default, rng.integers(50, 99, size=n_his).astype(np.float64))
+
+    def both(n, dflt, dense):
+        o = OracleStore(n, type_name, dflt)
+        typed = to_typed(dense, type_name).astype(np.float64)
+        if type_name in ("int32", "uint32") and dflt != dflt:
+            typed = np.where(np.isnan(dense), np.nan, typed)
+        o.set_data(typed)
+        g = pkg.HipStore(n, type_name, dflt)
+        g.set_data_f64(dense)
+        return o, g
+
+    om, gm = both(n_my, my_default, mine)
+    oh, gh = both(n_his, his_default, his)
+    om.load(oh, my_len, his_len, maps)
+    gm.load(gh, my_len, his_len, maps)
+    ev, es = expected_typed(om)
+    assert np.array_equal(gm.get_status(), es)
+    assert same_typed(gm.get_data(), ev)
+
+
 @pytest.mark.parametrize("seed", range(40))
 def test_drilldown_with_distributions_randomized(seed):
     """drillDown with per-cell weights (in-memory.js:389-401) on one or two refined dimensions."""

@@ -35,8 +35,10 @@ __device__ __forceinline__ uint32_t xcd_contiguous(uint32_t b, uint32_t n) {
 enum { READ = 0, WRITE = 1, COPY = 2, TRANS = 3 };
 
 // source [R][C] cells, destination [C][R] (TRANS) or [R][C] (COPY).  Tile: TX cells along C, TY rows.
-template <int TX, int TY, int MODE, int ORDER>
-__global__ __launch_bounds__(256) void pattern(const float *__restrict__ in, float *__restrict__ out, uint32_t R, uint32_t C, float *sink) {
+// OCC = waves per SIMD the compiler must leave room for (the product's transpose holds its tile in LDS: 33 KB per
+// 64 x 128 tile = 4 workgroups = 4 waves per SIMD; without LDS up to 8 fit)
+template <int TX, int TY, int MODE, int ORDER, int OCC>
+__global__ __launch_bounds__(256, OCC) void pattern(const float *__restrict__ in, float *__restrict__ out, uint32_t R, uint32_t C, float *sink) {
   constexpr int F4 = TX * TY / 4;      // 16-byte groups per tile
   constexpr int U = F4 / 256;          // per lane
   const uint32_t tiles_x = (C + TX - 1) / TX, tiles_y = (R + TY - 1) / TY;
@@ -128,17 +130,17 @@ static float timed(F fn, int iters = 10, int rounds = 5) {
   return ms[ms.size() / 2] * 1e3f;  // us
 }
 
-template <int TX, int TY, int ORDER>
+template <int TX, int TY, int ORDER, int OCC>
 static void run_tile(const float *in, float *out, float *sink, uint32_t R, uint32_t C) {
   const uint32_t tiles_x = (C + TX - 1) / TX, tiles_y = (R + TY - 1) / TY;
   const unsigned grid = ORDER == 2 ? ((tiles_x + 3) / 4) * ((tiles_y + 3) / 4) * 16 : tiles_x * tiles_y;
   const double bytes = (double)R * C * 4;
-  const float r = timed([&] { hipLaunchKernelGGL((pattern<TX, TY, READ, ORDER>), grid, 256, 0, 0, in, out, R, C, sink); });
-  const float w = timed([&] { hipLaunchKernelGGL((pattern<TX, TY, WRITE, ORDER>), grid, 256, 0, 0, in, out, R, C, sink); });
-  const float c = timed([&] { hipLaunchKernelGGL((pattern<TX, TY, COPY, ORDER>), grid, 256, 0, 0, in, out, R, C, sink); });
-  const float t = timed([&] { hipLaunchKernelGGL((pattern<TX, TY, TRANS, ORDER>), grid, 256, 0, 0, in, out, R, C, sink); });
-  printf("  tile %3d x %3d (reads %4d B, writes %4d B) order %d:  read %6.1f us %.3f | write %6.1f us %.3f | strided copy %6.1f us %.3f | transposed %6.1f us %.3f\n",
-         TX, TY, TX * 4, TY * 4, ORDER, r, bytes / (r * 1e-6) / 8e12, w, bytes / (w * 1e-6) / 8e12, c, 2 * bytes / (c * 1e-6) / 8e12, t,
+  const float r = timed([&] { hipLaunchKernelGGL((pattern<TX, TY, READ, ORDER, OCC>), grid, 256, 0, 0, in, out, R, C, sink); });
+  const float w = timed([&] { hipLaunchKernelGGL((pattern<TX, TY, WRITE, ORDER, OCC>), grid, 256, 0, 0, in, out, R, C, sink); });
+  const float c = timed([&] { hipLaunchKernelGGL((pattern<TX, TY, COPY, ORDER, OCC>), grid, 256, 0, 0, in, out, R, C, sink); });
+  const float t = timed([&] { hipLaunchKernelGGL((pattern<TX, TY, TRANS, ORDER, OCC>), grid, 256, 0, 0, in, out, R, C, sink); });
+  printf("  tile %3d x %3d (reads %4d B, writes %4d B) order %d, %d waves/SIMD:  read %6.1f us %.3f | write %6.1f us %.3f | strided copy %6.1f us %.3f | transposed %6.1f us %.3f\n",
+         TX, TY, TX * 4, TY * 4, ORDER, OCC, r, bytes / (r * 1e-6) / 8e12, w, bytes / (w * 1e-6) / 8e12, c, 2 * bytes / (c * 1e-6) / 8e12, t,
          2 * bytes / (t * 1e-6) / 8e12);
   fflush(stdout);
 }
@@ -159,18 +161,17 @@ int main(int argc, char **argv) {
     CK(hipMemset(in, 1, n * 4));
     const float s = timed([&] { hipLaunchKernelGGL(stream_copy, 8192, 256, 0, 0, (const f4 *)in, (f4 *)out, n / 4); });
     printf("[%u, %u] (%.0f MB each way): streaming copy %6.1f us %.3f of 8 TB/s\n", R, C, n * 4 / 1e6, s, 2.0 * n * 4 / (s * 1e-6) / 8e12);
-    run_tile<64, 128, 0>(in, out, sink, R, C);
-    run_tile<64, 128, 2>(in, out, sink, R, C);  // the product's tile and walk
-    run_tile<128, 64, 2>(in, out, sink, R, C);
-    run_tile<128, 128, 2>(in, out, sink, R, C);
-    run_tile<64, 256, 2>(in, out, sink, R, C);
-    run_tile<256, 64, 2>(in, out, sink, R, C);
-    run_tile<256, 128, 2>(in, out, sink, R, C);
-    run_tile<128, 256, 2>(in, out, sink, R, C);
-    run_tile<512, 64, 2>(in, out, sink, R, C);
-    run_tile<64, 512, 2>(in, out, sink, R, C);
-    run_tile<1024, 32, 2>(in, out, sink, R, C);
-    run_tile<32, 1024, 2>(in, out, sink, R, C);
+    run_tile<64, 128, 2, 4>(in, out, sink, R, C);  // the product's tile, walk and residency
+    run_tile<64, 128, 2, 8>(in, out, sink, R, C);
+    run_tile<64, 128, 0, 8>(in, out, sink, R, C);
+    run_tile<128, 64, 2, 8>(in, out, sink, R, C);
+    run_tile<128, 128, 2, 4>(in, out, sink, R, C);
+    run_tile<64, 256, 2, 4>(in, out, sink, R, C);
+    run_tile<256, 64, 2, 4>(in, out, sink, R, C);
+    run_tile<128, 256, 2, 2>(in, out, sink, R, C);
+    run_tile<256, 128, 2, 2>(in, out, sink, R, C);
+    run_tile<64, 512, 2, 2>(in, out, sink, R, C);
+    run_tile<512, 64, 2, 2>(in, out, sink, R, C);
     CK(hipFree(in));
     CK(hipFree(out));
   }

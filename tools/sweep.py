@@ -93,8 +93,26 @@ ms, gbs, k = bench(lambda: pkg.Plan.reorder("float32", 0.0, [10000, 10000], [1, 
 rows.append(("reorder transpose [1e4,1e4]", ms, gbs, k))
 ms, gbs, k = bench(lambda: pkg.Plan.reorder("float32", 0.0, [3652, 100, 274], [2, 1, 0]), n5, n5)
 rows.append(("reorder C5 [3652,100,274] reversed", ms, gbs, k))
+# load (in-memory.js:139-176): the other store's cells scattered into this one through per-dimension item maps
+sel_id = [np.arange(10, dtype=np.int32)] * 8
+ms, gbs, k = bench(lambda: pkg.Plan.load("float32", 0.0, 0.0, shape, shape, sel_id), n, n)
+rows.append(("load [10]^8 identity item maps", ms, gbs, k))
+perm4 = list(sel_id)
+perm4[4] = np.array([3, 1, 4, 0, 9, 2, 6, 5, 8, 7], np.int32)
+ms, gbs, k = bench(lambda: pkg.Plan.load("float32", 0.0, 0.0, shape, shape, perm4), n, n)
+rows.append(("load [10]^8 items of dim4 remapped", ms, gbs, k))
+perm7 = list(sel_id)
+perm7[7] = np.array([3, 1, 4, 0, 9, 2, 6, 5, 8, 7], np.int32)
+ms, gbs, k = bench(lambda: pkg.Plan.load("float32", 0.0, 0.0, shape, shape, perm7), n, n)
+rows.append(("load [10]^8 items of dim7 (innermost) remapped", ms, gbs, k))
+drop0 = list(sel_id)
+drop0[0] = np.array([0, 1, 2, -1, 3, 4, -1, 5, 6, 7], np.int32)  # two of his items are unknown here; mine has 8 (+ untouched cells)
+ms, gbs, k = bench(lambda: pkg.Plan.load("float32", 0.0, 0.0, [8] + shape[1:], shape, drop0), n, 8 * 10 ** 7)
+rows.append(("load [10]^8 -> [8,10^7] two items dropped", ms, (1e8 + 8e7) * 4 / (ms * 1e-3) / 1e9, k))
 if "--only-reorder" in sys.argv:
     rows = [r for r in rows if r[0].startswith("reorder")]
+if "--only-load" in sys.argv:
+    rows = [r for r in rows if r[0].startswith("load")]
 month_of_day = day_to_month
 ms, gbs, k = bench(lambda: pkg.Plan.drilldown("float32", 0.0, "sum", [G, 100, 274], s5, [month_of_day, ident(100), ident(274)]), G * 27400, n5)
 rows.append(("drillDown month->day", ms, gbs, k))
