@@ -246,6 +246,7 @@ struct olap_plan {
   bool xy_ok = false;                      // reorder of 4-byte cells without a mask: two-axis LDS transpose (olap_transpose.hip)
   TransposeXY xy{};
   DrillUpReduce reduce{};                  // S > 0: reduce regime of the one-axis drillUp
+  SegmentedRows seg{};                     // S_tot > 0: wide rows of that regime run as the row kernel over segments + a fold (all rules but product)
   bool dd_two_pass = false;                // float cells, no distributions: scale + broadcast
   bool dice_direct = false;                // dice of one dimension, rows not whole 16-byte groups: dice_direct_kernel
   DiceRows dice_rows{};
@@ -484,7 +485,12 @@ extern "C" int olap_drillup_plan(olap_plan **out, int dtype, int default_kind, i
       if (cells > 0 && cells < 131072 && longest >= 256) {
         DrillUpReduce &rd = p->reduce;
         uint64_t S;
-        if (a.inner <= 128) {
+        // (rows of up to 1 024 four-byte cells too when the 16-byte form below applies — one contiguous '-> all' group
+        // whose steps are whole 16-byte groups: a unit then streams its segment as ONE contiguous range, 1-7 rows per
+        // step, where the lane-per-cell split form reads 4 KB pieces a row apart: [4e5,250] -> [1,250] 88 us -> see DESIGN K1r)
+        const bool wide16 = a.inner > 128 && a.inner <= 1024 && contiguous && a.G == 1 && olap_dtype_size(dtype) == 4 && (a.K * a.inner) % 4 == 0 &&
+                            (a.inner % 4 == 0 || (a.inner % 2 == 0 && a.inner <= 512) || a.inner <= 256) && !getenv("OLAP_REDUCE_NO_WIDE");
+        if (a.inner <= 128 || wide16) {
           const uint64_t groups = a.outer * a.G;
           // Segments per group.  More, shorter segments lose to the per-unit epilogue and to the partials they write
           // and the merge reads back ([1e6,100] -> [1,100] with 4 096 units: 81 us; with 512: 65 us); fewer leave CUs
@@ -519,8 +525,11 @@ extern "C" int olap_drillup_plan(olap_plan **out, int dtype, int default_kind, i
           // 16 B form: one contiguous '-> all' group, whole rows and segments in multiples of 4 cells
           uint64_t seg_len = ((uint64_t)longest + S - 1) / S;
           seg_len = (seg_len + 3) & ~3ull;
-          uint32_t rows4 = 4;
+          // rows per step: a power of two whose cells are whole 16-byte groups (1 for rows of a multiple of 4 cells, 2 for
+          // even rows, 4 otherwise), doubled while the unit's lanes hold them
+          uint32_t rows4 = a.inner % 4 == 0 ? 1 : a.inner % 2 == 0 ? 2 : 4;
           while ((uint64_t)rows4 * 2 * a.inner <= (uint64_t)rd.unit * 4) rows4 *= 2;
+          if (rows4 < 4 && a.inner <= 128) rows4 = 4;  // (narrow rows: as before)
           if (contiguous && a.G == 1 && olap_dtype_size(dtype) == 4 && (a.K * a.inner) % 4 == 0 &&
               (uint64_t)rows4 * a.inner <= (uint64_t)rd.unit * 4) {
             // as many rows per step as the unit's lanes hold (whole 16-byte groups): 10 rows of 100 cells fill 250 of 256
@@ -562,6 +571,45 @@ extern "C" int olap_drillup_plan(olap_plan **out, int dtype, int default_kind, i
             S = std::max<uint64_t>(1, std::min<uint64_t>(s_bal, longest / 32));
           }
         }
+        if (rd.rows == 0 && !plan_dry() && !getenv("OLAP_NO_SEGMENTED_ROWS") && a.inner / (uint64_t)p->vec >= 128 && a.inner * olap_dtype_size(dtype) >= 2048) {
+          // Wide rows (beyond the cooperative forms): the row kernel over SEGMENTS of the groups + a fold (see
+          // SegmentedRows) — as many segments as give the chip ~8 workgroups per CU, at least 16 members each.
+          int cus = 256;
+          {
+            int dev = 0, n = 0;
+            if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) cus = n;
+          }
+          const uint64_t n_vec = a.inner / (uint64_t)p->vec, bpr = (n_vec + kBlock - 1) / kBlock;
+          const uint64_t want = std::max<uint64_t>(1, (uint64_t)cus * 8 / std::max<uint64_t>(1, a.outer * bpr));
+          const uint64_t seg_len = std::max<uint64_t>(16, (a.K + want - 1) / want);
+          std::vector<uint32_t> sg_gstart{0}, sg_first{0};
+          for (uint64_t gi = 0; gi < a.G; ++gi) {
+            for (uint64_t j = gstart[gi]; j < gstart[gi + 1]; j += seg_len) sg_gstart.push_back((uint32_t)std::min<uint64_t>(j + seg_len, gstart[gi + 1]));
+            sg_first.push_back((uint32_t)sg_gstart.size() - 1);
+          }
+          const uint64_t s_tot = sg_gstart.size() - 1;
+          void *d_g = nullptr, *d_f = nullptr, *d_p = nullptr, *d_a = nullptr;
+          if (s_tot > a.G && a.outer * s_tot * bpr < 0x7FFFFFFFull && !(rc = upload(&d_g, sg_gstart.data(), sg_gstart.size() * 4)) &&
+              !(rc = upload(&d_f, sg_first.data(), sg_first.size() * 4))) {
+            hipError_t e1 = dev_alloc(&d_p, a.outer * s_tot * a.inner * sizeof(double));
+            if (e1 == hipSuccess) e1 = dev_alloc(&d_a, a.outer * s_tot * a.inner * sizeof(int32_t));
+            if (e1 == hipSuccess) {
+              p->seg.S_tot = (uint32_t)s_tot;
+              p->seg.gstart = (const uint32_t *)d_g;
+              p->seg.seg_start = (const uint32_t *)d_f;
+              p->seg.partial = d_p;
+              p->seg.aux = (int32_t *)d_a;
+            } else {
+              (void)hipGetLastError();  // no room for the partials: the split forms below need less
+            }
+          }
+          for (void *q : {d_g, d_f, d_p, d_a})
+            if (q) p->owned.push_back(q);
+          if (rc) {
+            olap_plan_destroy(p);
+            return rc;
+          }
+        }
         rd.S = (uint32_t)S;
         if (!rd.vec4 || rd.rows == 0) rd.seg_len = (uint32_t)((longest + S - 1) / S);
         hipError_t e = dev_alloc(&p->dev_tmp, cells * S * sizeof(Partial));
@@ -572,7 +620,9 @@ extern "C" int olap_drillup_plan(olap_plan **out, int dtype, int default_kind, i
         rd.part = (Partial *)p->dev_tmp;
       }
     }
-    if (p->reduce.S > 0)
+    if (p->seg.S_tot > 0 && method != OLAP_PRODUCT && method != OLAP_PARTIAL_AVERAGE)
+      p->kernel_name = "drillup_rows_kernel (segments)+segments_combine_kernel";
+    else if (p->reduce.S > 0)
       p->kernel_name = p->reduce.rows == 0 ? (p->reduce.vec4 ? "drillup_split4_kernel+drillup_merge_kernel" : "drillup_split_kernel+drillup_merge_kernel")
                        : p->reduce.vec4    ? (p->reduce.S == 1 ? "drillup_reduce4_kernel" : "drillup_reduce4_kernel+drillup_merge_kernel")
                                            : "drillup_reduce_kernel+drillup_merge_kernel";
@@ -1550,6 +1600,10 @@ static int run_typed(olap_plan *p, const void *in_v, const int32_t *in_s, void *
       a.total = a.outer * a.G * a.n_vec;
       a.blocks_per_row = (a.n_vec + kBlock - 1) / kBlock;
       { const char *x = getenv("OLAP_XCD_ORDER"); a.xcd_order = x ? atoi(x) : 1; }  // 0: A/B against the dispatch order
+      if (p->seg.S_tot > 0 && drillup_method != OLAP_PRODUCT && drillup_method != OLAP_PARTIAL_AVERAGE) {
+        e = Launch<T>::drillup_segmented(drillup_method, hs, vec, in, in_s, out, out_s, a, p->seg, stream);
+        break;
+      }
       if (p->reduce.S > 0) {
         e = Launch<T>::drillup_reduce(drillup_method, hs, in, in_s, out, out_s, a, p->reduce, stream);
         break;

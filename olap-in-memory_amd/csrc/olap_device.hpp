@@ -301,6 +301,33 @@ __device__ __forceinline__ bool cell_is_set(T v, int32_t st, bool has_status, bo
   return (!has_status || (st & OLAP_STATUS_SET)) && !Cell<T>::is_default(v, def_nan);
 }
 
+// One output cell from partial payloads added up (over the ranks of a sharded cube, olap_sharded.hip; over the segments
+// of a long group, segments_combine_kernel).  FINISH_ROUND / _AVERAGE: float64 partial sums (+ contribution
+// counts) -> typed cell, rounded ONCE — what the one-device kernels do with their accumulator: Agg::finish
+// (in-memory.js:323-331: divide by the Uint16 counter unless it wrapped to 0), then emit_cell.  Without counts (a sum
+// over a 0 default) "somebody contributed" does not matter: set <=> the rounded sum is not 0.
+template <typename T, typename P>
+__device__ __forceinline__ void finish_cell(int finish, P a, uint32_t b, bool has_b, bool def_nan, T &ov, int32_t &os) {
+  if (finish == OLAP_FINISH_ROUND || finish == OLAP_FINISH_AVERAGE) {
+    double r = (double)a;
+    const uint32_t c = has_b ? b : 1u;
+    bool has = c != 0 && !is_default_f64(r, def_nan);
+    if (finish == OLAP_FINISH_AVERAGE) {
+      const uint32_t c16 = c & 0xFFFFu;  // Uint16Array counter
+      if (c16) {
+        r = (has ? r : (def_nan ? __builtin_nan("") : 0.0)) / (double)c16;
+        has = !is_default_f64(r, def_nan);
+      }
+    }
+    emit_cell<T>(r, has, def_nan, ov, os);
+  } else {  // FINISH_NONE / FINISH_RESTORE: the payload is the typed cell (b: the OR of the masks)
+    const T v = (T)a;
+    const bool set = (!has_b || (b & OLAP_STATUS_SET) != 0) && !Cell<T>::is_default(v, def_nan);
+    ov = set ? v : Cell<T>::default_value(def_nan);
+    os = set ? OLAP_STATUS_SET : 0;
+  }
+}
+
 // Workgroups are dealt to the 8 XCDs round-robin (workgroup b runs on XCD b % 8) and each XCD has its own
 // L2.  Mapping b -> logical id so that every XCD owns one CONTIGUOUS range of logical ids keeps
 // neighbouring tiles (which share the 128-byte lines at their edges whenever a row is not line-aligned)

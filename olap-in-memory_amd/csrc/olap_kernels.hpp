@@ -1494,6 +1494,115 @@ __global__ __launch_bounds__(kBlock) void drillup_merge_few_kernel(T *__restrict
   if (st_out) st_out[cell] = os;
 }
 
+// Segmented rows (few output cells, long groups, rows wider than the cooperative forms take): every group's member
+// list is cut into segments, the ROW regime — the headline kernel, 16-byte or ragged lanes and all — reduces each
+// segment as if it were a group of its own (float64 partial sums + contribution counts for sum / average, the typed
+// pick for highest / lowest / first / last), and this kernel folds a group's segments, in order, into the output
+// cell: 64 adjacent cells x 4 lanes per cell, each lane a contiguous quarter of the segments, combined in lane order
+// (deterministic; additive methods are re-associated exactly as in the cooperative forms).
+struct SegmentedRows {
+  uint32_t S_tot;             // segments of all groups
+  const uint32_t *gstart;     // device [S_tot + 1]: the segments as contiguous member runs (they index the plan's `order`)
+  const uint32_t *seg_start;  // device [G + 1]: first segment of every group
+  void *partial;              // [outer, S_tot, inner]: float64 sums, or typed picks
+  int32_t *aux;               // [outer, S_tot, inner]: contribution counts, or the picks' masks (where needed)
+};
+
+template <typename T, int METHOD>
+__global__ __launch_bounds__(kBlock) void segments_combine_kernel(const void *__restrict__ partial, const int32_t *__restrict__ aux, T *__restrict__ out,
+                                                                  int32_t *__restrict__ st_out, const DrillUpAxis a, const SegmentedRows sg) {
+  constexpr bool kAdd = (METHOD == OLAP_SUM || METHOD == OLAP_AVERAGE);
+  __shared__ double l_acc[kBlock];
+  __shared__ uint32_t l_cnt[kBlock];
+  const uint32_t x = threadIdx.x & 63, y = threadIdx.x >> 6;
+  const uint64_t strips = (a.inner + 63) / 64;
+  const uint64_t og = blockIdx.x / strips;
+  const uint64_t i = (blockIdx.x - og * strips) * 64 + x;
+  const uint64_t g = og % a.G, o = og / a.G;
+  const bool def_nan = a.def_nan != 0;
+  const bool live = i < a.inner;
+  const uint32_t s0 = sg.seg_start[g], s1 = sg.seg_start[g + 1];
+  const uint32_t per = (s1 - s0 + 3) / 4;
+  const uint32_t sb = s0 + y * per < s1 ? s0 + y * per : s1, se = sb + per < s1 ? sb + per : s1;
+  const uint64_t base = o * sg.S_tot * a.inner + i;
+  double acc = 0.0;
+  uint32_t cnt = 0;
+  Pick<T, kAdd ? OLAP_FIRST : METHOD> pk;
+  pk.init();
+  if (live) {
+    constexpr int U = 8;
+    for (uint32_t s = sb; s < se; s += U) {
+      if constexpr (kAdd) {
+        double v[U];
+        uint32_t c[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const bool in = s + u < se;
+          const uint64_t at = base + (uint64_t)(in ? s + u : sb) * a.inner;
+          v[u] = in ? ((const double *)partial)[at] : 0.0;
+          c[u] = (in && aux) ? (uint32_t)aux[at] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          acc += v[u];
+          cnt += c[u];
+        }
+      } else {
+        T v[U];
+        int32_t f[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const bool in = s + u < se;
+          const uint64_t at = base + (uint64_t)(in ? s + u : sb) * a.inner;
+          v[u] = ((const T *)partial)[at];
+          f[u] = in ? (aux ? aux[at] : OLAP_STATUS_SET) : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) pk.add_if(cell_is_set<T>(v[u], f[u], true, def_nan), v[u]);
+      }
+    }
+  }
+  if constexpr (kAdd) {
+    l_acc[threadIdx.x] = acc;
+    l_cnt[threadIdx.x] = cnt;
+  } else if constexpr (sizeof(T) == 4) {  // a pick and whether there is one: 4-byte cells ride the count slots
+    l_acc[threadIdx.x] = pk.has ? 1.0 : 0.0;
+    reinterpret_cast<T *>(l_cnt)[threadIdx.x] = pk.cur;
+  } else {  // 8-byte cells ride the float64 slots
+    reinterpret_cast<T *>(l_acc)[threadIdx.x] = pk.cur;
+    l_cnt[threadIdx.x] = pk.has ? 1u : 0u;
+  }
+  __syncthreads();
+  if (y != 0 || !live) return;
+  T ov;
+  int32_t os;
+  if constexpr (kAdd) {
+    for (uint32_t q = 1; q < 4; ++q) {
+      acc += l_acc[q * 64 + x];
+      cnt += l_cnt[q * 64 + x];
+    }
+    finish_cell<T, double>(METHOD == OLAP_AVERAGE ? OLAP_FINISH_AVERAGE : OLAP_FINISH_ROUND, acc, cnt, aux != nullptr, def_nan, ov, os);
+  } else {
+    for (uint32_t q = 1; q < 4; ++q) {
+      T v;
+      bool has;
+      if constexpr (sizeof(T) == 8) {
+        v = reinterpret_cast<const T *>(l_acc)[q * 64 + x];
+        has = l_cnt[q * 64 + x] != 0;
+      } else {
+        v = reinterpret_cast<const T *>(l_cnt)[q * 64 + x];
+        has = l_acc[q * 64 + x] != 0.0;
+      }
+      pk.add_if(has, v);
+    }
+    ov = pk.has ? pk.cur : Cell<T>::default_value(def_nan);
+    os = pk.has ? OLAP_STATUS_SET : 0;
+  }
+  const uint64_t at = (o * a.G + g) * a.inner + i;
+  out[at] = ov;
+  if (st_out) st_out[at] = os;
+}
+
 // ======================================================================= K1g: drillUp, any maps
 // The store method accepts a map on every dimension (in-memory.js:270-274).  One lane per output
 // cell walks the cartesian product of its groups' member lists in ascending flat order.
@@ -3001,6 +3110,8 @@ struct Launch {
                                 hipStream_t stream);
   static hipError_t average_finish(T *values, const int32_t *counts, int32_t *status, uint64_t n, int def_nan,
                                    hipStream_t stream);
+  static hipError_t drillup_segmented(int method, bool has_status, int vec, const T *in, const int32_t *st_in, T *out, int32_t *st_out,
+                                      const DrillUpAxis &a, const SegmentedRows &sg, hipStream_t stream);
   static hipError_t total(const T *values, const int32_t *status, uint64_t n, int def_nan, void *workspace, double *total,
                           unsigned long long *count, hipStream_t stream);
   static hipError_t compact_count(const T *values, const int32_t *status, uint64_t n, uint64_t chunk, unsigned n_chunks,
@@ -3312,7 +3423,10 @@ static hipError_t drillup_reduce_launch(bool has_status, const T *in, const int3
   const uint64_t cells = a.outer * a.G * a.inner;
   constexpr bool kAdditive = (METHOD == OLAP_SUM || METHOD == OLAP_AVERAGE || METHOD == OLAP_PARTIAL_AVERAGE);
   const bool fast = kAdditive && !has_status && !a.def_nan;
-  if (rd.rows > 0) {  // cooperative form (inner <= 128)
+  // cooperative form: rows of up to 128 cells, or — 16-byte form only — of up to 1 024 (the scalar form gives a lane
+  // one cell of one row per step: rows must fit the unit's lanes; otherwise the lane-per-cell split form below)
+  const bool vec4_now = rd.vec4 && a.aligned16 && sizeof(T) == 4;
+  if (rd.rows > 0 && (vec4_now || a.inner <= rd.unit)) {
     const uint64_t upb = kBlock / rd.unit;
     const unsigned grid = (unsigned)((a.outer * a.G * rd.S + upb - 1) / upb);
     if (rd.vec4 && a.aligned16 && sizeof(T) == 4) {
@@ -3331,7 +3445,7 @@ static hipError_t drillup_reduce_launch(bool has_status, const T *in, const int3
       else if (kAdditive && fast) hipLaunchKernelGGL((drillup_reduce_kernel<T, METHOD, false, kAdditive>), grid, kBlock, 0, stream, in, st_in, a, r1);
       else hipLaunchKernelGGL((drillup_reduce_kernel<T, METHOD, false, false>), grid, kBlock, 0, stream, in, st_in, a, r1);
     }
-  } else if (rd.vec4 && a.aligned16 && sizeof(T) == 4 && a.inner % 4 == 0) {  // 16-byte lanes
+  } else if (rd.rows == 0 && rd.vec4 && a.aligned16 && sizeof(T) == 4 && a.inner % 4 == 0) {  // 16-byte lanes
     const unsigned grid = grid_for(cells / 4 * rd.S);
     if (has_status) hipLaunchKernelGGL((drillup_split4_kernel<T, METHOD, true, false>), grid, kBlock, 0, stream, in, st_in, a, rd);
     else if (kAdditive && fast) hipLaunchKernelGGL((drillup_split4_kernel<T, METHOD, false, kAdditive>), grid, kBlock, 0, stream, in, st_in, a, rd);
@@ -3362,6 +3476,41 @@ hipError_t Launch<T>::drillup_reduce(int method, bool has_status, const T *in, c
     case OLAP_PARTIAL_AVERAGE: return drillup_reduce_launch<T, OLAP_PARTIAL_AVERAGE>(has_status, in, st_in, out, st_out, a, rd, stream);
     default: return drillup_reduce_launch<T, OLAP_PRODUCT>(has_status, in, st_in, out, st_out, a, rd, stream);
   }
+}
+
+template <typename T>
+hipError_t Launch<T>::drillup_segmented(int method, bool has_status, int vec, const T *in, const int32_t *st_in, T *out, int32_t *st_out,
+                                        const DrillUpAxis &a, const SegmentedRows &sg, hipStream_t stream) {
+  if (a.outer * a.G * a.inner == 0) return hipSuccess;
+  const bool additive = method == OLAP_SUM || method == OLAP_AVERAGE;
+  const bool mask_primary = has_status;  // (the plan passes the mask only where it carries information)
+  // stage 1: the row regime over the segments
+  DrillUpAxis a1 = a;
+  a1.G = sg.S_tot;
+  a1.gstart = sg.gstart;
+  a1.gtile = nullptr;
+  a1.n_gtile = 0;
+  a1.perm_cell = nullptr;
+  a1.total = a1.outer * a1.G * a1.n_vec;
+  a1.aligned16 = a.aligned16;  // (the partial buffers come from the pool: 256-byte aligned)
+  const bool want_aux = additive ? (method == OLAP_AVERAGE || a.def_nan || mask_primary) : mask_primary;
+  int32_t *aux = want_aux ? sg.aux : nullptr;
+  hipError_t e = drillup_axis(additive ? OLAP_PARTIAL_AVERAGE : method, has_status, vec, in, st_in, (T *)sg.partial, aux, a1, stream);
+  if (e != hipSuccess) return e;
+  // stage 2: a group's segments folded in order
+  const uint64_t blocks = a.outer * a.G * ((a.inner + 63) / 64);
+  if (blocks >= 0x7FFFFFFFull) return hipErrorInvalidValue;
+#define OLAP_SEGC(M) hipLaunchKernelGGL((segments_combine_kernel<T, M>), (unsigned)blocks, kBlock, 0, stream, (const void *)sg.partial, (const int32_t *)aux, out, st_out, a, sg)
+  switch (method) {
+    case OLAP_SUM: OLAP_SEGC(OLAP_SUM); break;
+    case OLAP_AVERAGE: OLAP_SEGC(OLAP_AVERAGE); break;
+    case OLAP_HIGHEST: OLAP_SEGC(OLAP_HIGHEST); break;
+    case OLAP_LOWEST: OLAP_SEGC(OLAP_LOWEST); break;
+    case OLAP_FIRST: OLAP_SEGC(OLAP_FIRST); break;
+    default: OLAP_SEGC(OLAP_LAST); break;
+  }
+#undef OLAP_SEGC
+  return hipGetLastError();
 }
 
 template <typename T, bool HS>

@@ -398,31 +398,6 @@ __global__ __launch_bounds__(kBlock) void restore_default_kernel(const T *src, c
     if (dst_status) dst_status[i] = set ? OLAP_STATUS_SET : 0;
   }
 }
-// One output cell from the payloads added over the ranks.  FINISH_ROUND / _AVERAGE: float64 partial sums (+ contribution
-// counts) -> typed cell, rounded ONCE — what the one-device kernels do with their accumulator: Agg::finish
-// (in-memory.js:323-331: divide by the Uint16 counter unless it wrapped to 0), then emit_cell.  Without counts (a sum
-// over a 0 default) "somebody contributed" does not matter: set <=> the rounded sum is not 0.
-template <typename T, typename P>
-__device__ __forceinline__ void finish_cell(int finish, P a, uint32_t b, bool has_b, bool def_nan, T &ov, int32_t &os) {
-  if (finish == OLAP_FINISH_ROUND || finish == OLAP_FINISH_AVERAGE) {
-    double r = (double)a;
-    const uint32_t c = has_b ? b : 1u;
-    bool has = c != 0 && !is_default_f64(r, def_nan);
-    if (finish == OLAP_FINISH_AVERAGE) {
-      const uint32_t c16 = c & 0xFFFFu;  // Uint16Array counter
-      if (c16) {
-        r = (has ? r : (def_nan ? __builtin_nan("") : 0.0)) / (double)c16;
-        has = !is_default_f64(r, def_nan);
-      }
-    }
-    emit_cell<T>(r, has, def_nan, ov, os);
-  } else {  // FINISH_NONE / FINISH_RESTORE: the payload is the typed cell (b: the OR of the masks)
-    const T v = (T)a;
-    const bool set = (!has_b || (b & OLAP_STATUS_SET) != 0) && !Cell<T>::is_default(v, def_nan);
-    ov = set ? v : Cell<T>::default_value(def_nan);
-    os = set ? OLAP_STATUS_SET : 0;
-  }
-}
 template <typename T>
 __global__ __launch_bounds__(kBlock) void partial_round_kernel(const double *sums, const int32_t *counts, T *values, int32_t *status,
                                                                uint64_t n, int def_nan_i, int finish) {

@@ -1469,7 +1469,8 @@ def test_drillup_multi_mixed_stores_and_plan_level():
 @pytest.mark.parametrize("method", ["sum", "average", "highest", "first", "last", "product"])
 @pytest.mark.parametrize("type_name,default", [("float32", 0.0), ("float32", float("nan")), ("int32", 0.0), ("uint32", float("nan")), ("float64", 0.0)])
 @pytest.mark.parametrize("lens,axis,kind", [([3000, 132], 0, "all"), ([2, 1500, 256], 1, "all"), ([2600, 200], 0, "halves"), ([3, 900, 516], 1, "interleaved"),
-                                            ([2100, 250], 0, "all")])
+                                            ([2100, 250], 0, "all"), ([1200, 1000], 0, "all"), ([1300, 1020], 0, "all"), ([1100, 2052], 0, "all"), ([2001, 251], 0, "all"),
+                                            ([1500, 514], 0, "all")])
 def test_split_regime_wide_rows(lens, axis, kind, type_name, default, method):
     """Few output cells, long groups, rows wider than 128 cells: segments of every group are streamed by lanes that own
     four adjacent output cells (drillup_split4_kernel: 4-byte cells, rows of a multiple of 4 cells) or one
@@ -1491,9 +1492,22 @@ def test_split_regime_wide_rows(lens, axis, kind, type_name, default, method):
             vals = vals * 0.25
     dense = np.where(rng.random(n) < 0.3, default, vals)
     plan = pkg.Plan.drillup(type_name, default, method, lens, new, maps)
-    assert "split" in plan.kernel_name, plan.kernel_name
-    if type_name != "float64" and lens[-1] % 4 == 0:
-        assert "split4" in plan.kernel_name, plan.kernel_name
+    # one contiguous '-> all' group of rows up to 1 024 four-byte cells: the cooperative 16-byte form streams whole
+    # segments (drillup_reduce4_kernel); everything else here takes the lane-per-cell split forms
+    inner = int(np.prod(lens[axis + 1:]))
+    coop = (kind == "all" and type_name != "float64" and inner <= 1024 and (K * inner) % 4 == 0 and
+            (inner % 4 == 0 or (inner % 2 == 0 and inner <= 512) or inner <= 256))
+    item = 8 if type_name == "float64" else 4
+    vec = next(v for v in (16 // item, 2, 1) if inner % v == 0 and v <= 16 // item)
+    if coop:
+        assert "reduce4" in plan.kernel_name, plan.kernel_name
+    elif method != "product" and inner * item >= 2048 and inner // vec >= 128:
+        # rows of 2 KB and more: the row kernel over segments of the groups + a fold (SegmentedRows)
+        assert "segments" in plan.kernel_name, plan.kernel_name
+    else:
+        assert "split" in plan.kernel_name, plan.kernel_name
+        if type_name != "float64" and lens[-1] % 4 == 0:
+            assert "split4" in plan.kernel_name, plan.kernel_name
     o = OracleStore(n, type_name, default)
     typed = to_typed(dense, type_name).astype(np.float64)
     if type_name in ("int32", "uint32") and default != default:
