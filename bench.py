@@ -46,25 +46,26 @@ FRIENDLY_SHAPE = [320, 5, 5, 5, 5, 5, 5, 10, 20]  # 10^9 cells; 320 rows divide 
 LITERAL_SHAPE = [10] * 9
 
 
-def cpu_baseline(seconds_budget=8.0):
-    """Single-thread C port of the reference's Map-semantics drillUp loop on [10, 2*10^6] (2*10^7 cells)."""
+def cpu_baseline(seconds_budget=12.0):
+    """Single-thread C port of the reference's Map-semantics drillUp loop (in-memory.js:265-334: decode D digits, map,
+    re-encode, Map get / set per cell) on THE headline configuration itself: [10]*8, 10^8 cells, dimension0 -> all."""
     from oracle.oracle import OracleStore
 
-    lens = [10, 2_000_000]
-    n = lens[0] * lens[1]
+    lens = [10] * 8
+    n = int(np.prod(lens))
     s = OracleStore(n, "float32", 0.0)
     s.fill_seeded(20240807, 1.0)
-    maps = [np.zeros(10, np.uint32), np.arange(lens[1], dtype=np.uint32)]
+    maps = [np.zeros(10, np.uint32)] + [np.arange(10, dtype=np.uint32) for _ in lens[1:]]
     reps, spent = 0, 0.0
     while reps < 2 or (spent < seconds_budget and reps < 20):
         t0 = time.perf_counter()
-        out = s.drill_up(lens, [1, lens[1]], maps, "sum")
+        out = s.drill_up(lens, [1] + lens[1:], maps, "sum")
         spent += time.perf_counter() - t0
         reps += 1
         del out
     return {"value": n * reps / spent, "unit": "cells/s", "cores": 1, "kind": "port",
-            "sample": "drillUp(sum) dim0 of a [10, 2000000] float32 cube (2e7 cells), %d repetitions, "
-                      "oracle/olap_oracle.c (Map-semantics C port of in-memory.js:265-334)" % reps}
+            "sample": "the headline workload itself: drillUp(sum) dimension0->all of the [10]*8 float32 cube (1e8 cells, sample ratio 1), "
+                      "%d repetitions, oracle/olap_oracle.c (Map-semantics C port of in-memory.js:265-334)" % reps}
 
 
 def cpu_baseline_flat(seconds_budget=6.0):
@@ -124,7 +125,7 @@ def read_traffic():
         return None
     try:
         with open(best) as fh:
-            return json.load(fh).get("hbm_bytes_per_launch")
+            return json.load(fh).get("hbm_bytes_per_launch"), os.path.relpath(best, ROOT)
     except Exception:
         return None
 
@@ -252,14 +253,14 @@ def bench_config5(pkg, engine, torch):
     return res
 
 
-def bench_1e9_single_gpu(pkg, engine, torch, iters=10):
+def bench_1e9_single_gpu(pkg, engine, torch, iters=10, shapes=(("friendly_shape", FRIENDLY_SHAPE), ("literal_shape", LITERAL_SHAPE))):
     """BASELINE configs[3]'s whole 10^9-cell cube on ONE GPU (4 GB resident), both shapes: the N = 1 point of
     the strong-scaling series that `bench.py --gpus N` continues."""
     n = 10 ** 9
     vals = engine.empty(n, "float32")
     pkg.capi.check(pkg.lib().olap_fill_seeded(vals.data_ptr(), None, n, 0, 2, 20240807, 1.0, engine.stream()))
     res = {}
-    for label, shape in (("friendly_shape", FRIENDLY_SHAPE), ("literal_shape", LITERAL_SHAPE)):
+    for label, shape in shapes:
         n_out = n // shape[0]
         out = engine.empty(n_out, "float32")
         maps = [np.zeros(shape[0], np.uint32)] + [np.arange(l, dtype=np.uint32) for l in shape[1:]]
@@ -288,6 +289,12 @@ def launch_ranks(args):
     (never an exec of a process that has initialised HIP) and relay what they print."""
     import socket
 
+    import torch
+
+    have = torch.cuda.device_count()  # (counting devices does not initialise the GPU)
+    if have < args.gpus and not args.rehearse:
+        sys.stderr.write("bench.py: --gpus %d but this node shows %d GPU(s): refusing to run fewer ranks than asked for\n" % (args.gpus, have))
+        raise SystemExit(2)
     with socket.socket() as sock:
         sock.bind(("127.0.0.1", 0))
         port = sock.getsockname()[1]
@@ -410,6 +417,18 @@ def main():
         else:
             comm = Comm.init_rank(Comm.unique_id(), 1, 0, local_rank)
         transport = comm.transport
+        # self-check: the communicator must span exactly the ranks asked for, each on a device of its own
+        if comm.world != args.gpus or (world > 1 and dist.get_world_size() != args.gpus):
+            sys.stderr.write("bench.py: --gpus %d but the communicator reports %d rank(s) (torch.distributed: %d)\n"
+                             % (args.gpus, comm.world, dist.get_world_size() if world > 1 else 1))
+            raise SystemExit(3)
+        if world > 1 and not args.rehearse:
+            mine = torch.tensor([local_rank], dtype=torch.int32, device="cuda")
+            devs = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(devs, mine)
+            if len({int(d.item()) for d in devs}) != world:
+                sys.stderr.write("bench.py: --gpus %d but the ranks sit on %d distinct device(s)\n" % (args.gpus, len({int(d.item()) for d in devs})))
+                raise SystemExit(3)
         store = ShardedStore(comm, lens, "float32", 0.0).fill_seeded(20240807, 1.0)
         pipelined = not (args.serial_steps or comm.transport == "detached")
         op = store.plan_drillup_dim0(np.zeros(lens[0], np.uint32), 1, "sum", placement=capi.PLACE_SCATTER, depth=2 if pipelined else 1)
@@ -502,8 +521,34 @@ def main():
         lit_elapsed = max_over_ranks(time.perf_counter() - t1)
         extra["literal_shape"] = {"shape": LITERAL_SHAPE, "steps": k_lit, "ms_per_step": lit_elapsed / k_lit * 1e3,
                                   "cells_per_s": 1e9 * k_lit / lit_elapsed, "rows_per_rank": [b - a for a, b in zip(lit.bounds, lit.bounds[1:])],
-                                  "partial_bytes_per_rank": int(lop.out_cells) * 4}
+                                  "partial_bytes_per_rank": int(lop.out_cells) * 8, "partial_type": "float64"}
         del lop, lit
+
+    kernel_ms_per_rank = None
+    if sharded_path:
+        # every rank's local reduction (HIP events on its own launch stream)
+        if world > 1:
+            t = torch.tensor([kernel_ms], dtype=torch.float64, device="cpu" if args.rehearse else "cuda")
+            gathered = [torch.zeros_like(t) for _ in range(world)]
+            dist.all_gather(gathered, t)
+            kernel_ms_per_rank = [float(x.item()) for x in gathered]
+        else:
+            kernel_ms_per_rank = [kernel_ms]
+        if transport == "rccl" and not args.rehearse:
+            # the N = 1 point of THIS series, measured in THIS run: the whole 10^9-cell cube of the headline shape on rank
+            # 0's GPU with the plain one-device plan (the other ranks wait) — so that a reader of the N-GPU line alone, or a
+            # sweep whose N = 1 line ran the 10^8 headline, divides like by like
+            barrier()
+            if rank == 0:
+                try:
+                    base = bench_1e9_single_gpu(pkg, engine, torch, iters=5, shapes=(("friendly_shape", FRIENDLY_SHAPE),))["friendly_shape"]
+                    extra["scaling_base"] = {"n_gpus": 1, "shape": FRIENDLY_SHAPE, "cells": 10 ** 9, "us_per_step": base["us_per_step"],
+                                             "cells_per_s": base["cells_per_s"], "kernel": base["kernel"],
+                                             "note": "same 10^9 cells on ONE GPU (rank 0's, this run, plain plan): divide `value` by this cells_per_s "
+                                                     "for the speed-up; the N = 1 bench line runs the 10^8-cell headline instead"}
+                except Exception as err:  # (an out-of-memory here must not cost the line)
+                    extra["scaling_base"] = {"error": str(err)[:200]}
+            barrier()
 
     with_mask = None
     ceiling = None
@@ -630,10 +675,23 @@ def main():
             "config": {"workload": workload, "shape": lens, "cells_per_gpu": local_cells, "cell_type": "float32",
                        "kernel": kernel_name, "collective": collective, "transport": transport, "steps_pipelined": bool(pipelined)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None if sharded_path else read_traffic(),
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "kernel_ms": kernel_ms, "algorithmic_bytes": alg_bytes,
                          "hbm_read_frac": local_cells * 4 / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
         }
+        if not sharded_path:
+            traffic = read_traffic()
+            if traffic:
+                line["roofline"]["traffic"] = traffic[0]
+                line["roofline"]["traffic_source"] = ("%s: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (gfx950 x2 FETCH_SIZE correction), "
+                                                      "recorded when the profile was taken — NOT measured in this run" % traffic[1])
+        else:
+            # what travels: every rank ships its float64 ACCUMULATORS (the reference never rounds between contributions)
+            line["config"].update({"partial_type": "float64", "partial_bytes_per_rank": int(n_out) * 8,
+                                   "result_cells_per_rank": int(n_out) // world if world else int(n_out)})
+            line["roofline"]["kernel_ms_per_rank"] = kernel_ms_per_rank
+            line["cpu_baseline_ref"] = ("timed on rank 0 at N = 1 only (the contract): see `cpu_baseline` of the N = 1 line of this sweep "
+                                        "(BENCH_rNN.json); a reported baseline, not a target")
         if ceiling:
             line["roofline"].update({"read_ceiling": ceiling, "frac_of_read_ceiling": achieved / ceiling,
                                      "read_ceiling_note": "plain 16-byte streaming read of the same 400 MB buffer, same run"})

@@ -29,6 +29,20 @@
 // i.e. the memory system, not latency or residency, bounds this access pattern; 128 x 128, 64 x 256 and 128 x 256
 // tiles with 512 / 1024 lanes (512-byte reads, 1 KB writes: within +-5 %); 16-byte accesses at cell-aligned addresses
 // instead of the 4-byte lanes on odd extents (free in the streaming kernels, 25 % SLOWER here: 245 against 195 us).
+//
+// Round 3: WHAT bounds it.  tools/pattern_ceiling.hip moves the same tiles with the same addresses, run lengths and
+// walk but no LDS, no barrier and full occupancy (registers to registers, the cells arrive scrambled): that pattern
+// ceiling is 148-190 us on the shapes below (0.53-0.68 of 8 TB/s; its read side alone runs at streaming speed,
+// 0.75-0.85, its write side — 512-byte runs a destination row apart — at 0.42-0.66), and this kernel reaches 0.86-1.0
+// of it on the same box (profiles/pattern_ceiling_r03.txt, transpose_probe_r03.txt).  The counters
+// (profiles/traffic_r03_kernels.json) rule the other suspects out: traffic 1.07-1.12 x algorithmic, no LDS bank
+// conflicts, address translation misses <= 2.5 % of the requests ([10]^8 reversed; 0.0-0.4 % elsewhere), and NO
+// back-pressure from the memory side of the L2 (write-request / read-credit stalls 0.00-0.03 of its busy cycles, against
+// ~0.2 for the streaming kernels that saturate HBM).  Measured and dropped on that evidence: workgroups that walk a
+// sequence of tiles with the NEXT tile's loads in flight (in registers) while the current tile leaves — twice the loads
+// in flight per CU for the same LDS: equal on [10^4,10^4] (169 against 170 us), 15-40 % SLOWER everywhere else
+// ([3652,27400] 213 against 177 us; profiles/transpose_stream_ab_r03.txt): once more many short-lived workgroups,
+// dispatched in tile order, beat long-lived ones that drift apart.
 #include <hip/hip_runtime.h>
 
 #include "olap_device.hpp"

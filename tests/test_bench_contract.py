@@ -27,8 +27,9 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     roof = d["roofline"]
     assert roof["bound"] == "hbm" and roof["unit"] == "GB/s" and roof["peak"] == 8000.0
     assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-9 and 0.3 < roof["frac"] < 1.0
-    assert roof["traffic"] is None or roof["traffic"] > 0
+    assert roof["traffic"] is None or (roof["traffic"] > 0 and "NOT measured in this run" in roof["traffic_source"])
     cpu = d["cpu_baseline"]
+    assert "1e8 cells" in cpu["sample"] and "sample ratio 1" in cpu["sample"]  # the baseline runs the headline configuration itself
     assert cpu["kind"] in ("port", "reference") and cpu["cores"] >= 1 and cpu["value"] > 0 and isinstance(cpu["sample"], str)
     # whole-job throughput and the per-step time describe the same run
     cells = d["config"]["cells_per_gpu"]
@@ -51,6 +52,12 @@ def test_bench_sharded_code_path_on_one_rank():
     assert d["serial_steps"]["ms_per_step"] > 0 and d["literal_shape"]["rows_per_rank"] == [10]
     assert abs(d["value"] - 1e9 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
     assert 0.3 < d["roofline"]["frac"] < 1.0
+    # the line stands on its own in a scaling sweep: the N = 1 point of the same 10^9 cells, what travels, every rank's kernel
+    base = d["scaling_base"]
+    assert base["n_gpus"] == 1 and base["cells"] == 10 ** 9 and base["cells_per_s"] > 1e11 and base["shape"] == d["config"]["shape"]
+    assert d["config"]["partial_type"] == "float64" and d["config"]["partial_bytes_per_rank"] == 8 * 10 ** 9 // 320
+    assert len(d["roofline"]["kernel_ms_per_rank"]) == 1 and isinstance(d["cpu_baseline_ref"], str)
+    assert d["literal_shape"]["partial_bytes_per_rank"] == 8 * 10 ** 8
 
 
 @pytest.mark.gpu
@@ -65,3 +72,16 @@ def test_bench_starts_its_own_ranks():
     assert len(lines) == 1, r.stdout[-2000:]
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["transport"] == "detached" and d["config"]["cells_per_gpu"] == 5 * 10 ** 7
+
+
+@pytest.mark.gpu
+def test_bench_refuses_fewer_gpus_than_asked_for():
+    """`--gpus N` on a node with fewer than N GPUs fails loudly (non-zero, a message on standard error, nothing on standard output)
+    instead of running a smaller job under the larger label."""
+    import torch
+
+    n = torch.cuda.device_count() + 1
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "2", "--warmup", "1"], stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, text=True, timeout=300, cwd=ROOT, env=env)
+    assert r.returncode != 0 and "refusing to run fewer ranks" in r.stderr and not r.stdout.strip(), (r.returncode, r.stderr[-500:])

@@ -58,6 +58,23 @@ def cases(pkg):
     add("drillUp [1e6,100]->[1,100] (reduce)", P.drillup("float32", 0.0, "sum", [10 ** 6, 100], [1, 100], [np.zeros(10 ** 6, np.uint32), ident(100)]), 10 ** 8, 100)
     add("drillUp [1e4,1e4]->[1,1e4] (split4)", P.drillup("float32", 0.0, "sum", [10 ** 4, 10 ** 4], [1, 10 ** 4], [np.zeros(10 ** 4, np.uint32), ident(10 ** 4)]), 10 ** 8, 10 ** 4)
     add("drillUp odd location->10 interleaved", P.drillup("float32", 0.0, "sum", odd, [3653, 10, 271], [ident(3653), (np.arange(101) % 10).astype(np.uint32), ident(271)]), n_odd, 3653 * 10 * 271, width="4")
+    # round 3: the regimes that were below 0.70 and the load kernels
+    add("drillUp [4e5,250]->[1,250] (reduce4, wide rows)", P.drillup("float32", 0.0, "sum", [400000, 250], [1, 250], [np.zeros(400000, np.uint32), ident(250)]), 10 ** 8, 250)
+    add("drillUp [1e5,1000]->[1,1000] (reduce4, wide rows)", P.drillup("float32", 0.0, "sum", [10 ** 5, 1000], [1, 1000], [np.zeros(10 ** 5, np.uint32), ident(1000)]), 10 ** 8, 1000)
+    add("drillUp [3001,3333,10]->11 groups (flat)", P.drillup("float32", 0.0, "sum", [3001, 3333, 10], [3001, 11, 10], [ident(3001), (np.arange(3333) // 303).astype(np.uint32), ident(10)]),
+        3001 * 3333 * 10, 3001 * 11 * 10, width="4")
+    add("drillUp C5 city->country", P.drillup("float32", 0.0, "sum", [3652, 100, 274], [3652, 10, 274], [ident(3652), (np.arange(100) // 10).astype(np.uint32), ident(274)]),
+        3652 * 100 * 274, 3652 * 10 * 274, width="8")
+    add("drillDown [12000,8192]->[120000,8192]", P.drilldown("float32", 0.0, "sum", [1200, 8192], [12000, 8192], [np.repeat(np.arange(1200), 10).astype(np.uint32), ident(8192)]),
+        1200 * 8192, 12000 * 8192)
+    i8 = [sel(10)] * 8
+    add("load [10]^8 identity item maps", P.load("float32", 0.0, 0.0, [10] * 8, [10] * 8, i8), 10 ** 8, 10 ** 8)
+    p4 = list(i8)
+    p4[4] = np.array([3, 1, 4, 0, 9, 2, 6, 5, 8, 7], np.int32)
+    add("load [10]^8 items of dim4 remapped", P.load("float32", 0.0, 0.0, [10] * 8, [10] * 8, p4), 10 ** 8, 10 ** 8)
+    p7 = list(i8)
+    p7[7] = np.array([3, 1, 4, 0, 9, 2, 6, 5, 8, 7], np.int32)
+    add("load [10]^8 items of dim7 remapped", P.load("float32", 0.0, 0.0, [10] * 8, [10] * 8, p7), 10 ** 8, 10 ** 8, width="16/4")
     return out
 
 
@@ -133,6 +150,13 @@ def summarize(tag):
     fetch = counters_by_case("pmc_fetch", {"FETCH_SIZE"})
     write = counters_by_case("pmc_write", {"WRITE_SIZE"})
     lds = counters_by_case("pmc_lds", {"SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE"})
+    tcc_names = {"TCC_EA0_WRREQ_sum", "TCC_EA0_WRREQ_64B_sum", "TCC_EA0_WRREQ_STALL_sum", "TCC_BUSY_sum", "TCC_EA0_RDREQ_sum", "TCC_EA0_RDREQ_32B_sum",
+                 "TCC_EA0_RDREQ_DRAM_CREDIT_STALL_sum", "TCC_EA0_WRREQ_DRAM_CREDIT_STALL_sum", "TCC_TOO_MANY_EA_WRREQS_STALL_sum", "TCC_TAG_STALL_sum"}
+    tcc = [counters_by_case(d, tcc_names) for d in ("pmc_tcc_wr", "pmc_tcc_rd", "pmc_tcc_stall")]
+    tlb_names = {"TCP_UTCL1_REQUEST_sum", "TCP_UTCL1_TRANSLATION_MISS_sum", "TCP_UTCL1_TRANSLATION_HIT_sum", "TCP_UTCL1_STALL_MULTI_MISS_sum",
+                 "TCP_UTCL1_STALL_INFLIGHT_MAX_sum", "TCP_UTCL1_STALL_UTCL2_REQ_OUT_OF_CREDITS_sum", "TCP_UTCL1_SERIALIZATION_STALL_sum", "TCP_UTCL1_THRASHING_STALL_sum",
+                 "TCP_PENDING_STALL_CYCLES_sum", "TCP_TCR_TCP_STALL_CYCLES_sum", "TCP_TA_ADDR_STALL_CYCLES_sum", "TCP_GATE_EN1_sum", "TA_ADDR_STALLED_BY_TC_CYCLES_sum", "TA_BUSY_sum"}
+    tcc += [counters_by_case(d, tlb_names) for d in ("pmc_tlb", "pmc_tlb_stall", "pmc_tcp")]
     doc = {"note": "per launch; FETCH_SIZE / WRITE_SIZE in KiB (separate --pmc passes).  gfx950: FETCH_SIZE reports half the bytes of a 16 B/lane "
                    "stream (MI355X_MICROARCH.md); the two calibration cases give the factor for each access width on this box "
                    "(fetch_factor = algorithmic read bytes / (FETCH_SIZE * 1024)), and the factor of a case's width is applied to it.",
@@ -148,6 +172,21 @@ def summarize(tag):
             c["SQ_LDS_IDX_ACTIVE"] = lds[i].get("SQ_LDS_IDX_ACTIVE")
             if c["SQ_LDS_IDX_ACTIVE"]:
                 c["lds_conflict_share"] = c["SQ_LDS_BANK_CONFLICT"] / c["SQ_LDS_IDX_ACTIVE"]
+        for t in tcc:  # memory-side (EA) requests of the L2 and its stall cycles, summed over the channels
+            if t and i < len(t):
+                c.update({k.replace("_sum", ""): v for k, v in t[i].items()})
+        if c.get("TCC_EA0_WRREQ") and c.get("TCC_EA0_WRREQ_64B") is not None:
+            c["partial_write_share"] = 1.0 - c["TCC_EA0_WRREQ_64B"] / c["TCC_EA0_WRREQ"]  # writes that are not whole 64-byte requests
+        if c.get("TCC_BUSY"):
+            for k in ("TCC_EA0_WRREQ_STALL", "TCC_EA0_RDREQ_DRAM_CREDIT_STALL", "TCC_EA0_WRREQ_DRAM_CREDIT_STALL", "TCC_TOO_MANY_EA_WRREQS_STALL", "TCC_TAG_STALL"):
+                if c.get(k) is not None:
+                    c[k.lower() + "_per_busy"] = c[k] / c["TCC_BUSY"]
+        if c.get("TCP_UTCL1_REQUEST"):
+            c["tlb_miss_share"] = (c.get("TCP_UTCL1_TRANSLATION_MISS") or 0.0) / c["TCP_UTCL1_REQUEST"]
+        if c.get("TCP_GATE_EN1"):
+            for k in ("TCP_PENDING_STALL_CYCLES", "TCP_TCR_TCP_STALL_CYCLES", "TCP_TA_ADDR_STALL_CYCLES"):
+                if c.get(k) is not None:
+                    c[k.lower() + "_per_tcp_cycle"] = c[k] / c["TCP_GATE_EN1"]
         if m["name"].startswith("calib") and f and w is not None:
             read_bytes = m["alg_bytes"] - w * 1024  # what is left of the algorithmic bytes after the (exact) writes
             factor[m["width"]] = read_bytes / (f * 1024)
@@ -167,8 +206,14 @@ def summarize(tag):
     doc["hbm_bytes_per_launch"] = head.get("hbm_bytes") if head else None
     json.dump(doc, open(path, "w"), indent=1)
     for c in doc["cases"]:
-        print("%-46s %8.1f us  frac %.3f  traffic/alg %s  lds conflict share %s" % (c["name"], c["us"], c["frac"], "%.2f" % c["traffic_over_algorithmic"] if "traffic_over_algorithmic" in c else "-",
-                                                                                    "%.2f" % c["lds_conflict_share"] if "lds_conflict_share" in c else "-"))
+        print("%-50s %8.1f us  frac %.3f  traffic/alg %s  lds conflict share %s  partial writes %s  wrreq stall/busy %s  rd credit stall/busy %s" % (
+            c["name"], c["us"], c["frac"], "%.2f" % c["traffic_over_algorithmic"] if "traffic_over_algorithmic" in c else "-",
+            "%.2f" % c["lds_conflict_share"] if "lds_conflict_share" in c else "-", "%.2f" % c["partial_write_share"] if "partial_write_share" in c else "-",
+            "%.2f" % c["tcc_ea0_wrreq_stall_per_busy"] if "tcc_ea0_wrreq_stall_per_busy" in c else "-",
+            "%.2f" % c["tcc_ea0_rdreq_dram_credit_stall_per_busy"] if "tcc_ea0_rdreq_dram_credit_stall_per_busy" in c else "-")
+            + ("  tlb miss share %.4f" % c["tlb_miss_share"] if "tlb_miss_share" in c else "")
+            + ("  L1: pending-stall %.2f  L2-return-stall %.2f of its cycles" % (c.get("tcp_pending_stall_cycles_per_tcp_cycle", float("nan")), c.get("tcp_tcr_tcp_stall_cycles_per_tcp_cycle", float("nan")))
+               if "tcp_pending_stall_cycles_per_tcp_cycle" in c else ""))
     print("wrote", path)
 
 
