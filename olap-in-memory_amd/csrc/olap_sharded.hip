@@ -1743,6 +1743,8 @@ extern "C" int olap_sharded_store_gather(const olap_sharded_store *s, olap_store
 
 extern "C" int olap_sharded_store_scatter(olap_sharded_store **out, olap_comm *comm, const olap_store *whole, int ndim, const uint32_t *lens) {
   if (!whole) return fail(OLAP_ERR_INVALID_ARGUMENT, "store is NULL");
+  if (whole->track_order)  // (first / last of the shards combine in ROW order: the Map's insertion order would be lost silently)
+    return fail(OLAP_ERR_INVALID_ARGUMENT, "ordered: this store tracks its insertion order, which a row partition cannot keep; it stays on one device (gather first / do not scatter)");
   olap_sharded_store *s = nullptr;
   int rc = sharded_frame(&s, comm, ndim, lens, whole->dtype, whole->default_kind, nullptr);
   if (rc) return rc;

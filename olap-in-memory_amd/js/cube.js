@@ -91,12 +91,21 @@ class Cube {
 
   createStoredMeasure(measureId, rules = {}, type = 'float32', defaultValue = 0) {
     this._checkNewMeasure(measureId);
-    this.storedMeasures[measureId] = new HipStore(this.storeSize, type, defaultValue, undefined, this.dimensions.map((d) => d.numItems));
+    this.storedMeasures[measureId] = this._newStore(type, defaultValue, rules);
     this.storedMeasuresRules[measureId] = rules;
-    // `first` / `last` follow the Map's insertion order in the reference (in-memory.js:298): such measures keep it
-    // (a measure split over several devices keeps the flat-index order: its shards combine in row order)
-    const store = this.storedMeasures[measureId];
-    if (!store._native.isSharded && Object.values(rules || {}).some((rule) => rule === 'first' || rule === 'last')) store.trackOrder();
+  }
+
+  /**
+   * A measure's store.  `first` / `last` follow the Map's INSERTION order in the reference (in-memory.js:298): a measure
+   * with such a rule keeps that order (HipStore.trackOrder) and therefore stays on ONE device even when a device list
+   * is set — the shards of a split measure combine in row order, which is the reference's order only for a cube
+   * filled in ascending index order — so that the same program answers the same with and without setDevices().
+   */
+  _newStore(type, defaultValue, rules) {
+    const ordered = Object.values(rules || {}).some((rule) => rule === 'first' || rule === 'last');
+    const store = new HipStore(this.storeSize, type, defaultValue, undefined, ordered ? undefined : this.dimensions.map((d) => d.numItems));
+    if (ordered) store.trackOrder();
+    return store;
   }
 
   /**
@@ -190,8 +199,7 @@ class Cube {
     const origin = originCube.storedMeasures[measureId];
     if (origin === undefined) throw new Error(`This measure does not exists in originCube: ${measureId}`);
     this.storedMeasuresRules[measureId] = Object.assign({}, originCube.storedMeasuresRules[measureId]);
-    this.storedMeasures[measureId] = new HipStore(this.storeSize, origin._type, origin._defaultValue, undefined, this.dimensions.map((d) => d.numItems));
-    if (origin.orderTracked && !this.storedMeasures[measureId]._native.isSharded) this.storedMeasures[measureId].trackOrder();
+    this.storedMeasures[measureId] = this._newStore(origin._type, origin._defaultValue, origin.orderTracked ? { any: 'first' } : this.storedMeasuresRules[measureId]);
   }
 
   renameMeasure(oldMeasureId, newMeasureId) {

@@ -119,6 +119,13 @@ def run_store_api(comm, what):
 
     same(s.gather(), o, "gather")
     same(ShardedStore.scatter(comm, s.gather(), lens), o, "scatter")
+    tracked = s.gather()
+    tracked.track_order()
+    try:  # a store that tracks the reference Map's insertion order cannot be split by rows without losing it
+        ShardedStore.scatter(comm, tracked, lens)
+        raise AssertionError("expected an 'ordered:' refusal")
+    except capi.OlapError as e:
+        assert str(e).startswith("ordered:") and "one device" in str(e), str(e)
     same(s.clone(), o, "clone")
     assert abs(s.total - o.total()) < 1e-9
     same(s.drill_up([7, 6, 2], [ident(7), ident(6), (np.arange(10) % 2).astype(np.uint32)], "average"),

@@ -41,39 +41,50 @@ function build(sharded) {
 
 const plain = build(false);
 const sharded = build(true);
-// A sharded measure orders its cells by flat index (shards combine in row order); on one device a measure with a
-// first / last rule tracks the reference Map's insertion order instead (tests/js/gpu_test.js, tests/test_insertion_order.py),
-// which differs after roll-ups of sparse cubes.  Compare like with like: switch the tracking of the one-device cube off.
-plain.storedMeasures.m_last.trackOrder(false);
+// A measure with a first / last rule tracks the reference Map's insertion order (tests/js/gpu_test.js,
+// tests/test_insertion_order.py) and therefore stays on ONE device whatever the device list says: `m_last` is the same
+// kind of store in both cubes, and the same program answers the same with and without setDevices().
 const MEASURES = ['m_sum', 'm_avg', 'm_last', 'm_high'];
+const SPLIT = ['m_sum', 'm_avg', 'm_high'];
 
-// sum / average partials are rounded to Float32 per shard and combined in another order: <= 1e-5 relative
-// (north star); last / highest pick one of the inputs and must be identical
+// Every rank ships its float64 accumulators and the sum is rounded ONCE, as on one device; the cells here are
+// multiples of 1/4, whose float64 sums are exact in any order: identical cell for cell, every measure.
 function same(a, b, what) {
-  for (const m of MEASURES) {
-    const x = a.getData(m);
-    const y = b.getData(m);
-    if (m === 'm_last' || m === 'm_high') {
-      assert.deepEqual(x, y, `${what} ${m}`);
-      continue;
-    }
-    assert.equal(x.length, y.length, `${what} ${m}`);
-    for (let i = 0; i < x.length; ++i) {
-      const ok = (Number.isNaN(x[i]) && Number.isNaN(y[i])) || Math.abs(x[i] - y[i]) <= 1e-5 * Math.abs(y[i]);
-      assert.ok(ok, `${what} ${m} cell ${i}: ${x[i]} vs ${y[i]}`);
-    }
-  }
+  for (const m of MEASURES) assert.deepEqual(a.getData(m), b.getData(m), `${what} ${m}`);
   assert.deepEqual(a.dimensionIds, b.dimensionIds);
 }
 
 describe('sharded cube', () => {
   it('measures really are sharded, three shards of 5 + 5 + 4 rows', () => {
-    for (const m of MEASURES) {
+    for (const m of SPLIT) {
       assert.ok(sharded.storedMeasures[m]._native.isSharded, m);
       assert.ok(!plain.storedMeasures[m]._native.isSharded, m);
       assert.deepEqual(Array.from(sharded.storedMeasures[m]._native.bounds), [0, 5, 10, 14]);
     }
     same(sharded, plain, 'data');
+  });
+  it('a measure with a first / last rule keeps the insertion order and stays on one device', () => {
+    assert.ok(!sharded.storedMeasures.m_last._native.isSharded && sharded.storedMeasures.m_last.orderTracked);
+    assert.ok(plain.storedMeasures.m_last.orderTracked);
+    // out-of-order writes, then a roll-up of the (would-be sharded) dimension: `last` = the LAST INSERTED member, with
+    // and without a device list alike (reference: in-memory.js:298 iterates the Map)
+    for (const devices of [[0, 0, 0], null]) {
+      olap.setDevices(devices);
+      const dim = new GenericDimension('rows', 'root', ['r0', 'r1', 'r2', 'r3', 'r4', 'r5']);
+      const c = new Cube([dim]);
+      c.createStoredMeasure('seen', { rows: 'last' }, 'float32', 0);
+      c.createStoredMeasure('total', { rows: 'sum' }, 'float32', 0);
+      olap.setDevices(null);
+      for (const [item, v] of [['r4', 40], ['r1', 10], ['r5', 50], ['r2', 20]]) {
+        c.setSingleData('seen', { rows: item }, v);
+        c.setSingleData('total', { rows: item }, v);
+      }
+      assert.equal(!!c.storedMeasures.total._native.isSharded, devices !== null);
+      assert.ok(!c.storedMeasures.seen._native.isSharded);
+      assert.deepEqual(c.drillUp('rows', 'all').getData('seen'), [20]); // r2 was written last
+      assert.deepEqual(c.drillUp('rows', 'all').getData('total'), [120]);
+      assert.deepEqual(Array.from(c.getStatusMap('seen').keys()), [4, 1, 5, 2]);
+    }
   });
   it("drillUp of the sharded dimension to 'all' and to an attribute: partial + one collective", () => {
     const a = sharded.drillUp('dimension0', 'all');
@@ -81,6 +92,22 @@ describe('sharded cube', () => {
     same(a, plain.drillUp('dimension0', 'all'), 'dim0 -> all');
     same(sharded.drillUp('dimension0', 'bucket'), plain.drillUp('dimension0', 'bucket'), 'dim0 -> bucket');
     same(sharded.removeDimension('dimension0'), plain.removeDimension('dimension0'), 'removeDimension(dimension0)');
+  });
+  it('float64 partials: cancellation across shards gives the one-device (and reference) answer', () => {
+    // VERDICT r02: [2^24, 1 | -2^24, unset] rolled up over two shards gave 0 / unset with Float32 partials
+    for (const devices of [[0, 0], [0, 0, 0], null]) {
+      olap.setDevices(devices);
+      const c = new Cube([new GenericDimension('rows', 'root', ['r0', 'r1', 'r2', 'r3'])]);
+      c.createStoredMeasure('m_sum', { rows: 'sum' }, 'float32', 0);
+      c.createStoredMeasure('m_avg', { rows: 'average' }, 'float32', 0);
+      olap.setDevices(null);
+      for (const m of ['m_sum', 'm_avg']) c.setData(m, [16777216, 1, -16777216, 0]);
+      assert.equal(!!c.storedMeasures.m_sum._native.isSharded, devices !== null);
+      const all = c.drillUp('rows', 'all');
+      assert.deepEqual(all.getData('m_sum'), [1]);
+      assert.deepEqual(all.getData('m_avg'), [Math.fround(1 / 3)]);
+      assert.deepEqual(Array.from(all.getStatusMap('m_sum').keys()), [0]);
+    }
   });
   it('operations on other dimensions stay sharded', () => {
     const u = sharded.drillUp('dimension2', 'bucket');
