@@ -402,6 +402,7 @@ extern "C" int olap_drillup_plan(olap_plan **out, int dtype, int default_kind, i
       if (order[j] != j) contiguous = false;
     p->vec = vec_for(dtype, a.inner);
     a.def_nan = p->def_nan;
+    a.min_group = 0;
     std::vector<uint32_t> tab(gstart);
     const size_t order_off = tab.size();
     if (!contiguous) tab.insert(tab.end(), order.begin(), order.end());
@@ -460,8 +461,12 @@ extern "C" int olap_drillup_plan(olap_plan **out, int dtype, int default_kind, i
         cut.push_back((uint32_t)a.G);
         // a tile reduces groups-in-tile x inner output cells, one lane each: with a long group or two
         // per tile most of the workgroup idles and the flat form is faster ([3001,3333,10] -> 11 groups
-        // of 303 members: 145 us here, 89 us flat)
-        const bool enough_lanes = a.G * a.inner >= 64 * (cut.size() - 1);
+        // of 303 members: 145 us here, 89 us flat) — unless every group is long enough for several lanes to share an
+        // output cell (>= 256 members: the kernel's cooperative form)
+        uint32_t shortest = ~0u;
+        for (uint32_t g = 0; g < a.G; ++g) shortest = std::min(shortest, gstart[g + 1] - gstart[g]);
+        const bool coop = shortest >= 256 && !getenv("OLAP_GTILE_NO_COOP");  // (whatever the rule: a plan's tables do not depend on it)
+        const bool enough_lanes = a.G * a.inner >= 64 * (cut.size() - 1) || coop;
         if (fits && enough_lanes && a.outer * (cut.size() - 1) < 0x7FFFFFFFull) {
           void *dev_cut = nullptr;
           if ((rc = upload(&dev_cut, cut.data(), cut.size() * sizeof(uint32_t)))) {
@@ -471,6 +476,7 @@ extern "C" int olap_drillup_plan(olap_plan **out, int dtype, int default_kind, i
           p->owned.push_back(dev_cut);
           a.gtile = (const uint32_t *)dev_cut;
           a.n_gtile = (uint32_t)(cut.size() - 1);
+          a.min_group = coop ? shortest : 0;
           gtile_ok = true;
         }
       }
@@ -482,7 +488,9 @@ extern "C" int olap_drillup_plan(olap_plan **out, int dtype, int default_kind, i
       for (size_t gi = 0; gi + 1 < gstart.size(); ++gi) longest = std::max(longest, gstart[gi + 1] - gstart[gi]);
       const uint64_t cells = a.outer * a.G * a.inner;
       // (a wavefront per 271-cell row was tried for more outputs than this: 260 us against the tile's 103)
-      if (cells > 0 && cells < 131072 && longest >= 256) {
+      uint64_t reduce_max_cells = 131072;
+      if (const char *e = getenv("OLAP_REDUCE_MAX_CELLS")) reduce_max_cells = (uint64_t)atoll(e);  // developer / test knob: who takes small outputs
+      if (cells > 0 && cells < reduce_max_cells && longest >= 256) {
         DrillUpReduce &rd = p->reduce;
         uint64_t S;
         // (rows of up to 1 024 four-byte cells too when the 16-byte form below applies — one contiguous '-> all' group

@@ -38,6 +38,7 @@ struct DrillUpAxis {
   const uint32_t *perm_cell;  // device, or nullptr: row-tile regime with interleaved groups (TilePerm), [K * inner + 3]
   const uint32_t *perm_grp;   // device, [2 G]
   uint32_t perm_pitch;        // members between two rows of the permuted tile
+  uint32_t min_group;         // members of the smallest group (the cooperative forms re-associate sums only for groups of >= 256)
 };
 
 // Several measures of a cube in ONE launch: the same drillUp (cell type, default, rule, shape, map) over up to
@@ -760,108 +761,6 @@ __global__ __launch_bounds__(kBlock) void drillup_tile_mixed_kernel(const Batch<
 }
 
 
-constexpr uint32_t kTotalBlocks = 4096;  // workgroups (and partial slots) of the store total
-constexpr uint32_t kGroupTileMaxGroups = 1024;  // groups per tile of the group-tile regime (LDS holds their bounds)
-
-// (Measured and dropped: the tile's bounds as ONE scalar load instead of two dependent ones, and the row-tile kernel's
-// software-pipelined reduction loop — 62.4 -> 64 us on [900,3652,30] day -> month; skipping the gstart loads of a
-// '-> all' roll-up in the row regime changed nothing.)
-// Group-tile regime: contiguous groups (calendars) whose rows K*inner do not fit LDS — e.g. day ->
-// month on [100, 3652, 30].  The members of consecutive groups are consecutive memory, so a tile is a
-// run of whole GROUPS of one outer row (the plan cuts the group list into tiles of <= kTileBytes of
-// cells, table `gtile`), staged with 16 B loads from the aligned address below its first cell; the
-// reduction and the store are those of the row-tile kernel.
-template <typename T, int METHOD, bool HAS_STATUS, bool FAST>
-__global__ __launch_bounds__(kBlock) void drillup_gtile_kernel(const Batch<T> b, const DrillUpAxis a, const uint64_t n_cells) {
-  const T *__restrict__ in = b.in[blockIdx.y];
-  const int32_t *__restrict__ st_in = b.st_in[blockIdx.y];
-  T *__restrict__ out = b.out[blockIdx.y];
-  int32_t *__restrict__ st_out = b.st_out[blockIdx.y];
-  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-  constexpr int V = 16 / sizeof(T);
-  constexpr uint32_t kCells = kTileBytes / sizeof(T);
-  constexpr int NL = kCells / V / kBlock;
-  T *tile = reinterpret_cast<T *>(lds_raw);
-  int32_t *stile = reinterpret_cast<int32_t *>(lds_raw + kTileBytes);
-  uint32_t *l_gstart = reinterpret_cast<uint32_t *>(lds_raw + kTileBytes + (HAS_STATUS ? kCells * 4 : 0));  // kGroupTileMaxGroups + 1 entries
-
-  const uint32_t bid = a.xcd_order ? xcd_contiguous(blockIdx.x, gridDim.x) : blockIdx.x;
-  const uint32_t t = bid % a.n_gtile;
-  const uint64_t o = bid / a.n_gtile;
-  const uint32_t g0 = a.gtile[t], g1 = a.gtile[t + 1];
-  const uint32_t ng = g1 - g0;
-  const uint32_t k0 = a.gstart[g0], k1 = a.gstart[g1];
-  const uint32_t inner = (uint32_t)a.inner;
-  const uint64_t first = (o * a.K + k0) * a.inner;        // first cell of the tile
-  const uint32_t n_in = (k1 - k0) * inner;                 // <= kCells - V
-  const uint64_t base = first & ~(uint64_t)(V - 1);        // 16 B aligned cell below it
-  const uint32_t shift = (uint32_t)(first - base);
-  const uint32_t n_vec = (shift + n_in + V - 1) / V;       // <= kCells / V
-  const bool def_nan = a.def_nan != 0;
-
-  Vec<T, V> v[NL];
-  Vec<int32_t, V> sv[NL];
-#pragma unroll
-  for (int u = 0; u < NL; ++u) {
-    const uint32_t i = threadIdx.x + u * kBlock;
-    if (i < n_vec) {
-      const uint64_t at = base + (uint64_t)i * V;
-      if (at + V <= n_cells) {
-        v[u] = load_stream<T, V>(in + at);
-        if constexpr (HAS_STATUS) sv[u] = load_stream<int32_t, V>(st_in + at);
-      } else {  // the very end of the buffer: cell by cell
-#pragma unroll
-        for (int e = 0; e < V; ++e) {
-          v[u].v[e] = at + e < n_cells ? in[at + e] : T(0);
-          if constexpr (HAS_STATUS) sv[u].v[e] = at + e < n_cells ? st_in[at + e] : 0;
-        }
-      }
-    }
-  }
-  for (uint32_t i = threadIdx.x; i <= ng; i += kBlock) l_gstart[i] = a.gstart[g0 + i] - k0;
-#pragma unroll
-  for (int u = 0; u < NL; ++u) {
-    const uint32_t i = threadIdx.x + u * kBlock;
-    if (i < n_vec) {
-      *reinterpret_cast<Vec<T, V> *>(tile + i * V) = v[u];
-      if constexpr (HAS_STATUS) *reinterpret_cast<Vec<int32_t, V> *>(stile + i * V) = sv[u];
-    }
-  }
-  __syncthreads();
-
-  const uint32_t n_out = ng * inner;
-  // (finish_and_store indexes the buffer in units of what METHOD writes: float64 partials under OLAP_PARTIAL_AVERAGE)
-  T *dst = reinterpret_cast<T *>(reinterpret_cast<typename OutCell<T, METHOD>::type *>(out) + (o * a.G + g0) * a.inner);
-  int32_t *sdst = st_out ? st_out + (o * a.G + g0) * a.inner : nullptr;
-  for (uint32_t idx = threadIdx.x; idx < n_out; idx += kBlock) {
-    const uint32_t g = idx / inner;
-    const uint32_t i = idx - g * inner;
-    const uint32_t at0 = shift + i;
-    Lane<T, METHOD, HAS_STATUS, 1, FAST> lane;
-    lane.init();
-    uint32_t j = l_gstart[g];
-    const uint32_t jend = l_gstart[g + 1];
-    constexpr int UJ = 4;
-    Vec<T, 1> x[UJ];
-    Vec<int32_t, 1> sx[UJ];
-    for (; j + UJ <= jend; j += UJ) {
-#pragma unroll
-      for (int u = 0; u < UJ; ++u) {
-        x[u].v[0] = tile[at0 + (j + u) * inner];
-        sx[u].v[0] = HAS_STATUS ? stile[at0 + (j + u) * inner] : OLAP_STATUS_SET;
-      }
-#pragma unroll
-      for (int u = 0; u < UJ; ++u) lane.add_row(x[u], sx[u], def_nan);
-    }
-    for (; j < jend; ++j) {
-      x[0].v[0] = tile[at0 + j * inner];
-      sx[0].v[0] = HAS_STATUS ? stile[at0 + j * inner] : OLAP_STATUS_SET;
-      lane.add_row(x[0], sx[0], def_nan);
-    }
-    lane.template finish_and_store<false>(def_nan, dst, sdst, idx);
-  }
-}
-
 // Reduce regime (few output cells, long groups — [10^6,100] -> [1,100], [27400,3652] -> [27400,1],
 // [10^8] -> [1]): the natural one-lane-per-output mappings above would leave the chip idle, so the
 // member list of every group is cut into S segments and reduced cooperatively; partial states are
@@ -987,6 +886,196 @@ __device__ __forceinline__ Partial partial_shfl_down(const Partial &p, uint32_t 
   q.meta = __shfl_down(p.meta, delta, 64);
   q.pos = __shfl_down(p.pos, delta, 64);
   return q;
+}
+
+constexpr uint32_t kTotalBlocks = 4096;  // workgroups (and partial slots) of the store total
+constexpr uint32_t kGroupTileMaxGroups = 1024;  // groups per tile of the group-tile regime (LDS holds their bounds)
+
+// (Measured and dropped: the tile's bounds as ONE scalar load instead of two dependent ones, and the row-tile kernel's
+// software-pipelined reduction loop — 62.4 -> 64 us on [900,3652,30] day -> month; skipping the gstart loads of a
+// '-> all' roll-up in the row regime changed nothing.)
+// Group-tile regime: contiguous groups (calendars) whose rows K*inner do not fit LDS — e.g. day ->
+// month on [100, 3652, 30].  The members of consecutive groups are consecutive memory, so a tile is a
+// run of whole GROUPS of one outer row (the plan cuts the group list into tiles of <= kTileBytes of
+// cells, table `gtile`), staged with 16 B loads from the aligned address below its first cell; the
+// reduction and the store are those of the row-tile kernel.
+template <typename T, int METHOD, bool HAS_STATUS, bool FAST>
+__global__ __launch_bounds__(kBlock) void drillup_gtile_kernel(const Batch<T> b, const DrillUpAxis a, const uint64_t n_cells) {
+  const T *__restrict__ in = b.in[blockIdx.y];
+  const int32_t *__restrict__ st_in = b.st_in[blockIdx.y];
+  T *__restrict__ out = b.out[blockIdx.y];
+  int32_t *__restrict__ st_out = b.st_out[blockIdx.y];
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  constexpr int V = 16 / sizeof(T);
+  constexpr uint32_t kCells = kTileBytes / sizeof(T);
+  constexpr int NL = kCells / V / kBlock;
+  T *tile = reinterpret_cast<T *>(lds_raw);
+  int32_t *stile = reinterpret_cast<int32_t *>(lds_raw + kTileBytes);
+  uint32_t *l_gstart = reinterpret_cast<uint32_t *>(lds_raw + kTileBytes + (HAS_STATUS ? kCells * 4 : 0));  // kGroupTileMaxGroups + 1 entries
+
+  const uint32_t bid = a.xcd_order ? xcd_contiguous(blockIdx.x, gridDim.x) : blockIdx.x;
+  const uint32_t t = bid % a.n_gtile;
+  const uint64_t o = bid / a.n_gtile;
+  const uint32_t g0 = a.gtile[t], g1 = a.gtile[t + 1];
+  const uint32_t ng = g1 - g0;
+  const uint32_t k0 = a.gstart[g0], k1 = a.gstart[g1];
+  const uint32_t inner = (uint32_t)a.inner;
+  const uint64_t first = (o * a.K + k0) * a.inner;        // first cell of the tile
+  const uint32_t n_in = (k1 - k0) * inner;                 // <= kCells - V
+  const uint64_t base = first & ~(uint64_t)(V - 1);        // 16 B aligned cell below it
+  const uint32_t shift = (uint32_t)(first - base);
+  const uint32_t n_vec = (shift + n_in + V - 1) / V;       // <= kCells / V
+  const bool def_nan = a.def_nan != 0;
+
+  Vec<T, V> v[NL];
+  Vec<int32_t, V> sv[NL];
+#pragma unroll
+  for (int u = 0; u < NL; ++u) {
+    const uint32_t i = threadIdx.x + u * kBlock;
+    if (i < n_vec) {
+      const uint64_t at = base + (uint64_t)i * V;
+      if (at + V <= n_cells) {
+        v[u] = load_stream<T, V>(in + at);
+        if constexpr (HAS_STATUS) sv[u] = load_stream<int32_t, V>(st_in + at);
+      } else {  // the very end of the buffer: cell by cell
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+          v[u].v[e] = at + e < n_cells ? in[at + e] : T(0);
+          if constexpr (HAS_STATUS) sv[u].v[e] = at + e < n_cells ? st_in[at + e] : 0;
+        }
+      }
+    }
+  }
+  for (uint32_t i = threadIdx.x; i <= ng; i += kBlock) l_gstart[i] = a.gstart[g0 + i] - k0;
+#pragma unroll
+  for (int u = 0; u < NL; ++u) {
+    const uint32_t i = threadIdx.x + u * kBlock;
+    if (i < n_vec) {
+      *reinterpret_cast<Vec<T, V> *>(tile + i * V) = v[u];
+      if constexpr (HAS_STATUS) *reinterpret_cast<Vec<int32_t, V> *>(stile + i * V) = sv[u];
+    }
+  }
+  __syncthreads();
+
+  const uint32_t n_out = ng * inner;
+  if constexpr (!FAST) {
+    // the same sharing of an output cell by L lanes for every other rule (and for masked / NaN-default sums): each lane
+    // folds its contiguous part of the members into a Partial (the reduce regime's state: value, set bit, contribution
+    // count, member position for first / last) and the parts are merged lane to lane in member order
+    if (a.min_group >= 256 && n_out * 2 <= kBlock) {
+      typedef typename OutCell<T, METHOD>::type O;
+      uint32_t L = 2;
+      while (L < 64 && L * 2 * n_out <= kBlock) L *= 2;
+      const uint32_t cell = threadIdx.x / L, part = threadIdx.x % L;
+      const bool live = cell < n_out;
+      const uint32_t g = live ? cell / inner : 0u, i = live ? cell - g * inner : 0u;
+      const uint32_t j0 = l_gstart[g], len = l_gstart[g + 1] - j0;
+      uint32_t k = live ? j0 + (uint32_t)((uint64_t)len * part / L) : 0u;
+      const uint32_t ke = live ? j0 + (uint32_t)((uint64_t)len * (part + 1) / L) : 0u;
+      Partial p = partial_identity<METHOD>();
+      for (; k < ke; ++k) {
+        const T x = tile[shift + i + k * inner];
+        const int32_t sx = HAS_STATUS ? stile[shift + i + k * inner] : OLAP_STATUS_SET;
+        if (cell_is_set<T>(x, sx, HAS_STATUS, def_nan)) partial_add<METHOD>(p, Cell<T>::to_f64(x), k, def_nan);
+      }
+      for (uint32_t d = L / 2; d > 0; d >>= 1) {
+        const Partial q = partial_shfl_down(p, d);  // (lanes past a cell's L read a neighbour's state, which nobody consumes)
+        partial_merge<METHOD>(p, q, def_nan);
+      }
+      if (live && part == 0) {
+        O ov;
+        int32_t os;
+        partial_finish<T, METHOD>(p, def_nan, ov, os);
+        const uint64_t at = (o * a.G + g0) * a.inner + cell;
+        reinterpret_cast<O *>(out)[at] = ov;
+        if (st_out) st_out[at] = os;
+      }
+      return;
+    }
+  }
+  if constexpr (FAST) {
+    // Long groups, few output cells per tile (day -> year over [stores, 3652 days, 10 metrics]: a tile is ONE year of one
+    // store, ten output cells of 365 members each): a lane per output cell leaves 246 lanes idle behind one wavefront's
+    // 365-deep dependent chain.  L lanes share an output cell instead, each adds a contiguous L-th of the group's members,
+    // and an L-lane shuffle adds the partial sums — float64, re-associated like the reduce regime and under the same
+    // condition (every group of the roll-up has >= 256 members; sum / average over a 0 default without a mask).
+    if (a.min_group >= 256 && n_out * 2 <= kBlock) {
+      typedef typename OutCell<T, METHOD>::type O;
+      uint32_t L = 2;
+      while (L < 64 && L * 2 * n_out <= kBlock) L *= 2;
+      const uint32_t cell = threadIdx.x / L, part = threadIdx.x % L;
+      const bool live = cell < n_out;
+      const uint32_t g = live ? cell / inner : 0u, i = live ? cell - g * inner : 0u;
+      const uint32_t j0 = l_gstart[g], len = l_gstart[g + 1] - j0;
+      uint32_t k = live ? j0 + (uint32_t)((uint64_t)len * part / L) : 0u;
+      const uint32_t ke = live ? j0 + (uint32_t)((uint64_t)len * (part + 1) / L) : 0u;
+      const T *cells = tile + shift + i;
+      double acc = 0.0;
+      uint32_t cnt = 0;  // contributions (cells that are set, i.e. non-zero): `average` divides by it
+      for (; k + 4 <= ke; k += 4) {
+        const T x0 = cells[k * inner], x1 = cells[(k + 1) * inner], x2 = cells[(k + 2) * inner], x3 = cells[(k + 3) * inner];
+        acc += Cell<T>::to_f64(x0);
+        acc += Cell<T>::to_f64(x1);
+        acc += Cell<T>::to_f64(x2);
+        acc += Cell<T>::to_f64(x3);
+        if constexpr (METHOD != OLAP_SUM)
+          cnt += (Cell<T>::is_default(x0, false) ? 0u : 1u) + (Cell<T>::is_default(x1, false) ? 0u : 1u) +
+                 (Cell<T>::is_default(x2, false) ? 0u : 1u) + (Cell<T>::is_default(x3, false) ? 0u : 1u);
+      }
+      for (; k < ke; ++k) {
+        acc += Cell<T>::to_f64(cells[k * inner]);
+        if constexpr (METHOD != OLAP_SUM) cnt += Cell<T>::is_default(cells[k * inner], false) ? 0u : 1u;
+      }
+      for (uint32_t d = L / 2; d > 0; d >>= 1) {
+        acc += __shfl_down(acc, d, L);
+        if constexpr (METHOD != OLAP_SUM) cnt += __shfl_down(cnt, d, L);
+      }
+      if (live && part == 0) {
+        Agg<METHOD> agg;
+        agg.acc = acc;
+        agg.count = cnt;
+        agg.has = acc != 0.0 && (METHOD == OLAP_SUM || cnt != 0);
+        agg.finish(def_nan);
+        O ov;
+        int32_t os;
+        emit_out<T, METHOD>(agg.acc, agg.has, agg.count, def_nan, ov, os);
+        const uint64_t at = (o * a.G + g0) * a.inner + cell;
+        reinterpret_cast<O *>(out)[at] = ov;
+        if (st_out) st_out[at] = os;
+      }
+      return;
+    }
+  }
+  // (finish_and_store indexes the buffer in units of what METHOD writes: float64 partials under OLAP_PARTIAL_AVERAGE)
+  T *dst = reinterpret_cast<T *>(reinterpret_cast<typename OutCell<T, METHOD>::type *>(out) + (o * a.G + g0) * a.inner);
+  int32_t *sdst = st_out ? st_out + (o * a.G + g0) * a.inner : nullptr;
+  for (uint32_t idx = threadIdx.x; idx < n_out; idx += kBlock) {
+    const uint32_t g = idx / inner;
+    const uint32_t i = idx - g * inner;
+    const uint32_t at0 = shift + i;
+    Lane<T, METHOD, HAS_STATUS, 1, FAST> lane;
+    lane.init();
+    uint32_t j = l_gstart[g];
+    const uint32_t jend = l_gstart[g + 1];
+    constexpr int UJ = 4;
+    Vec<T, 1> x[UJ];
+    Vec<int32_t, 1> sx[UJ];
+    for (; j + UJ <= jend; j += UJ) {
+#pragma unroll
+      for (int u = 0; u < UJ; ++u) {
+        x[u].v[0] = tile[at0 + (j + u) * inner];
+        sx[u].v[0] = HAS_STATUS ? stile[at0 + (j + u) * inner] : OLAP_STATUS_SET;
+      }
+#pragma unroll
+      for (int u = 0; u < UJ; ++u) lane.add_row(x[u], sx[u], def_nan);
+    }
+    for (; j < jend; ++j) {
+      x[0].v[0] = tile[at0 + j * inner];
+      sx[0].v[0] = HAS_STATUS ? stile[at0 + j * inner] : OLAP_STATUS_SET;
+      lane.add_row(x[0], sx[0], def_nan);
+    }
+    lane.template finish_and_store<false>(def_nan, dst, sdst, idx);
+  }
 }
 
 // One UNIT (a wavefront for short segments, a whole workgroup for long ones) per (outer, group,

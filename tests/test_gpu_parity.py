@@ -417,6 +417,53 @@ def test_config3_chain_fused_vs_unfused():
 
 @pytest.mark.parametrize("method", ["sum", "average", "highest", "lowest", "first", "last", "product"])
 @pytest.mark.parametrize("type_name,default", [("float32", 0.0), ("float32", float("nan")), ("int32", 0.0), ("uint32", float("nan")), ("float64", 0.0)])
+@pytest.mark.parametrize("lens,groups", [([7, 1500, 3], 4), ([3, 3652, 10], 10), ([5, 5200, 1], 5)])
+def test_group_tile_long_groups_share_output_cells(method, type_name, default, lens, groups, monkeypatch):
+    """Contiguous LONG groups (>= 256 members: day -> year) over short row pieces: a tile of the group-tile regime
+    holds one or two groups, i.e. a handful of output cells, and L lanes share each of them — a plain running sum +
+    shuffle for sum / average over a 0 default, the reduce regime's Partial merge (in member order) for everything
+    else.  Picks are exact; float64 sums are re-associated (the inputs are quarter-integers: still exact here)."""
+    monkeypatch.setenv("OLAP_REDUCE_MAX_CELLS", "0")  # (below 131 072 output cells the few-outputs reduce regime would take these small cubes)
+    rng = np.random.default_rng(sum(lens) + len(method))
+    n = int(np.prod(lens))
+    K = lens[1]
+    bounds = np.linspace(0, K, groups + 1).astype(int)
+    amap = np.repeat(np.arange(groups), np.diff(bounds)).astype(np.uint32)
+    assert np.diff(bounds).min() >= 256
+    if method == "product":
+        vals = np.where(rng.random(n) < 0.5, 1.0, -1.0) * np.where(rng.random(n) < 0.01, 2.0, 1.0)
+        if type_name == "uint32":
+            vals = np.abs(vals)
+    else:
+        vals = rng.integers(0 if type_name == "uint32" else -50, 51, size=n).astype(np.float64)
+        if type_name.startswith("float"):
+            vals = vals * 0.25
+    dense = np.where(rng.random(n) < 0.3, default, vals)
+    new = [lens[0], groups, lens[2]]
+    maps = [np.arange(lens[0], dtype=np.uint32), amap, np.arange(lens[2], dtype=np.uint32)]
+    plan = pkg.Plan.drillup(type_name, default, method, lens, new, maps)
+    item = 8 if type_name == "float64" else 4
+    fits = int(np.diff(bounds).max()) * lens[2] <= 16384 // item - 16 // item  # a whole group per tile
+    assert ("gtile" if fits else "flat") in plan.kernel_name, plan.kernel_name
+    o = OracleStore(n, type_name, default)
+    typed = to_typed(dense, type_name).astype(np.float64)
+    if type_name in ("int32", "uint32") and default != default:
+        typed = np.where(np.isnan(dense), np.nan, typed)
+    o.set_data(typed)
+    ev, es = expected_typed(o.drill_up(lens, new, maps, method))
+    g = pkg.HipStore(n, type_name, default)
+    g.set_data_f64(dense)
+    out = g.drill_up(lens, new, maps, method)
+    assert np.array_equal(out.get_status(), es)
+    gv = out.get_data()
+    if type_name == "float64" and method in ("sum", "average", "product"):
+        assert np.allclose(gv, ev, rtol=1e-12, atol=0, equal_nan=True)
+    else:
+        assert same_typed(gv, ev)
+
+
+@pytest.mark.parametrize("method", ["sum", "average", "highest", "lowest", "first", "last", "product"])
+@pytest.mark.parametrize("type_name,default", [("float32", 0.0), ("float32", float("nan")), ("int32", 0.0), ("uint32", float("nan")), ("float64", 0.0)])
 def test_split_regime_few_outputs_long_groups(method, type_name, default):
     """[6000, 7] -> [2, 7]: 14 output cells, groups of ~3000 rows: the reduce regime (cooperative
     segments + merge).  Picks are exact; float64 sums are re-associated (1e-12 relative; the inputs
