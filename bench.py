@@ -230,9 +230,18 @@ def bench_config5(pkg, engine, torch):
             p2.run(o1.data_ptr(), None, o2.data_ptr(), None, st)
 
     us1, us2 = _time(torch, months, iters=20), _time(torch, countries, iters=50)
-    b1 = 4 * (n + 120 * 27400) * 4
+    # bytes the four rules have to move: sum / average read every day; first / last need the first / last SET day of a
+    # month only — on this dense cube one day of ~30 — and the row kernel stops there (one row read per group)
+    out1 = 120 * 27400
+    b1 = (2 * (n + out1) + 2 * (out1 + out1)) * 4
+    per_rule = {}
+    for (v, p1, _p2, o1, _o2), method in zip(measures, ("sum", "average", "first", "last")):
+        per_rule[method] = _time(torch, lambda: p1.run(v.data_ptr(), None, o1.data_ptr(), None, st), iters=20)
     res = {"cells": n, "measures": 4, "drillUp_time_month_us": us1, "drillUp_time_month_GBps": b1 / (us1 * 1e-6) / 1e9,
            "drillUp_time_month_frac": b1 / (us1 * 1e-6) / 1e9 / HBM_PEAK_GBS, "cell_measures_per_s": 4 * n / (us1 * 1e-6),
+           "drillUp_time_month_algorithmic_bytes": b1, "drillUp_time_month_us_by_rule": {k: round(v, 2) for k, v in per_rule.items()},
+           "bytes_note": "sum / average read every cell (4 B) and write the result; first / last read ONE day per month on a dense cube "
+                         "(the first / last set member) and write the result",
            "drillUp_location_country_us": us2, "kernel": measures[0][1].kernel_name}
     # the four measures, each with its own rule, as ONE launch (olap_plan_run_batch_rules: what Cube.drillUp sends)
     try:

@@ -212,6 +212,54 @@ __device__ __forceinline__ void drillup_rows_body(const T *__restrict__ in, cons
         }
       }
     };
+    if constexpr (METHOD == OLAP_FIRST || METHOD == OLAP_LAST) {
+      // `first` / `last` need the first / last SET member only: walk towards it — ascending for first, descending for
+      // last — and stop as soon as every cell of the wavefront has found one (a wave-uniform test; the workgroup's
+      // other wavefronts go on by themselves).  On a dense cube that is ONE row of the group instead of all K: the
+      // roll-up reads 1/K of the cube.  Rows are requested one ahead of the test, then four at a time, so that a sparse
+      // group does not pay one memory round trip per row.
+      constexpr bool DESC = METHOD == OLAP_LAST;
+      const uint32_t n = jend - j;
+      auto member = [&](uint32_t t) -> uint64_t {
+        const uint32_t jj = DESC ? jend - 1 - t : j + t;
+        return CONTIG ? (uint64_t)jj : (uint64_t)a.order[jj];
+      };
+      auto take = [&](const Vec<T, VEC> &vv, const Vec<int32_t, VEC> &ss) {
+        bool all = true;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          const bool set = cell_is_set<T>(vv.v[e], HAS_STATUS ? ss.v[e] : OLAP_STATUS_SET, HAS_STATUS, def_nan);
+          lane.pick[e].cur = (!lane.pick[e].has && set) ? vv.v[e] : lane.pick[e].cur;  // the first one found on the way stays
+          lane.pick[e].has = lane.pick[e].has || set;
+          all = all && (lane.pick[e].has || (RAGGED && (uint32_t)e >= valid));
+        }
+        return all;
+      };
+      uint32_t t = 0;
+      bool done = n == 0;
+      if (!done) {
+        fetch(member(0), v[0], s[0]);
+        done = __all(take(v[0], s[0]));
+        t = 1;
+      }
+      while (!done && t < n) {
+        constexpr int B = 4;
+        Vec<T, VEC> bv[B];
+        Vec<int32_t, VEC> bs[B];
+        const uint32_t m = n - t < (uint32_t)B ? n - t : (uint32_t)B;  // wave-uniform
+#pragma unroll
+        for (int u = 0; u < B; ++u)
+          if ((uint32_t)u < m) fetch(member(t + u), bv[u], bs[u]);
+        bool all = false;
+#pragma unroll
+        for (int u = 0; u < B; ++u)
+          if ((uint32_t)u < m) all = take(bv[u], bs[u]);
+        done = __all(all);
+        t += m;
+      }
+      j = jend;
+      return;
+    }
     // (not for values + mask — two streams per row already: 149 -> 151 us with it — and not for the plain sums, whose
     // fold is eight instructions: no difference beyond the run-to-run spread in a same-box A/B)
     constexpr bool kPrefetch = U == 1 && !FAST && !HAS_STATUS;
