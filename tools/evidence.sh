@@ -31,4 +31,9 @@ timeout -k 10 200 node tools/js_chain.js > "$O/js_chain.txt" 2>&1 && tail -3 "$O
 timeout -k 10 200 python tools/transpose_probe.py 2>&1 | grep -v amdgpu.ids > "$O/transpose_probe.txt" && tail -3 "$O/transpose_probe.txt"
 if [ ! -x tools/tile_probe.bin ]; then hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -DOLAP_TILE_PROBE -I include -I olap-in-memory_amd/csrc tools/tile_probe.hip -o tools/tile_probe.bin; fi
 timeout -k 10 120 ./tools/tile_probe.bin > "$O/tile_probe.txt" 2>&1 && tail -4 "$O/tile_probe.txt"
+timeout -k 10 200 python tools/totals_probe.py 2>&1 | grep -v amdgpu.ids > "$O/totals_probe.txt" && tail -5 "$O/totals_probe.txt"
+if [ ! -x tools/pattern_ceiling.bin ]; then hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/pattern_ceiling.hip -o tools/pattern_ceiling.bin; fi
+timeout -k 10 300 ./tools/pattern_ceiling.bin > "$O/pattern_ceiling.txt" 2>&1 && tail -3 "$O/pattern_ceiling.txt"
 echo evidence done
+# separately (each its own gpurun call): bash tools/pmc_run.sh (per-kernel PMC passes -> profiles/traffic_<tag>_kernels.json),
+# bash tools/run_sharded_evidence.sh (sharded tests + tools/js_sharded_bench.js by device list and issuing mode)
