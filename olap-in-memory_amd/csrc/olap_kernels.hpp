@@ -734,6 +734,18 @@ __device__ __forceinline__ void drillup_tile_body(const T *__restrict__ in, cons
     lane.init();
     uint32_t j = ALL ? 0u : PERMUTE ? l_gstart[2 * g] : l_gstart[g];
     const uint32_t jend = ALL ? (uint32_t)a.K : PERMUTE ? l_gstart[2 * g + 1] : l_gstart[g + 1];
+    if constexpr (METHOD == OLAP_FIRST || METHOD == OLAP_LAST) {
+      // the first / last SET member is the answer: walk towards it and stop there
+      for (uint32_t t = 0; t < jend - j && !lane.pick[0].has; ++t) {
+        const uint32_t jj = METHOD == OLAP_FIRST ? j + t : jend - 1 - t;
+        const uint32_t k = MODE == 0 ? l_order[jj] : jj;
+        const T xv = tile[base + k * tl.inner];
+        const int32_t sv = HAS_STATUS ? stile[base + k * tl.inner] : OLAP_STATUS_SET;
+        lane.pick[0].has = cell_is_set<T>(xv, sv, HAS_STATUS, def_nan);
+        lane.pick[0].cur = xv;
+      }
+      j = jend;
+    }
     constexpr int UJ = (MODE == 0 || MODE == 3) ? 8 : 4;  // independent LDS reads in flight (MODE 0: member index, then cell — two dependent reads; MODE 3: long runs, few lanes)
     Vec<T, 1> x[UJ], y[UJ];
     Vec<int32_t, 1> sx[UJ], sy[UJ];
@@ -1105,6 +1117,17 @@ __global__ __launch_bounds__(kBlock) void drillup_gtile_kernel(const Batch<T> b,
     lane.init();
     uint32_t j = l_gstart[g];
     const uint32_t jend = l_gstart[g + 1];
+    if constexpr (METHOD == OLAP_FIRST || METHOD == OLAP_LAST) {
+      // the first / last SET member is the answer: walk towards it and stop there (dense cubes: one LDS read, not a group's worth)
+      for (uint32_t t = 0; t < jend - j && !lane.pick[0].has; ++t) {
+        const uint32_t k = METHOD == OLAP_FIRST ? j + t : jend - 1 - t;
+        const T xv = tile[at0 + k * inner];
+        const int32_t sv = HAS_STATUS ? stile[at0 + k * inner] : OLAP_STATUS_SET;
+        lane.pick[0].has = cell_is_set<T>(xv, sv, HAS_STATUS, def_nan);
+        lane.pick[0].cur = xv;
+      }
+      j = jend;
+    }
     constexpr int UJ = 4;
     Vec<T, 1> x[UJ];
     Vec<int32_t, 1> sx[UJ];
