@@ -232,35 +232,70 @@ template <> __device__ __forceinline__ float select_min<float>(float a, float b)
 template <> __device__ __forceinline__ double select_max<double>(double a, double b) { return js_max(a, b); }
 template <> __device__ __forceinline__ double select_min<double>(double a, double b) { return js_min(a, b); }
 
+// Math.max / Math.min over float cells with the hardware's v_max / v_min: on gfx950 they order -0 below +0 (what
+// Math.max / Math.min want) and DROP a NaN operand (tools/… probe: max(-0,+0) = max(+0,-0) = +0, min = -0, max(NaN,1) = 1),
+// so the running extreme never holds a NaN and a separate flag remembers that one was seen — Math.max / Math.min
+// propagate it.  Inline asm: the builtin would quiet both operands first (two more v_max per call).
+__device__ __forceinline__ float hw_max(float a, float b) {
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ float hw_min(float a, float b) {
+  float r;
+  asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ double hw_max(double a, double b) {
+  double r;
+  asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ double hw_min(double a, double b) {
+  double r;
+  asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+template <typename T> struct IsFloatCell { static constexpr bool value = false; };
+template <> struct IsFloatCell<float> { static constexpr bool value = true; };
+template <> struct IsFloatCell<double> { static constexpr bool value = true; };
+
 template <typename T, int METHOD>
 struct Pick {
+  // highest / lowest of float cells: `cur` is the running extreme of the non-NaN members (the identity until the first one)
+  static constexpr bool kHw = IsFloatCell<T>::value && (METHOD == OLAP_HIGHEST || METHOD == OLAP_LOWEST);
   T cur;
   bool has;
+  bool nan;  // (kHw) a set member was NaN
   __device__ __forceinline__ void init() {
-    cur = T(0);
+    if constexpr (kHw) cur = METHOD == OLAP_HIGHEST ? -__builtin_huge_val() : __builtin_huge_val();
+    else cur = T(0);
     has = false;
+    nan = false;
   }
-  __device__ __forceinline__ void add(T v) {
-    if (!has) {
-      cur = v;
-      has = true;
-    } else if constexpr (METHOD == OLAP_HIGHEST) {
-      cur = select_max<T>(cur, v);
-    } else if constexpr (METHOD == OLAP_LOWEST) {
-      cur = select_min<T>(cur, v);
-    } else if constexpr (METHOD == OLAP_LAST) {
-      cur = v;
-    }  // OLAP_FIRST keeps cur
-  }
+  __device__ __forceinline__ void add(T v) { add_if(true, v); }
   // the same as `if (set) add(v)` written as selects: no divergent branch per cell in the streaming kernels
   __device__ __forceinline__ void add_if(bool set, T v) {
-    T next;
-    if constexpr (METHOD == OLAP_HIGHEST) next = select_max<T>(cur, v);
-    else if constexpr (METHOD == OLAP_LOWEST) next = select_min<T>(cur, v);
-    else if constexpr (METHOD == OLAP_LAST) next = v;
-    else next = cur;
-    cur = set ? (has ? next : v) : cur;
-    has = has || set;
+    if constexpr (kHw) {
+      const T ve = set ? v : cur;  // (cur is never NaN: an unset cell changes nothing)
+      nan = nan || (ve != ve);
+      if constexpr (METHOD == OLAP_HIGHEST) cur = hw_max(cur, ve);
+      else cur = hw_min(cur, ve);
+      has = has || set;
+    } else {
+      T next;
+      if constexpr (METHOD == OLAP_HIGHEST) next = select_max<T>(cur, v);
+      else if constexpr (METHOD == OLAP_LOWEST) next = select_min<T>(cur, v);
+      else if constexpr (METHOD == OLAP_LAST) next = v;
+      else next = cur;
+      cur = set ? (has ? next : v) : cur;
+      has = has || set;
+    }
+  }
+  // the pick (meaningful when `has`)
+  __device__ __forceinline__ T value() const {
+    if constexpr (kHw) return nan ? (T)__builtin_nan("") : cur;
+    else return cur;
   }
 };
 

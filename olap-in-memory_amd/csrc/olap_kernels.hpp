@@ -110,7 +110,7 @@ struct Lane {
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
       if constexpr (kPick) {
-        ov.v[e] = pick[e].has ? pick[e].cur : Cell<T>::default_value(def_nan);
+        ov.v[e] = pick[e].has ? pick[e].value() : Cell<T>::default_value(def_nan);
         os.v[e] = pick[e].has ? OLAP_STATUS_SET : 0;
       } else {
         if constexpr (FAST) {
@@ -1727,9 +1727,9 @@ __global__ __launch_bounds__(kBlock) void segments_combine_kernel(const void *__
     l_cnt[threadIdx.x] = cnt;
   } else if constexpr (sizeof(T) == 4) {  // a pick and whether there is one: 4-byte cells ride the count slots
     l_acc[threadIdx.x] = pk.has ? 1.0 : 0.0;
-    reinterpret_cast<T *>(l_cnt)[threadIdx.x] = pk.cur;
+    reinterpret_cast<T *>(l_cnt)[threadIdx.x] = pk.value();
   } else {  // 8-byte cells ride the float64 slots
-    reinterpret_cast<T *>(l_acc)[threadIdx.x] = pk.cur;
+    reinterpret_cast<T *>(l_acc)[threadIdx.x] = pk.value();
     l_cnt[threadIdx.x] = pk.has ? 1u : 0u;
   }
   __syncthreads();
@@ -1755,7 +1755,7 @@ __global__ __launch_bounds__(kBlock) void segments_combine_kernel(const void *__
       }
       pk.add_if(has, v);
     }
-    ov = pk.has ? pk.cur : Cell<T>::default_value(def_nan);
+    ov = pk.has ? pk.value() : Cell<T>::default_value(def_nan);
     os = pk.has ? OLAP_STATUS_SET : 0;
   }
   const uint64_t at = (o * a.G + g) * a.inner + i;
