@@ -117,7 +117,14 @@ int olap_drillup_plan(olap_plan **plan, int dtype, int default_kind, int method,
 /* InMemoryStore.drillDown(oldDimensions, newDimensions, method, distributions) — :336-430.
  * maps[d] has new_len[d] entries: new root index -> old index (< old_len[d]) (:349-353).
  * distributions: NULL or n_dist float64 weights (NaN entry = JS null/undefined => the run
- * fails with OLAP_ERR_DISTRIBUTION_MISSING if a contributing cell needs it, :397-398). */
+ * fails with OLAP_ERR_DISTRIBUTION_MISSING if a contributing cell needs it, :397-398).
+ * method: OLAP_SUM splits the parent between its children, anything else copies it (:421-423).
+ * The reference decides "integers: spread the remainder one by one" by the measure's DECLARED type
+ * (:343), while its cells are float64 numbers until serialize() (:77-92).  A host that wants exactly
+ * that — int32 / uint32 measures whose intermediate values keep fractions and never wrap — holds them
+ * in OLAP_FLOAT64 cells and ORs OLAP_DRILLDOWN_INTEGER_MEASURE into `method`; the remainder rule
+ * (:403-417) then runs on the float64 cells.  Int32 / Uint32 cells always use it. */
+#define OLAP_DRILLDOWN_INTEGER_MEASURE 0x100
 int olap_drilldown_plan(olap_plan **plan, int dtype, int default_kind, int method, int ndim,
                         const uint32_t *old_len, const uint32_t *new_len,
                         const uint32_t *const *maps, const double *distributions,

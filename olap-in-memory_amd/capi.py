@@ -172,6 +172,7 @@ class ShardRecipe(C.Structure):
 
 XCHG_SUM, XCHG_MAX, XCHG_GATHER = 0, 1, 2
 FINISH_NONE, FINISH_RESTORE, FINISH_AVERAGE, FINISH_COMBINE, FINISH_ROUND = 0, 1, 2, 3, 4
+DRILLDOWN_INTEGER_MEASURE = 0x100  # OR into drillDown's method: int32 / uint32 measure held in float64 cells
 PLACE_SCATTER, PLACE_ALL, PLACE_ROOT, PLACE_SCATTER_ROWS = 0, 1, 2, 3
 UNIQUE_ID_BYTES = 128
 

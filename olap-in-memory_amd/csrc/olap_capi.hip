@@ -1391,6 +1391,9 @@ extern "C" int olap_drilldown_plan(olap_plan **out, int dtype, int default_kind,
   if (!out) return fail(OLAP_ERR_INVALID_ARGUMENT, "plan out-pointer is NULL");
   *out = nullptr;
   int rc;
+  // the measure's declared type is int32 / uint32 whatever the cells are (olap_hip.h): in-memory.js:343
+  const bool integer_measure = (method & OLAP_DRILLDOWN_INTEGER_MEASURE) != 0 || dtype == OLAP_INT32 || dtype == OLAP_UINT32;
+  method &= ~OLAP_DRILLDOWN_INTEGER_MEASURE;
   if ((rc = check_dtype(dtype)) || (rc = check_default(default_kind))) return rc;
   if ((rc = check_dims(ndim, old_len, new_len))) return rc;
   if (ndim > 0 && !maps) return fail(OLAP_ERR_INVALID_ARGUMENT, "maps is NULL");
@@ -1516,7 +1519,7 @@ extern "C" int olap_drilldown_plan(olap_plan **out, int dtype, int default_kind,
       }
     }
   }
-  p->dd_two_pass = !p->dd_rows && !distributions && (dtype == OLAP_FLOAT32 || dtype == OLAP_FLOAT64);
+  p->dd_two_pass = !p->dd_rows && !distributions && !integer_measure;
   if (p->dd_two_pass) {
     if ((rc = finish_remap(p, bcast, p->out_cells, true))) {  // uploads p->dev_tab (int64 offsets)
       olap_plan_destroy(p);
@@ -1542,7 +1545,7 @@ extern "C" int olap_drilldown_plan(olap_plan **out, int dtype, int default_kind,
   a.total = p->out_cells;
   a.def_nan = p->def_nan;
   a.method = method;
-  a.use_rounding = (dtype == OLAP_INT32 || dtype == OLAP_UINT32);  // in-memory.js:343
+  a.use_rounding = integer_measure;  // in-memory.js:343
   a.dist = nullptr;
   a.n_dist = 0;
   if ((rc = upload(&p->dev_tab, tab.data(), tab.size() * sizeof(uint32_t)))) {

@@ -380,7 +380,9 @@ class HipStore:
         check(capi.lib().olap_store_drillup_multi(n, hs, codes, outs, len(ol), ol.ctypes.data_as(capi._pu32), nl.ctypes.data_as(capi._pu32), arr))
         return [HipStore(0, _handle=C.c_void_p(outs[i])) for i in range(n)]
 
-    def drill_down(self, old_len, new_len, maps, method="sum", distributions=None):
+    def drill_down(self, old_len, new_len, maps, method="sum", distributions=None, integer_measure=False):
+        """in-memory.js:336-430.  `integer_measure`: the measure is DECLARED int32 / uint32 but held in float64 cells (what
+        the reference's Map does until serialize()): `sum` spreads the integer remainder (:343, :403-417) all the same."""
         ol, nl = _u32(old_len), _u32(new_len)
         keep, arr = _tables(maps, np.uint32, C.c_uint32)
         if distributions is not None:
@@ -392,6 +394,8 @@ class HipStore:
             m = _method_code(method)
         except OlapError:
             m = METHODS["first"]
+        if integer_measure:
+            m |= capi.DRILLDOWN_INTEGER_MEASURE
         h = C.c_void_p()
         check(self._lib.olap_store_drilldown(self._h, C.byref(h), len(ol), ol.ctypes.data_as(capi._pu32),
                                              nl.ctypes.data_as(capi._pu32), arr, m, dp, dn))

@@ -37,4 +37,17 @@ function shardWorld() {
   return load().shardWorld();
 }
 
-module.exports = { load, setDevices, shardWorld };
+/**
+ * How int32 / uint32 measures are held on the device (store/hip.js cellTypeOf): false (default) = Float64
+ * cells, the reference's values exactly; true = 4-byte typed cells, coerced after every operation.
+ * Applies to measures created afterwards.
+ */
+let compact = process.env.OLAP_COMPACT_INT === '1';
+function setCompactIntegers(on) {
+  compact = !!on;
+}
+function compactIntegers() {
+  return compact;
+}
+
+module.exports = { load, setDevices, shardWorld, setCompactIntegers, compactIntegers };

@@ -22,6 +22,8 @@ const entries = {
   wire: lazy('./wire'),
   setDevices: lazy('./backend', 'setDevices'),
   shardWorld: lazy('./backend', 'shardWorld'),
+  setCompactIntegers: lazy('./backend', 'setCompactIntegers'),
+  backend: lazy('./backend'),
 };
 
 for (const name of Object.keys(entries)) Object.defineProperty(exports, name, { enumerable: true, get: entries[name] });

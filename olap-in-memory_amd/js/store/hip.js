@@ -12,7 +12,21 @@ const backend = require('../backend');
 const { toBuffer, fromBuffer } = require('../wire');
 
 const TYPE_CODE = { int32: 0, uint32: 1, float32: 2, float64: 3 };
+const TYPE_NAME = ['int32', 'uint32', 'float32', 'float64'];
 const BYTES = { int32: 4, uint32: 4, float32: 4, float64: 8 };
+const TYPED_ARRAY = { int32: Int32Array, uint32: Uint32Array, float32: Float32Array, float64: Float64Array };
+
+/**
+ * The element type of the device cells of a measure DECLARED `type`.  The reference's Map holds plain
+ * float64 numbers whatever the declared type and coerces only in serialize() (in-memory.js:77-92): an
+ * int32 `average` of 7 and 8 is 7.5 until then, a uint32 sum may pass 2^32.  Integer measures therefore
+ * live in Float64 cells (8 bytes per cell) and give the reference's values exactly; the declared type
+ * still decides byteLength (:15), the remainder rule of drillDown (:343) and the serialized form.
+ * backend.setCompactIntegers(true) (or OLAP_COMPACT_INT=1) stores them as 4-byte Int32 / Uint32 cells
+ * instead — half the memory and traffic, values coerced after every operation.  Float32 measures are
+ * Float32 cells (the tolerance the port states: 1e-5 relative).
+ */
+const cellTypeOf = (type) => ((type === 'int32' || type === 'uint32') && !backend.compactIntegers() ? 'float64' : type);
 
 const lengthsOf = (dimensions) => Uint32Array.from(dimensions, (d) => d.numItems);
 
@@ -133,8 +147,10 @@ class HipStore {
     if (native && native.source) {
       this._pending = native;
       this._nativeStore = null;
+      this._cells = TYPE_NAME[native.source.dtype];
     } else {
-      this._nativeStore = native || HipStore._create(size, type, defaultValue, lengths);
+      this._nativeStore = native || HipStore._create(size, cellTypeOf(type), defaultValue, lengths);
+      this._cells = TYPE_NAME[this._nativeStore.dtype];
     }
     this._dataMap = new CellMapView(this);
   }
@@ -223,7 +239,7 @@ class HipStore {
 
   set data(values) {
     if (this._size !== values.length) throw new Error(`value length is invalid: ${this._size} !== ${values.length}`);
-    if (ArrayBuffer.isView(values) && !(values instanceof Float64Array) && values.constructor.name.toLowerCase().startsWith(this._type) &&
+    if (ArrayBuffer.isView(values) && !(values instanceof Float64Array) && values.constructor === TYPED_ARRAY[this._cells] &&
         !this._native.isSharded) {
       this._writable.setData(values); // a typed array of the store's own element type: no conversion
       return;
@@ -320,7 +336,9 @@ class HipStore {
   drillDown(oldDimensions, newDimensions, method = 'sum', distributions = null) {
     const maps = oldDimensions.map((dim, i) => Uint32Array.from(newDimensions[i].getGroupIndexFromRootIndexMap(dim.rootAttribute)));
     const weights = distributions ? toFloat64(distributions, Number.NaN) : null;
-    return this._wrap(onShards(this._native, 'drillDown', [lengthsOf(oldDimensions), lengthsOf(newDimensions), maps, method === 'sum' ? 0 : 4, weights]));
+    // the remainder rule goes by the DECLARED type (:343), whatever the cells are (OLAP_DRILLDOWN_INTEGER_MEASURE)
+    const integerMeasure = this._type === 'int32' || this._type === 'uint32' ? 0x100 : 0;
+    return this._wrap(onShards(this._native, 'drillDown', [lengthsOf(oldDimensions), lengthsOf(newDimensions), maps, (method === 'sum' ? 0 : 4) | integerMeasure, weights]));
   }
 
   /** in-memory.js:213-263 — the new dimensions' item ORDER decides where cells land */
@@ -363,7 +381,7 @@ class HipStore {
       const position = myDimensions[i].getItemsToIdx();
       return Int32Array.from(dim.getItems(), (item) => (position[item] === undefined ? -1 : position[item]));
     });
-    if (otherStore._type !== this._type) {
+    if (otherStore._cells !== this._cells) {
       // the kernels copy cells of one element type; re-type the source through float64 first
       const retyped = new HipStore(otherStore._size, this._type, otherStore._defaultValue);
       retyped.data = otherStore.data;
@@ -381,7 +399,9 @@ class HipStore {
    */
   serialize() {
     const sparse = this._whole.toSparse();
-    return toBuffer({ size: this._size, type: this._type, defaultValue: this._defaultValue, indexes: sparse.indexes, dataBuffer: sparse.values });
+    // `new Int32Array(map.values())` (in-memory.js:77-92): the coercion to the declared type happens here
+    const values = sparse.values.constructor === TYPED_ARRAY[this._type] ? sparse.values : TYPED_ARRAY[this._type].from(sparse.values);
+    return toBuffer({ size: this._size, type: this._type, defaultValue: this._defaultValue, indexes: sparse.indexes, dataBuffer: values });
   }
 
   /** in-memory.js:103-116; accepts blobs written by the reference. */
@@ -390,9 +410,10 @@ class HipStore {
     const type = data.type;
     if (!Object.prototype.hasOwnProperty.call(TYPE_CODE, type)) throw new Error('Invalid type');
     const defaultValue = Number.isNaN(data.defaultValue) ? Number.NaN : 0;
-    const TA = { int32: Int32Array, uint32: Uint32Array, float32: Float32Array, float64: Float64Array }[type];
+    const cells = cellTypeOf(type);
+    const TA = TYPED_ARRAY[cells];
     const values = data.dataBuffer instanceof TA ? data.dataBuffer : TA.from(data.dataBuffer);
-    const native = backend.load().storeFromSparse(data.size, TYPE_CODE[type], Number.isNaN(defaultValue) ? 1 : 0, data.indexes instanceof Uint32Array ? data.indexes : new Uint32Array(data.indexes), values);
+    const native = backend.load().storeFromSparse(data.size, TYPE_CODE[cells], Number.isNaN(defaultValue) ? 1 : 0, data.indexes instanceof Uint32Array ? data.indexes : new Uint32Array(data.indexes), values);
     return new HipStore(data.size, type, defaultValue, native);
   }
 }

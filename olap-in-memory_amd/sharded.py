@@ -395,7 +395,7 @@ class ShardedStore:
         check(self._lib.olap_sharded_store_dice(self._h, C.byref(h), nl.ctypes.data_as(capi._pu32), arr))
         return self._wrap(h)
 
-    def drill_down(self, new_len, maps, method="sum", distributions=None):
+    def drill_down(self, new_len, maps, method="sum", distributions=None, integer_measure=False):
         nl = _u32(new_len)
         keep, arr = _tables(maps, np.uint32, C.c_uint32)
         if distributions is not None:
@@ -404,7 +404,8 @@ class ShardedStore:
         else:
             dp, dn = None, 0
         h = C.c_void_p()
-        check(self._lib.olap_sharded_store_drilldown(self._h, C.byref(h), nl.ctypes.data_as(capi._pu32), arr, _method_code(method), dp, dn))
+        check(self._lib.olap_sharded_store_drilldown(self._h, C.byref(h), nl.ctypes.data_as(capi._pu32), arr,
+                                                     _method_code(method) | (capi.DRILLDOWN_INTEGER_MEASURE if integer_measure else 0), dp, dn))
         return self._wrap(h)
 
     def reorder(self, perm):

@@ -744,4 +744,109 @@ describe('measures that share a rule are rolled up in one launch (HipStore.drill
   });
 });
 
+describe('integer measures hold the reference Map\'s float64 numbers (in-memory.js:77-92 coerces only in serialize())', () => {
+  const { HipStore, wire, backend } = require('../../olap-in-memory_amd/js');
+  const golden = JSON.parse(fs.readFileSync(path.join(__dirname, '..', 'golden', 'store_kat.json'), 'utf8')).cases;
+  const kat = (name) => golden.find((c) => c.name === name);
+  const lineDims = (n, groups, id = 'd') => {
+    const items = Array.from({ length: n }, (_, i) => `i${i}`);
+    const dim = new GenericDimension(id, 'item', items);
+    dim.addAttribute('item', 'group', Object.fromEntries(items.map((it, i) => [it, `g${groups(i)}`])));
+    return dim;
+  };
+  it('int32 average of 7 and 8 is 7.5 (reference golden int32_average_fraction), 7 once serialized', () => {
+    assert.deepEqual(kat('int32_average_fraction').out.values, [7.5]);
+    const cube = new Cube([lineDims(2, () => 0)]);
+    cube.createStoredMeasure('mm', { d: 'average' }, 'int32', 0);
+    cube.setData('mm', [7, 8]);
+    const up = cube.drillUp('d', 'all');
+    assert.deepEqual(up.getData('mm'), [7.5]);
+    assert.equal(up.storedMeasures.mm._type, 'int32');
+    assert.equal(up.storedMeasures.mm.byteLength, 4);
+    const blob = wire.fromBuffer(up.storedMeasures.mm.serialize());
+    assert.ok(blob.dataBuffer instanceof Int32Array);
+    assert.deepEqual(Array.from(blob.dataBuffer), [7]);
+    assert.deepEqual(HipStore.deserialize(up.storedMeasures.mm.serialize()).data, [7]);
+  });
+  it('uint32 sum passes 2^32 without wrapping (reference golden uint32_sum_no_wrap); serialize() wraps', () => {
+    assert.deepEqual(kat('uint32_sum_no_wrap').out.values, [8000000000]);
+    const cube = new Cube([lineDims(2, () => 0)]);
+    cube.createStoredMeasure('mm', { d: 'sum' }, 'uint32', 0);
+    cube.setData('mm', [4000000000, 4000000000]);
+    const up = cube.drillUp('d', 'all');
+    assert.deepEqual(up.getData('mm'), [8000000000]);
+    assert.deepEqual(Array.from(wire.fromBuffer(up.storedMeasures.mm.serialize()).dataBuffer), [8000000000 % 4294967296]);
+  });
+  it('chains keep the fractions: average of [1, 2] twice, then their sum = 3', () => {
+    const cube = new Cube([lineDims(2, (i) => i, 'd0'), lineDims(2, () => 0, 'd1')]);
+    cube.createStoredMeasure('mm', { d0: 'sum', d1: 'average' }, 'int32', 0);
+    cube.setData('mm', [1, 2, 1, 2]);
+    assert.deepEqual(cube.drillUp('d1', 'all').getData('mm'), [1.5, 1.5]);
+    assert.deepEqual(cube.drillUp('d1', 'all').drillUp('d0', 'all').getData('mm'), [3]);
+  });
+  it('drillDown spreads the integer remainder by the DECLARED type (in-memory.js:343, :403-417) on those cells', () => {
+    for (const type of ['int32', 'uint32']) {
+      const cube = new Cube([new TimeDimension('time', 'month', '2010-01', '2010-02')]);
+      cube.createStoredMeasure('mm', { time: 'sum' }, type, 0);
+      cube.setData('mm', [100, 7.5]);
+      const days = cube.drillDown('time', 'day');
+      const jan = days.getData('mm').slice(0, 31);
+      assert.equal(jan.reduce((a, b) => a + b, 0), 100);
+      assert.deepEqual(Array.from(new Set(jan)).sort(), [3, 4]);
+      // 7.5 over 28 days, replayed with the reference's own arithmetic
+      const want = [];
+      for (let id = 0; id < 28; ++id) {
+        const one = (7.5 % 28) / 28;
+        want.push(Math.floor(Math.floor(7.5 / 28)) + (Math.floor(id * one) === Math.floor((id - 1) * one) ? 0 : 1));
+      }
+      assert.deepEqual(days.getData('mm').slice(31), want);
+    }
+    const f = new Cube([new TimeDimension('time', 'month', '2010-01', '2010-01')]);
+    f.createStoredMeasure('mm', { time: 'sum' }, 'float64', 0);
+    f.setData('mm', [100]);
+    assert.deepEqual(f.drillDown('time', 'day').getData('mm'), Array(31).fill(100 / 31));
+  });
+  it('NaN is an ordinary value of a 0-default integer measure (in-memory.js:118-133), 0 once serialized', () => {
+    const store = new HipStore(3, 'int32', 0);
+    store.setValue(1, Number.NaN);
+    store.setValue(2, 2.25);
+    assert.deepEqual(store.data, [0, Number.NaN, 2.25]);
+    assert.deepEqual(Array.from(store._dataMap.keys()), [1, 2]);
+    assert.deepEqual(Array.from(wire.fromBuffer(store.serialize()).dataBuffer), [0, 2]);
+  });
+  it('load() between an integer and a float64 measure copies the numbers as they are', () => {
+    const dim = lineDims(3, () => 0);
+    const a = new HipStore(3, 'int32', 0);
+    a.data = [1.5, 0, -2.5];
+    const b = new HipStore(3, 'float64', 0);
+    b.load(a, [dim], [dim]);
+    assert.deepEqual(b.data, [1.5, 0, -2.5]);
+  });
+  it('backend.setCompactIntegers(true): 4-byte typed cells, values coerced after every operation', () => {
+    backend.setCompactIntegers(true);
+    try {
+      const cube = new Cube([lineDims(2, () => 0)]);
+      cube.createStoredMeasure('mm', { d: 'average' }, 'int32', 0);
+      cube.createStoredMeasure('uu', { d: 'sum' }, 'uint32', 0);
+      cube.setData('mm', [7, 8]);
+      cube.setData('uu', [4000000000, 4000000000]);
+      assert.equal(cube.storedMeasures.mm._cells, 'int32');
+      const up = cube.drillUp('d', 'all');
+      assert.deepEqual(up.getData('mm'), [7]);
+      assert.deepEqual(up.getData('uu'), [8000000000 % 4294967296]);
+      assert.deepEqual(Array.from(wire.fromBuffer(up.storedMeasures.mm.serialize()).dataBuffer), [7]);
+      const days = new Cube([new TimeDimension('time', 'month', '2010-01', '2010-01')]);
+      days.createStoredMeasure('mm', { time: 'sum' }, 'uint32', 0);
+      days.setData('mm', [100]);
+      const jan = days.drillDown('time', 'day').getData('mm');
+      assert.equal(jan.reduce((x, y) => x + y, 0), 100);
+      assert.deepEqual(Array.from(new Set(jan)).sort(), [3, 4]);
+    } finally {
+      backend.setCompactIntegers(false);
+    }
+    const exact = new HipStore(2, 'int32', 0);
+    assert.equal(exact._cells, 'float64');
+  });
+});
+
 run();

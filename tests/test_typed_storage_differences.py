@@ -2,9 +2,10 @@
 normalised away by golden_util.expected_typed().
 
 The reference keeps every cell as a float64 JS number until serialize() (in-memory.js:118-133 never coerces;
-:77-92 does, at serialisation) and iterates its Map in insertion order (:298).  This implementation stores
-cells in the measure's declared type after every operation and orders cells by flat index (DESIGN.md
-section 2).  Each test states: reference golden = X (tests/golden/store_kat.json, produced by running the
+:77-92 does, at serialisation) and iterates its Map in insertion order (:298).  The C ABI stores cells in the
+type a store is created with, after every operation, and orders cells by flat index —
+which is what an Int32 / Uint32 / Float32 STORE shows below.  (The Node host holds int32 / uint32 MEASURES in
+float64 cells and so has none of the integer differences: last test here, and tests/js/gpu_test.js.)  Each test states: reference golden = X (tests/golden/store_kat.json, produced by running the
 reference), this store = Y, because ...  A change to either side of these numbers must be deliberate."""
 import numpy as np
 import pytest
@@ -126,3 +127,44 @@ def test_sparse_rollup_order_is_by_index_too():
     g.set_data_f64(vals)
     got = g.drill_up([2, 2], [1, 2], m0, "sum").drill_up([1, 2], [1, 1], m1, "first").get_data_f64()
     assert got.tolist() == [7.0]
+
+
+@pytest.mark.parametrize("declared", ["int32", "uint32"])
+@pytest.mark.parametrize("default", [0.0, float("nan")])
+def test_integer_measure_in_float64_cells_equals_the_reference_exactly(declared, default):
+    """The way out of the differences above, and what the Node host does by default (js/store/hip.js cellTypeOf):
+    an int32 / uint32 MEASURE held in float64 CELLS.  Every operation then works on the numbers the reference's
+    Map holds; the one place the declared type matters before serialize() is drillDown's remainder rule
+    (in-memory.js:343, :403-417), asked for with OLAP_DRILLDOWN_INTEGER_MEASURE.  Compared with the oracle of the
+    DECLARED type, bit for bit, without expected_typed()'s coercion."""
+    rng = np.random.default_rng(5)
+    # fractions, values past 2^32 and negative values in a uint32 measure: all legal numbers of the reference's Map
+    for child_map, inner in [(np.repeat(np.arange(4), [3, 1, 5, 3]), 520), (np.arange(12) % 4, 3), (np.repeat(np.arange(2), [19, 2]), 2056)]:
+        G, K = int(child_map.max()) + 1, len(child_map)
+        old_len, new_len = [3, G, inner], [3, K, inner]
+        n_old = int(np.prod(old_len))
+        vals = rng.integers(-40, 90, size=n_old).astype(np.float64) * 0.5
+        vals[rng.random(n_old) < 0.05] = 6e9 + 0.25
+        dense = np.where(rng.random(n_old) < 0.25, default, vals)
+        maps = [np.arange(3, dtype=np.uint32), child_map.astype(np.uint32), np.arange(inner, dtype=np.uint32)]
+        for method in ("sum", "average"):
+            o = OracleStore(n_old, declared, default)
+            o.set_data(dense)
+            want = o.drill_down(old_len, new_len, maps, method)
+            g = pkg.HipStore(n_old, "float64", default)
+            g.set_data_f64(dense)
+            out = g.drill_down(old_len, new_len, maps, method, integer_measure=True)
+            vals, present = want.dense()
+            assert np.array_equal(out.get_data_f64(), np.where(present, vals, default), equal_nan=True), (declared, method, inner)
+            assert np.array_equal(out.get_status() != 0, present)
+            if method == "sum":  # not what a float64 MEASURE gives (plain division)
+                plain = g.drill_down(old_len, new_len, maps, method).get_data_f64()
+                assert not np.array_equal(plain, out.get_data_f64(), equal_nan=True)
+    # and back up: average keeps its fraction, sums pass 2^32
+    o = OracleStore(4, declared, default)
+    o.set_data(np.array([7.0, 8.0, 4e9, 4e9]))
+    up_maps = [np.array([0, 0, 1, 1], np.uint32)]
+    g = pkg.HipStore(4, "float64", default)
+    g.set_data_f64([7.0, 8.0, 4e9, 4e9])
+    assert g.drill_up([4], [2], up_maps, "average").get_data_f64().tolist() == [7.5, 4e9]
+    assert g.drill_up([4], [2], up_maps, "sum").get_data_f64().tolist() == o.drill_up([4], [2], up_maps, "sum").dense()[0].tolist() == [15.0, 8e9]
