@@ -5,7 +5,7 @@ launched REPS times between marker launches so that a rocprofv3 pass can be cut 
   python tools/pmc_probe.py                 # timings only (HIP events), prints one line per case
   rocprofv3 --pmc FETCH_SIZE -d gpurun_out/pmc_fetch --output-format csv -- python3 tools/pmc_probe.py --quiet
   ... one pass per counter set (FETCH_SIZE | WRITE_SIZE | SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE)
-  python tools/pmc_probe.py --summarize r02 # gpurun_out/pmc_* + pmc_cases.json -> profiles/traffic_<tag>.json
+  python tools/pmc_probe.py --summarize r02 # gpurun_out/pmc_* + pmc_cases.json -> profiles/traffic_<tag>_kernels.json (+ a copy in gpurun_out/)
 
 Markers: one olap_diag_read_ceiling launch (kernel `diag_read_kernel`) before every case.
 Counter units and the gfx950 FETCH_SIZE correction: /opt/skills/guides/MI355X_MICROARCH.md, "HBM".  The x2
@@ -200,11 +200,17 @@ def summarize(tag):
         c["hbm_bytes"] = k * f * 1024 + w * 1024
         c["traffic_over_algorithmic"] = c["hbm_bytes"] / c["alg_bytes"]
     doc["fetch_factor_by_width"] = factor
+    # always "<tag>_kernels": profiles/traffic_<tag>.json is the headline launch's file that bench.py reads
+    if not tag.endswith("_kernels"):
+        tag += "_kernels"
     path = os.path.join(ROOT, "profiles", "traffic_%s.json" % tag)
     # keep the headline launch's figure where bench.py looks for it
     head = next((c for c in doc["cases"] if c["name"].startswith("calib rows 16B")), None)
     doc["hbm_bytes_per_launch"] = head.get("hbm_bytes") if head else None
     json.dump(doc, open(path, "w"), indent=1)
+    # on the GPU box only gpurun_out/ travels back
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    json.dump(doc, open(os.path.join(ROOT, "gpurun_out", os.path.basename(path)), "w"), indent=1)
     for c in doc["cases"]:
         print("%-50s %8.1f us  frac %.3f  traffic/alg %s  lds conflict share %s  partial writes %s  wrreq stall/busy %s  rd credit stall/busy %s" % (
             c["name"], c["us"], c["frac"], "%.2f" % c["traffic_over_algorithmic"] if "traffic_over_algorithmic" in c else "-",
