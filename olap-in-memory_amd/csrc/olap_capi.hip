@@ -403,6 +403,7 @@ extern "C" int olap_drillup_plan(olap_plan **out, int dtype, int default_kind, i
     p->vec = vec_for(dtype, a.inner);
     a.def_nan = p->def_nan;
     a.min_group = 0;
+    a.depth = 0;
     std::vector<uint32_t> tab(gstart);
     const size_t order_off = tab.size();
     if (!contiguous) tab.insert(tab.end(), order.begin(), order.end());
@@ -442,7 +443,9 @@ extern "C" int olap_drillup_plan(olap_plan **out, int dtype, int default_kind, i
     {
       const uint64_t budget = kTileBytes / olap_dtype_size(dtype);
       const uint64_t vcells = 16 / olap_dtype_size(dtype);
-      if (contiguous && a.G > 1 && a.inner > 0 && a.inner / (uint64_t)p->vec < 128 && a.K * a.inner > budget && !getenv("OLAP_NO_GTILE")) {
+      uint64_t gtile_max_slots = 128;
+      if (const char *e = getenv("OLAP_GTILE_MAX_SLOTS")) gtile_max_slots = (uint64_t)atoll(e);  // developer knob
+      if (contiguous && a.G > 1 && a.inner > 0 && a.inner / (uint64_t)p->vec < gtile_max_slots && a.K * a.inner > budget && !getenv("OLAP_NO_GTILE")) {
         std::vector<uint32_t> cut{0};
         uint64_t cells = 0;
         uint32_t groups = 0;
@@ -588,7 +591,11 @@ extern "C" int olap_drillup_plan(olap_plan **out, int dtype, int default_kind, i
             if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) cus = n;
           }
           const uint64_t n_vec = a.inner / (uint64_t)p->vec, bpr = (n_vec + kBlock - 1) / kBlock;
-          const uint64_t want = std::max<uint64_t>(1, (uint64_t)cus * 8 / std::max<uint64_t>(1, a.outer * bpr));
+          // (two workgroups per CU with four rows in flight per lane: [1e4,1e4] -> [1,1e4] 62.9 us; eight per CU with one
+          // row in flight, as the plain row regime runs: 75-77 us — four times the partials to write and to fold)
+          uint64_t per_cu = 2;
+          if (const char *e = getenv("OLAP_SEG_WG_PER_CU")) per_cu = std::max<uint64_t>(1, (uint64_t)atoll(e));  // developer knob
+          const uint64_t want = std::max<uint64_t>(1, (uint64_t)cus * per_cu / std::max<uint64_t>(1, a.outer * bpr));
           const uint64_t seg_len = std::max<uint64_t>(16, (a.K + want - 1) / want);
           std::vector<uint32_t> sg_gstart{0}, sg_first{0};
           for (uint64_t gi = 0; gi < a.G; ++gi) {
@@ -634,8 +641,8 @@ extern "C" int olap_drillup_plan(olap_plan **out, int dtype, int default_kind, i
       p->kernel_name = p->reduce.rows == 0 ? (p->reduce.vec4 ? "drillup_split4_kernel+drillup_merge_kernel" : "drillup_split_kernel+drillup_merge_kernel")
                        : p->reduce.vec4    ? (p->reduce.S == 1 ? "drillup_reduce4_kernel" : "drillup_reduce4_kernel+drillup_merge_kernel")
                                            : "drillup_reduce_kernel+drillup_merge_kernel";
-    else if (a.inner / (uint64_t)p->vec >= 128) p->kernel_name = "drillup_rows_kernel";
     else if (gtile_ok) p->kernel_name = "drillup_gtile_kernel";
+    else if (a.inner / (uint64_t)p->vec >= 128) p->kernel_name = "drillup_rows_kernel";
     else if (a.inner < 128 && a.K * a.inner <= (16 * 1024) / olap_dtype_size(dtype) && a.K * a.inner > 0 &&
              (a.perm_cell && !getenv("OLAP_TILE_NO_PERMUTE") ? 2 * a.G : a.G + 1 + (contiguous ? 0 : a.K)) * 4 <= 16 * 1024)
       p->kernel_name = "drillup_tile_kernel";  // (the launcher re-checks alignment; may still pick the flat form)

@@ -39,6 +39,8 @@ struct DrillUpAxis {
   const uint32_t *perm_grp;   // device, [2 G]
   uint32_t perm_pitch;        // members between two rows of the permuted tile
   uint32_t min_group;         // members of the smallest group (the cooperative forms re-associate sums only for groups of >= 256)
+  uint32_t depth;             // row regime: 0 = the launcher decides; 4 = four rows in flight per lane whatever the row width
+                              // (few, long workgroups: the segmented form)
 };
 
 // Several measures of a cube in ONE launch: the same drillUp (cell type, default, rule, shape, map) over up to
@@ -3337,6 +3339,26 @@ static bool tile_geometry(const DrillUpAxis &a, bool has_status, TileGeometry *o
   return out->tiles < 0x7FFFFFFFull;
 }
 
+// Lanes per workgroup of the row regime.  A row takes a whole number of workgroups: 271 slots fill 271 of 512 lanes at 256
+// lanes per workgroup, 271 of 320 at 64 — the widest workgroup that fills >= 85 % of its lanes, else the best filled.
+// A row of up to 256 slots takes ONE workgroup, the smallest that holds it: two workgroups per row of which the second
+// is nearly empty is the worst choice by far (135 slots: 128 + 7 lanes 99 us, one workgroup of 256 lanes 75 us, 64 + 64
+// + 7 lanes 78 us; 69 slots: 64 + 5 lanes 100 us, one of 128 lanes 76 us — full and empty workgroups alternate, and
+// with an even number of CUs per XCD the full ones keep landing on the same half of them).
+static inline unsigned rows_lanes_for(uint64_t n_vec) {
+  if (n_vec <= 64) return 64u;
+  if (n_vec <= 128) return 128u;
+  if (n_vec <= 256) return 256u;
+  unsigned lanes = kBlock;
+  double best = 0.0;
+  for (unsigned cand : {256u, 128u, 64u}) {
+    const double fill = (double)n_vec / (double)(((n_vec + cand - 1) / cand) * cand);
+    if (fill >= 0.85) return cand;
+    if (fill > best) { best = fill; lanes = cand; }
+  }
+  return lanes;
+}
+
 // Row regime when a row of VEC-slots fills at least one wavefront-sized piece of a workgroup
 // reasonably (>= 128 slots); otherwise the flat regime.  FAST = additive method, zero default, no
 // mask read.  The grid of the row regime is outer*G*blocks_per_row workgroups.
@@ -3350,12 +3372,7 @@ static hipError_t drillup_axis_launch(const Batch<T> &b, unsigned nb, const Dril
   unsigned row_lanes = kBlock;
   {
     static const int forced = getenv("OLAP_ROWS_LANES") ? atoi(getenv("OLAP_ROWS_LANES")) : 0;
-    double best = 0.0;
-    for (unsigned cand : {256u, 128u, 64u}) {
-      const double fill = (double)a.n_vec / (double)(((a.n_vec + cand - 1) / cand) * cand);
-      if (fill >= 0.85) { row_lanes = cand; best = 1.0; break; }
-      if (fill > best) { best = fill; row_lanes = cand; }
-    }
+    row_lanes = rows_lanes_for(a.n_vec);
     if (forced == 64 || forced == 128 || forced == 256) row_lanes = (unsigned)forced;
   }
   const uint64_t row_blocks = a.outer * a.G * ((a.n_vec + row_lanes - 1) / row_lanes);
@@ -3367,7 +3384,9 @@ static hipError_t drillup_axis_launch(const Batch<T> &b, unsigned nb, const Dril
   // depth back, and so does the heavier exact state machine.
   constexpr int U = 4;
   bool shallow = (kAdditive || IsPick<METHOD>::value) && VEC * sizeof(T) >= 16 && a.n_vec >= 1024;
+  if (a.depth == 4) shallow = false;
   if (const char *e = getenv("OLAP_ROWS_DEPTH")) shallow = atoi(e) == 1;  // A/B: 1 or 4 rows in flight
+  const int deep_probe = getenv("OLAP_ROWS_DEPTH") ? atoi(getenv("OLAP_ROWS_DEPTH")) : 0;  // 8 / 16: probe variants (plain sums)
   if (!rows) {
     // LDS tile regime for small `inner` (short row pieces make the flat regime's accesses waste much
     // of every cache line): whole rows of K*inner cells staged per workgroup, kTileBytes of cells
@@ -3391,7 +3410,7 @@ static hipError_t drillup_axis_launch(const Batch<T> &b, unsigned nb, const Dril
       }
     }
   }
-  if (!rows && a.gtile && a.n_gtile > 0 && a.aligned16 && a.outer * a.n_gtile < 0x7FFFFFFFull) {
+  if (a.gtile && a.n_gtile > 0 && a.aligned16 && a.outer * a.n_gtile < 0x7FFFFFFFull) {  // (the plan decides; also over rows of >= 128 slots)
     const size_t lds = kTileBytes + (HS ? kTileBytes / sizeof(T) * 4 : 0) + (kGroupTileMaxGroups + 1) * 4;
     const unsigned blocks = (unsigned)(a.outer * a.n_gtile);
     const uint64_t n_cells = a.outer * a.K * a.inner;
@@ -3412,26 +3431,30 @@ static hipError_t drillup_axis_launch(const Batch<T> &b, unsigned nb, const Dril
   } while (0)
   DrillUpAxis ar = a;  // the row regime's own workgroup width
   ar.blocks_per_row = (a.n_vec + row_lanes - 1) / row_lanes;
-  if constexpr (VEC == 1) {
+  if constexpr (VEC * sizeof(T) < 16) {
     // rows that are not whole 16-byte groups (or buffers that are not 16-byte aligned): 16-byte slots at
     // cell-aligned addresses instead of 4-byte lanes
     constexpr int RV = 16 / sizeof(T);
     static const bool no_ragged = getenv("OLAP_NO_RAGGED_ROWS") != nullptr;
-    if (rows && !no_ragged) {
+    // (8-byte lanes — 4-byte cells in rows of an even, not fourfold, number of cells — too: [3652,100,274] city -> country
+    // 79-82 us with 8-byte lanes, 76 us with these; OLAP_NO_RAGGED_VEC2 keeps the 8-byte lanes)
+    static const bool no_ragged2 = getenv("OLAP_NO_RAGGED_VEC2") != nullptr;
+    if (rows && !no_ragged && (VEC == 1 || !no_ragged2)) {
       DrillUpAxis rg = a;
       rg.n_vec = (a.inner + RV - 1) / RV;
-      unsigned lanes = kBlock;
-      double best = 0.0;
-      for (unsigned cand : {256u, 128u, 64u}) {
-        const double fill = (double)rg.n_vec / (double)(((rg.n_vec + cand - 1) / cand) * cand);
-        if (fill >= 0.85) { lanes = cand; break; }
-        if (fill > best) { best = fill; lanes = cand; }
+      unsigned lanes = rows_lanes_for(rg.n_vec);
+      {
+        static const int forced = getenv("OLAP_ROWS_LANES") ? atoi(getenv("OLAP_ROWS_LANES")) : 0;
+        if (forced == 64 || forced == 128 || forced == 256) lanes = (unsigned)forced;
       }
       rg.blocks_per_row = (rg.n_vec + lanes - 1) / lanes;
       const uint64_t blocks = a.outer * a.G * rg.blocks_per_row;
       if (blocks < 0x7FFFFFFFull) {
 #define OLAP_RAGGED(C, F) hipLaunchKernelGGL((drillup_rows_kernel<T, METHOD, HS, RV, U, C, F, true, true>), dim3((unsigned)blocks, nb), lanes, 0, stream, b, rg)
+#define OLAP_RAGGED_D(D, C) hipLaunchKernelGGL((drillup_rows_kernel<T, METHOD, HS, RV, D, C, true, true, true>), dim3((unsigned)blocks, nb), lanes, 0, stream, b, rg)
         if constexpr (kAdditive && !HS) {
+          if (fast && deep_probe == 8) { if (contig) OLAP_RAGGED_D(8, true); else OLAP_RAGGED_D(8, false); return hipGetLastError(); }
+          if (fast && deep_probe == 16) { if (contig) OLAP_RAGGED_D(16, true); else OLAP_RAGGED_D(16, false); return hipGetLastError(); }
           if (fast) {
             if (contig) OLAP_RAGGED(true, true); else OLAP_RAGGED(false, true);
             return hipGetLastError();
@@ -3445,6 +3468,10 @@ static hipError_t drillup_axis_launch(const Batch<T> &b, unsigned nb, const Dril
   }
   if (rows) {
     if constexpr (kAdditive && !HS) {
+#define OLAP_ROWS_D(D, C) hipLaunchKernelGGL((drillup_rows_kernel<T, METHOD, HS, VEC, D, C, true>), dim3((unsigned)row_blocks, nb), row_lanes, 0, stream, b, ar)
+      if (fast && deep_probe == 8) { if (contig) OLAP_ROWS_D(8, true); else OLAP_ROWS_D(8, false); return hipGetLastError(); }
+      if (fast && deep_probe == 16) { if (contig) OLAP_ROWS_D(16, true); else OLAP_ROWS_D(16, false); return hipGetLastError(); }
+#undef OLAP_ROWS_D
       if (fast) {
         if (shallow) { if (contig) OLAP_ROWS1(true, true); else OLAP_ROWS1(false, true); }
         else { if (contig) OLAP_ROWS(true, true); else OLAP_ROWS(false, true); }
@@ -3511,15 +3538,7 @@ hipError_t Launch<T>::drillup_axis_batch(int method, bool has_status, int vec, c
 
 template <typename T, int VEC>
 static hipError_t drillup_rows_mixed_vec(bool has_status, const Batch<T> &b, unsigned nb, const DrillUpAxis &a, bool deep, hipStream_t stream) {
-  unsigned row_lanes = kBlock;  // (as drillup_axis_launch picks it)
-  {
-    double best = 0.0;
-    for (unsigned cand : {256u, 128u, 64u}) {
-      const double fill = (double)a.n_vec / (double)(((a.n_vec + cand - 1) / cand) * cand);
-      if (fill >= 0.85) { row_lanes = cand; break; }
-      if (fill > best) { best = fill; row_lanes = cand; }
-    }
-  }
+  const unsigned row_lanes = rows_lanes_for(a.n_vec);  // (as drillup_axis_launch picks it)
   DrillUpAxis ar = a;
   ar.blocks_per_row = (a.n_vec + row_lanes - 1) / row_lanes;
   const uint64_t row_blocks = a.outer * a.G * ar.blocks_per_row;
@@ -3653,6 +3672,7 @@ hipError_t Launch<T>::drillup_segmented(int method, bool has_status, int vec, co
   a1.perm_cell = nullptr;
   a1.total = a1.outer * a1.G * a1.n_vec;
   a1.aligned16 = a.aligned16;  // (the partial buffers come from the pool: 256-byte aligned)
+  a1.depth = 4;                // few, long workgroups (two per CU): four rows in flight per lane
   const bool want_aux = additive ? (method == OLAP_AVERAGE || a.def_nan || mask_primary) : mask_primary;
   int32_t *aux = want_aux ? sg.aux : nullptr;
   hipError_t e = drillup_axis(additive ? OLAP_PARTIAL_AVERAGE : method, has_status, vec, in, st_in, (T *)sg.partial, aux, a1, stream);
