@@ -39,6 +39,10 @@ struct DrillUpAxis {
   const uint32_t *perm_grp;   // device, [2 G]
   uint32_t perm_pitch;        // members between two rows of the permuted tile
   uint32_t min_group;         // members of the smallest group (the cooperative forms re-associate sums only for groups of >= 256)
+  uint32_t lanes;             // row regime: lanes per workgroup of this launch (256, 128 or 64; 0 = 256).  In the kernel
+                              // arguments because blockDim.x is a VECTOR load from the dispatch's implicit arguments that
+                              // every workgroup would wait for before it can compute its first address
+  uint32_t grid;              // row regime: workgroups of this launch along x (0 = read gridDim.x): same reason
   uint32_t depth;             // row regime: 0 = the launcher decides; 4 = four rows in flight per lane whatever the row width
                               // (few, long workgroups: the segmented form)
 };
@@ -158,20 +162,30 @@ __device__ __forceinline__ void drillup_rows_body(const T *__restrict__ in, cons
                                                   int32_t *__restrict__ st_out, const DrillUpAxis &a) {
   // blocks_per_row = ceil(n_vec / kBlock); blockIdx.x = og * blocks_per_row + chunk  (uniform math)
   const uint32_t bpr = (uint32_t)a.blocks_per_row;
-  const uint32_t bid = a.xcd_order ? xcd_contiguous(blockIdx.x, gridDim.x) : blockIdx.x;
+  const uint32_t bid = a.xcd_order ? xcd_contiguous(blockIdx.x, a.grid ? a.grid : gridDim.x) : blockIdx.x;
   const uint64_t og = bid / bpr;
   const uint32_t chunk = bid - (uint32_t)og * bpr;
   const uint64_t g = og % a.G;
   const uint64_t o = og / a.G;
-  const uint64_t iv = (uint64_t)chunk * blockDim.x + threadIdx.x;  // workgroups of 256, 128 or 64 lanes (launcher)
+  const uint64_t iv = (uint64_t)chunk * (a.lanes ? a.lanes : kBlock) + threadIdx.x;  // workgroups of 256, 128 or 64 lanes (launcher)
   if (iv >= a.n_vec) return;
   const uint64_t i0 = iv * VEC;
   const bool def_nan = a.def_nan != 0;
 
   const T *base = in + (o * a.K) * a.inner + i0;
   const int32_t *sbase = HAS_STATUS ? st_in + (o * a.K) * a.inner + i0 : nullptr;
-  uint32_t j = a.gstart[g];
-  const uint32_t jend = a.gstart[g + 1];
+  // ('-> all' over a contiguous member list: the bounds are 0 and K — no table to wait for before the first row's address)
+  const bool whole = CONTIG && a.G == 1;
+  uint32_t j = 0u, jend = (uint32_t)a.K;
+  if (!whole) {
+    // (workgroup-uniform; written as the scalar load it is — behind the select above the compiler issues two VECTOR
+    // loads here, several times the latency, on every workgroup's way to its first row)
+    const uint32_t *gp = a.gstart + __builtin_amdgcn_readfirstlane((uint32_t)g);
+    uint64_t bounds;
+    asm volatile("s_load_dwordx2 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(bounds) : "s"(gp) : "memory");
+    j = (uint32_t)bounds;
+    jend = (uint32_t)(bounds >> 32);
+  }
 
   Lane<T, METHOD, HAS_STATUS, VEC, FAST> lane;
   lane.init();
@@ -329,8 +343,18 @@ __device__ __forceinline__ void drillup_rows_body(const T *__restrict__ in, cons
 
 template <typename T, int METHOD, bool HAS_STATUS, int VEC, int U, bool CONTIG, bool FAST, bool NT = true, bool RAGGED = false>
 __global__ __launch_bounds__(kBlock) void drillup_rows_kernel(const Batch<T> b, const DrillUpAxis a) {
-  drillup_rows_body<T, METHOD, HAS_STATUS, VEC, U, CONTIG, FAST, NT, RAGGED>(b.in[blockIdx.y], b.st_in[blockIdx.y], b.out[blockIdx.y],
-                                                                               b.st_out[blockIdx.y], a);
+  // Everything that comes from the kernel arguments is requested HERE, in one batch of scalar loads: left to itself the
+  // compiler requests each pointer where it is first used — behind the early exit, the table look-up, the loop — and
+  // a workgroup then pays five dependent scalar round trips before its first row is requested (ISA of round 3's
+  // build; a stripped loop with one round trip was 3 % faster on the headline, tools/headline_limit.hip).
+  const T *in = b.in[blockIdx.y];
+  const int32_t *st_in = b.st_in[blockIdx.y];
+  T *out = b.out[blockIdx.y];
+  int32_t *st_out = b.st_out[blockIdx.y];
+  const uint32_t *gs = a.gstart, *ord = a.order;
+  asm volatile("" ::"s"(in), "s"(st_in), "s"(out), "s"(st_out), "s"(gs), "s"(ord), "s"(a.K), "s"(a.inner), "s"(a.G), "s"(a.n_vec),
+               "s"(a.blocks_per_row), "s"(a.grid), "s"(a.lanes), "s"(a.xcd_order), "s"(a.def_nan));
+  drillup_rows_body<T, METHOD, HAS_STATUS, VEC, U, CONTIG, FAST, NT, RAGGED>(in, st_in, out, st_out, a);
 }
 
 // Measures with DIFFERENT rules in one launch (config 5: sum / average / first / last over the same roll-up): the rule
@@ -3431,6 +3455,8 @@ static hipError_t drillup_axis_launch(const Batch<T> &b, unsigned nb, const Dril
   } while (0)
   DrillUpAxis ar = a;  // the row regime's own workgroup width
   ar.blocks_per_row = (a.n_vec + row_lanes - 1) / row_lanes;
+  ar.lanes = row_lanes;
+  ar.grid = rows ? (uint32_t)row_blocks : 0u;
   if constexpr (VEC * sizeof(T) < 16) {
     // rows that are not whole 16-byte groups (or buffers that are not 16-byte aligned): 16-byte slots at
     // cell-aligned addresses instead of 4-byte lanes
@@ -3448,7 +3474,9 @@ static hipError_t drillup_axis_launch(const Batch<T> &b, unsigned nb, const Dril
         if (forced == 64 || forced == 128 || forced == 256) lanes = (unsigned)forced;
       }
       rg.blocks_per_row = (rg.n_vec + lanes - 1) / lanes;
+      rg.lanes = lanes;
       const uint64_t blocks = a.outer * a.G * rg.blocks_per_row;
+      rg.grid = blocks < 0x7FFFFFFFull ? (uint32_t)blocks : 0u;
       if (blocks < 0x7FFFFFFFull) {
 #define OLAP_RAGGED(C, F) hipLaunchKernelGGL((drillup_rows_kernel<T, METHOD, HS, RV, U, C, F, true, true>), dim3((unsigned)blocks, nb), lanes, 0, stream, b, rg)
 #define OLAP_RAGGED_D(D, C) hipLaunchKernelGGL((drillup_rows_kernel<T, METHOD, HS, RV, D, C, true, true, true>), dim3((unsigned)blocks, nb), lanes, 0, stream, b, rg)
@@ -3541,8 +3569,10 @@ static hipError_t drillup_rows_mixed_vec(bool has_status, const Batch<T> &b, uns
   const unsigned row_lanes = rows_lanes_for(a.n_vec);  // (as drillup_axis_launch picks it)
   DrillUpAxis ar = a;
   ar.blocks_per_row = (a.n_vec + row_lanes - 1) / row_lanes;
+  ar.lanes = row_lanes;
   const uint64_t row_blocks = a.outer * a.G * ar.blocks_per_row;
   if (row_blocks >= 0x7FFFFFFFull) return hipErrorNotSupported;
+  ar.grid = (uint32_t)row_blocks;
   const bool shallow = !deep && VEC * sizeof(T) >= 16 && a.n_vec >= 1024;
   const bool contig = a.order == nullptr;
   const dim3 grid((unsigned)row_blocks, nb);

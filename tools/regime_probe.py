@@ -23,6 +23,15 @@ CASES = {
     "narrow540c": ([1800, 100, 540], 1, lambda K: np.arange(K) // 5),
     "narrow1200c": ([400, 100, 1200], 1, lambda K: np.arange(K) // 2),
     "narrow700": ([700, 100, 700], 1, lambda K: np.arange(K) % 10),
+    "axis4": ([10 ** 4, 10, 1000], 1, lambda K: np.zeros(K)),
+    "axis3": ([10 ** 3, 10, 10 ** 4], 1, lambda K: np.zeros(K)),
+    "axis4_1024": ([10 ** 4, 10, 1024], 1, lambda K: np.zeros(K)),
+    "axis1": ([10, 10, 10 ** 6], 1, lambda K: np.zeros(K)),
+    "axis2": ([100, 10, 10 ** 5], 1, lambda K: np.zeros(K)),
+    "c5_month": ([3652, 100, 274], 0, lambda K: (np.arange(K) // 30.4375).astype(np.uint32)),
+    "odd_axis0": ([10, 3001, 3333], 0, lambda K: np.zeros(K)),
+    "odd_axis1": ([3001, 10, 3333], 1, lambda K: np.zeros(K)),
+    "odd_loc": ([3653, 101, 271], 1, lambda K: np.arange(K) % 10),
     "headline": ([10] * 8, 0, lambda K: np.zeros(K)),
 }
 
@@ -63,4 +72,5 @@ def main():
     print("%-18s %-8s %9.1f us %9.1f GB/s  %.3f  %s" % (sys.argv[1], method, ms * 1e3, gbs, gbs / 8000, plan.kernel_name), flush=True)
 
 
-main()
+if __name__ == "__main__":
+    main()
