@@ -246,6 +246,7 @@ struct olap_plan {
   bool xy_ok = false;                      // reorder of 4-byte cells without a mask: two-axis LDS transpose (olap_transpose.hip)
   TransposeXY xy{};
   DrillUpReduce reduce{};                  // S > 0: reduce regime of the one-axis drillUp
+  LoadPermute lperm{};                     // lperm.perm != nullptr: load whose innermost items are permuted, nothing else (load_permute_rows_kernel)
   SegmentedRows seg{};                     // S_tot > 0: wide rows of that regime run as the row kernel over segments + a fold (all rules but product)
   bool dd_two_pass = false;                // float cells, no distributions: scale + broadcast
   bool dice_direct = false;                // dice of one dimension, rows not whole 16-byte groups: dice_direct_kernel
@@ -1380,12 +1381,52 @@ extern "C" int olap_load_plan(olap_plan **out, int dtype, int my_default_kind, i
     }
     stride *= my_len[d];
   }
+  // the innermost dimension's items in another order and nothing else: rows rearranged through LDS
+  bool permuted_rows = false;
+  if (ndim >= 1 && !getenv("OLAP_LOAD_NO_PERMUTE")) {
+    const int last = ndim - 1;
+    const uint64_t row_cap = kTileBytes / olap_dtype_size(dtype);
+    bool ok = !dims[last].arithmetic && his_len[last] == my_len[last] && his_len[last] >= 2 && his_len[last] <= row_cap;
+    for (int d = 0; d < last && ok; ++d) ok = dims[d].arithmetic;
+    std::vector<uint32_t> perm;
+    if (ok) {
+      std::vector<char> seen(my_len[last], 0);
+      perm.resize(his_len[last]);
+      for (uint32_t j = 0; j < his_len[last] && ok; ++j) {
+        const int32_t m = his_to_mine[last][j];
+        if (m < 0 || seen[m]) ok = false;
+        else {
+          seen[m] = 1;
+          perm[j] = (uint32_t)m;
+        }
+      }
+    }
+    LoadPermute lp{};
+    if (ok && small_div_for(his_len[last], row_cap, &lp.by_len)) {
+      void *dev = nullptr;
+      if ((rc = upload(&dev, perm.data(), perm.size() * sizeof(uint32_t)))) {
+        olap_plan_destroy(p);
+        return rc;
+      }
+      p->owned.push_back(dev);
+      lp.perm = (const uint32_t *)dev;
+      lp.len = his_len[last];
+      lp.n_rows = p->in_cells / his_len[last];
+      lp.rows_per_tile = (uint32_t)(row_cap / his_len[last]);
+      lp.def_nan = p->def_nan;
+      lp.src_def_nan = p->his_def_nan;
+      p->lperm = lp;
+      permuted_rows = true;
+    }
+  }
   // (16-byte lanes when the innermost merged run is contiguous in both stores: finish_remap checks it)
   if ((rc = finish_remap(p, dims, p->in_cells, true))) {
     olap_plan_destroy(p);
     return rc;
   }
-  p->kernel_name = p->vec > 1 ? "load_scatter (16-byte lanes)" : "load_scatter (16-byte runs of the other store)";
+  p->kernel_name = permuted_rows ? "load_permute_rows_kernel"
+                   : p->vec > 1  ? "load_scatter (16-byte lanes)"
+                                 : "load_scatter (16-byte runs of the other store)";
   *out = p;
   return OLAP_OK;
 }
@@ -1647,6 +1688,10 @@ static int run_typed(olap_plan *p, const void *in_v, const int32_t *in_s, void *
       break;
     }
     case PLAN_LOAD: {
+      if (p->lperm.perm) {
+        e = Launch<T>::load_permute(hs, in, in_s, out, out_s, p->lperm, stream);
+        break;
+      }
       Remap r = p->remap;
       int vec = p->vec;
       if (vec > 1 && !(aligned16(in) && aligned16(out) && (!in_s || aligned16(in_s)) && (!out_s || aligned16(out_s)))) {

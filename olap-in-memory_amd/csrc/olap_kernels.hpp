@@ -2137,6 +2137,100 @@ __global__ __launch_bounds__(kBlock) void load_scatter_run_kernel(const T *__res
   }
 }
 
+// The innermost dimension's items PERMUTED (the same items in another order — hydrating from a cube whose last
+// dimension lists them differently) and every other dimension left alone: his row r is my row r with its cells
+// rearranged.  A workgroup stages a tile of whole rows: 16-byte streaming loads of HIS cells, every cell written to
+// its place in MY row inside LDS, and the tile leaves as 16-byte streaming stores — where the scatter forms above
+// issue one 4-byte store per cell ([10]^8, last dimension permuted: 272 us).  load() writes EVERY cell of his
+// (in-memory.js:152-158 iterates the other store densely), so a permutation covers every cell of my rows and nothing
+// of mine has to be read.
+struct LoadPermute {
+  uint64_t n_rows;         // rows of `len` cells, the same in both stores
+  uint32_t len;            // cells per row (<= kTileBytes / sizeof(T))
+  uint32_t rows_per_tile;  // whole rows in kTileBytes
+  SmallDiv by_len;         // cell of the tile -> its row
+  const uint32_t *perm;    // device, [len]: where HIS j-th cell of a row sits in MY row
+  int def_nan, src_def_nan;
+};
+
+template <typename T, bool HAS_STATUS>
+__global__ __launch_bounds__(kBlock) void load_permute_rows_kernel(const T *__restrict__ his, const int32_t *__restrict__ his_st, T *__restrict__ mine,
+                                                                   int32_t *__restrict__ mine_st, const LoadPermute a) {
+  constexpr uint32_t V = 16 / sizeof(T);
+  constexpr uint32_t kCells = kTileBytes / sizeof(T);
+  constexpr int NL = kCells / V / kBlock;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  T *tile = reinterpret_cast<T *>(lds_raw);
+  int32_t *stile = reinterpret_cast<int32_t *>(lds_raw + kTileBytes);                              // only with mine_st
+  uint32_t *l_perm = reinterpret_cast<uint32_t *>(lds_raw + kTileBytes + (mine_st ? kCells * 4 : 0));  // [len]
+  const uint64_t row0 = (uint64_t)xcd_contiguous(blockIdx.x, gridDim.x) * a.rows_per_tile;
+  const uint64_t left = a.n_rows - row0;
+  const uint32_t rows = left < a.rows_per_tile ? (uint32_t)left : a.rows_per_tile;
+  const uint32_t n = rows * a.len;  // cells of this tile
+  const uint64_t base = row0 * a.len;
+  const bool def_nan = a.def_nan != 0, his_nan = a.src_def_nan != 0;
+  Vec<T, (int)V> v[NL];
+  Vec<int32_t, (int)V> sv[NL];
+#pragma unroll
+  for (int u = 0; u < NL; ++u) {
+    const uint32_t c = (threadIdx.x + (uint32_t)u * kBlock) * V;
+    if (c + V <= n) {
+      v[u] = load_stream_cell_aligned<T, (int)V>(his + base + c);
+      if constexpr (HAS_STATUS) sv[u] = load_stream_cell_aligned<int32_t, (int)V>(his_st + base + c);
+    } else {
+#pragma unroll
+      for (uint32_t e = 0; e < V; ++e) {
+        v[u].v[e] = c + e < n ? his[base + c + e] : T(0);
+        if constexpr (HAS_STATUS) sv[u].v[e] = c + e < n ? his_st[base + c + e] : 0;
+      }
+    }
+  }
+  for (uint32_t i = threadIdx.x; i < a.len; i += kBlock) l_perm[i] = a.perm[i];
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < NL; ++u) {
+    const uint32_t c0 = (threadIdx.x + (uint32_t)u * kBlock) * V;
+#pragma unroll
+    for (uint32_t e = 0; e < V; ++e) {
+      const uint32_t c = c0 + e;
+      if (c < n) {
+        const uint32_t t = small_div(c, a.by_len);
+        const uint32_t dst = t * a.len + l_perm[c - t * a.len];
+        const T x = v[u].v[e];
+        const bool his_set = cell_is_set<T>(x, HAS_STATUS ? sv[u].v[e] : OLAP_STATUS_SET, HAS_STATUS, his_nan);
+        bool set;
+        T val;
+        if (his_set) {
+          val = x;
+          set = !Cell<T>::is_default(val, def_nan);
+        } else {  // his default against mine (see load_scatter_kernel)
+          val = Cell<T>::default_value(his_nan);
+          constexpr bool is_float = (Cell<T>::dtype == OLAP_FLOAT32 || Cell<T>::dtype == OLAP_FLOAT64);
+          set = his_nan ? (is_float && !def_nan) : def_nan;
+        }
+        tile[dst] = set ? val : Cell<T>::default_value(def_nan);
+        if (mine_st) stile[dst] = set ? OLAP_STATUS_SET : 0;
+      }
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < NL; ++u) {
+    const uint32_t c = (threadIdx.x + (uint32_t)u * kBlock) * V;
+    if (c + V <= n) {
+      store_stream_cell_aligned<T, (int)V>(mine + base + c, *reinterpret_cast<const Vec<T, (int)V> *>(tile + c));
+      if (mine_st) store_stream_cell_aligned<int32_t, (int)V>(mine_st + base + c, *reinterpret_cast<const Vec<int32_t, (int)V> *>(stile + c));
+    } else {
+#pragma unroll
+      for (uint32_t e = 0; e < V; ++e)
+        if (c + e < n) {
+          mine[base + c + e] = tile[c + e];
+          if (mine_st) mine_st[base + c + e] = stile[c + e];
+        }
+    }
+  }
+}
+
 // ======================================================================= K4: reorder as a brick transpose
 // in-memory.js:178-211.  When the output's fastest dimension is not the input's fastest one a plain
 // gather reads 4 B per cache line.  Here a workgroup owns a BRICK: a small range of every dimension
@@ -3298,6 +3392,8 @@ struct Launch {
                                    hipStream_t stream);
   static hipError_t drillup_segmented(int method, bool has_status, int vec, const T *in, const int32_t *st_in, T *out, int32_t *st_out,
                                       const DrillUpAxis &a, const SegmentedRows &sg, hipStream_t stream);
+  static hipError_t load_permute(bool has_status, const T *his, const int32_t *his_st, T *mine, int32_t *mine_st, const LoadPermute &a,
+                                 hipStream_t stream);
   static hipError_t total(const T *values, const int32_t *status, uint64_t n, int def_nan, void *workspace, double *total,
                           unsigned long long *count, hipStream_t stream);
   static hipError_t compact_count(const T *values, const int32_t *status, uint64_t n, uint64_t chunk, unsigned n_chunks,
@@ -3905,6 +4001,18 @@ hipError_t Launch<T>::load_scatter(bool has_status, int vec, const T *his, const
     if (vec == 4) OLAP_LD(false, 4); else if (vec == 2) OLAP_LD(false, 2); else OLAP_LD(false, 1);
   }
 #undef OLAP_LD
+  return hipGetLastError();
+}
+
+template <typename T>
+hipError_t Launch<T>::load_permute(bool has_status, const T *his, const int32_t *his_st, T *mine, int32_t *mine_st, const LoadPermute &a,
+                                   hipStream_t stream) {
+  if (a.n_rows == 0 || a.len == 0) return hipSuccess;
+  const uint64_t tiles = (a.n_rows + a.rows_per_tile - 1) / a.rows_per_tile;
+  if (tiles >= 0x7FFFFFFFull) return hipErrorInvalidValue;
+  const size_t lds = kTileBytes + (mine_st ? kTileBytes / sizeof(T) * 4 : 0) + (size_t)a.len * 4;
+  if (has_status) hipLaunchKernelGGL((load_permute_rows_kernel<T, true>), (unsigned)tiles, kBlock, lds, stream, his, his_st, mine, mine_st, a);
+  else hipLaunchKernelGGL((load_permute_rows_kernel<T, false>), (unsigned)tiles, kBlock, lds, stream, his, his_st, mine, mine_st, a);
   return hipGetLastError();
 }
 

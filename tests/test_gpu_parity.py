@@ -922,6 +922,57 @@ def test_load_lane_forms(case):
     assert same_typed(gm.get_data(), ev)
 
 
+@pytest.mark.parametrize("type_name", ["float32", "float64", "int32", "uint32"])
+@pytest.mark.parametrize("my_len,tag", [
+    ([700, 10], "many rows per tile, tiles that end inside the cube"),
+    ([3, 5, 4095], "one odd row per tile: rows that start at any cell offset"),
+    ([5, 4096], "a row is exactly a tile (4-byte cells)"),
+    ([2, 3, 1365], "three rows per tile, odd length"),
+    ([1, 2], "one row of two cells"),
+    ([9000, 3], "1 365 rows per tile"),
+])
+def test_load_permuted_rows(type_name, my_len, tag, monkeypatch):
+    """load() from a store whose LAST dimension lists the same items in another order, nothing else remapped
+    (load_permute_rows_kernel: rows rearranged through LDS, 16-byte loads and stores), every default pairing and both
+    masks, against the oracle — and the same answer from the scatter form it replaces."""
+    rng = np.random.default_rng(len(my_len) * 1000 + my_len[-1])
+    cap = 16384 // np.dtype(type_name).itemsize
+    maps = [np.arange(l, dtype=np.int32) for l in my_len[:-1]] + [rng.permutation(my_len[-1]).astype(np.int32)]
+    n = int(np.prod(my_len))
+    for my_default, his_default in [(0.0, 0.0), (float("nan"), 0.0), (0.0, float("nan")), (float("nan"), float("nan"))]:
+        monkeypatch.delenv("OLAP_LOAD_NO_PERMUTE", raising=False)
+        plan = pkg.Plan.load(type_name, my_default, his_default, my_len, my_len, maps)
+        assert plan.kernel_name == ("load_permute_rows_kernel" if my_len[-1] <= cap else "load_scatter (16-byte runs of the other store)"), tag
+        mine = np.where(rng.random(n) < 0.5, my_default, rng.integers(1, 50, size=n).astype(np.float64))
+        his = np.where(rng.random(n) < 0.4, his_default, rng.integers(50, 99, size=n).astype(np.float64))
+        results = []
+        for no_permute in (False, True):
+            if no_permute:
+                monkeypatch.setenv("OLAP_LOAD_NO_PERMUTE", "1")
+            else:
+                monkeypatch.delenv("OLAP_LOAD_NO_PERMUTE", raising=False)
+
+            def both(dflt, dense):
+                o = OracleStore(n, type_name, dflt)
+                typed = to_typed(dense, type_name).astype(np.float64)
+                if type_name in ("int32", "uint32") and dflt != dflt:
+                    typed = np.where(np.isnan(dense), np.nan, typed)
+                o.set_data(typed)
+                g = pkg.HipStore(n, type_name, dflt)
+                g.set_data_f64(dense)
+                return o, g
+
+            om, gm = both(my_default, mine)
+            oh, gh = both(his_default, his)
+            om.load(oh, my_len, my_len, maps)
+            gm.load(gh, my_len, my_len, maps)
+            ev, es = expected_typed(om)
+            assert np.array_equal(gm.get_status(), es), (tag, my_default, his_default, no_permute)
+            assert same_typed(gm.get_data(), ev), (tag, my_default, his_default, no_permute)
+            results.append(gm.get_data())
+        assert same_typed(results[0], results[1])
+
+
 @pytest.mark.parametrize("seed", range(40))
 def test_drilldown_with_distributions_randomized(seed):
     """drillDown with per-cell weights (in-memory.js:389-401) on one or two refined dimensions."""
