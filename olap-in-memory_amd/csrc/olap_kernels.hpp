@@ -3506,7 +3506,6 @@ static hipError_t drillup_axis_launch(const Batch<T> &b, unsigned nb, const Dril
   bool shallow = (kAdditive || IsPick<METHOD>::value) && VEC * sizeof(T) >= 16 && a.n_vec >= 1024;
   if (a.depth == 4) shallow = false;
   if (const char *e = getenv("OLAP_ROWS_DEPTH")) shallow = atoi(e) == 1;  // A/B: 1 or 4 rows in flight
-  const int deep_probe = getenv("OLAP_ROWS_DEPTH") ? atoi(getenv("OLAP_ROWS_DEPTH")) : 0;  // 8 / 16: probe variants (plain sums)
   if (!rows) {
     // LDS tile regime for small `inner` (short row pieces make the flat regime's accesses waste much
     // of every cache line): whole rows of K*inner cells staged per workgroup, kTileBytes of cells
@@ -3575,10 +3574,7 @@ static hipError_t drillup_axis_launch(const Batch<T> &b, unsigned nb, const Dril
       rg.grid = blocks < 0x7FFFFFFFull ? (uint32_t)blocks : 0u;
       if (blocks < 0x7FFFFFFFull) {
 #define OLAP_RAGGED(C, F) hipLaunchKernelGGL((drillup_rows_kernel<T, METHOD, HS, RV, U, C, F, true, true>), dim3((unsigned)blocks, nb), lanes, 0, stream, b, rg)
-#define OLAP_RAGGED_D(D, C) hipLaunchKernelGGL((drillup_rows_kernel<T, METHOD, HS, RV, D, C, true, true, true>), dim3((unsigned)blocks, nb), lanes, 0, stream, b, rg)
         if constexpr (kAdditive && !HS) {
-          if (fast && deep_probe == 8) { if (contig) OLAP_RAGGED_D(8, true); else OLAP_RAGGED_D(8, false); return hipGetLastError(); }
-          if (fast && deep_probe == 16) { if (contig) OLAP_RAGGED_D(16, true); else OLAP_RAGGED_D(16, false); return hipGetLastError(); }
           if (fast) {
             if (contig) OLAP_RAGGED(true, true); else OLAP_RAGGED(false, true);
             return hipGetLastError();
@@ -3592,10 +3588,6 @@ static hipError_t drillup_axis_launch(const Batch<T> &b, unsigned nb, const Dril
   }
   if (rows) {
     if constexpr (kAdditive && !HS) {
-#define OLAP_ROWS_D(D, C) hipLaunchKernelGGL((drillup_rows_kernel<T, METHOD, HS, VEC, D, C, true>), dim3((unsigned)row_blocks, nb), row_lanes, 0, stream, b, ar)
-      if (fast && deep_probe == 8) { if (contig) OLAP_ROWS_D(8, true); else OLAP_ROWS_D(8, false); return hipGetLastError(); }
-      if (fast && deep_probe == 16) { if (contig) OLAP_ROWS_D(16, true); else OLAP_ROWS_D(16, false); return hipGetLastError(); }
-#undef OLAP_ROWS_D
       if (fast) {
         if (shallow) { if (contig) OLAP_ROWS1(true, true); else OLAP_ROWS1(false, true); }
         else { if (contig) OLAP_ROWS(true, true); else OLAP_ROWS(false, true); }
