@@ -177,14 +177,22 @@ __device__ __forceinline__ void drillup_rows_body(const T *__restrict__ in, cons
   // ('-> all' over a contiguous member list: the bounds are 0 and K — no table to wait for before the first row's address)
   const bool whole = CONTIG && a.G == 1;
   uint32_t j = 0u, jend = (uint32_t)a.K;
-  if (!whole) {
-    // (workgroup-uniform; written as the scalar load it is — behind the select above the compiler issues two VECTOR
-    // loads here, several times the latency, on every workgroup's way to its first row)
-    const uint32_t *gp = a.gstart + __builtin_amdgcn_readfirstlane((uint32_t)g);
-    uint64_t bounds;
-    asm volatile("s_load_dwordx2 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(bounds) : "s"(gp) : "memory");
-    j = (uint32_t)bounds;
-    jend = (uint32_t)(bounds >> 32);
+  if constexpr (CONTIG) {
+    if (!whole) {
+      // (workgroup-uniform; written as the scalar load it is — behind the test above the compiler issues two VECTOR
+      // loads here, several times the latency, on every workgroup's way to its first row)
+      const uint32_t *gp = a.gstart + __builtin_amdgcn_readfirstlane((uint32_t)g);
+      uint64_t bounds;
+      asm("s_load_dwordx2 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(bounds) : "s"(gp));
+      j = (uint32_t)bounds;
+      jend = (uint32_t)(bounds >> 32);
+    }
+  } else {
+    // (interleaved groups keep the compiler's own scalar loads: behind an asm statement it no longer trusts that nothing
+    // was written and reads the member list in the loop with VECTOR loads — a dependent round trip in front of every
+    // batch of rows, 6-8 % on [3652,100,274] location -> 10 interleaved groups)
+    j = a.gstart[g];
+    jend = a.gstart[g + 1];
   }
 
   Lane<T, METHOD, HAS_STATUS, VEC, FAST> lane;
@@ -347,14 +355,20 @@ __global__ __launch_bounds__(kBlock) void drillup_rows_kernel(const Batch<T> b, 
   // compiler requests each pointer where it is first used — behind the early exit, the table look-up, the loop — and
   // a workgroup then pays five dependent scalar round trips before its first row is requested (ISA of round 3's
   // build; a stripped loop with one round trip was 3 % faster on the headline, tools/headline_limit.hip).
+  // (asm statements WITHOUT side effects and without a memory clobber: a volatile one counts as a possible write, after
+  // which the compiler reads the bounds and the member list with vector loads — a dependent round trip per batch of
+  // rows.  And the pointers themselves must not pass through one: what comes out is a generic pointer — flat loads.
+  // Their bits are tied into a value the first address needs instead: `pin >> 63` is 0, which the compiler cannot know.)
   const T *in = b.in[blockIdx.y];
   const int32_t *st_in = b.st_in[blockIdx.y];
   T *out = b.out[blockIdx.y];
   int32_t *st_out = b.st_out[blockIdx.y];
-  const uint32_t *gs = a.gstart, *ord = a.order;
-  asm volatile("" ::"s"(in), "s"(st_in), "s"(out), "s"(st_out), "s"(gs), "s"(ord), "s"(a.K), "s"(a.inner), "s"(a.G), "s"(a.n_vec),
-               "s"(a.blocks_per_row), "s"(a.grid), "s"(a.lanes), "s"(a.xcd_order), "s"(a.def_nan));
-  drillup_rows_body<T, METHOD, HAS_STATUS, VEC, U, CONTIG, FAST, NT, RAGGED>(in, st_in, out, st_out, a);
+  DrillUpAxis al = a;
+  uint64_t pin = (uint64_t)in | (uint64_t)st_in | (uint64_t)out | (uint64_t)st_out | (uint64_t)al.gstart | (uint64_t)al.order;
+  asm("" : "+s"(pin), "+s"(al.K), "+s"(al.inner), "+s"(al.G), "+s"(al.n_vec), "+s"(al.blocks_per_row), "+s"(al.grid), "+s"(al.lanes),
+      "+s"(al.xcd_order), "+s"(al.def_nan));
+  al.blocks_per_row += pin >> 63;
+  drillup_rows_body<T, METHOD, HAS_STATUS, VEC, U, CONTIG, FAST, NT, RAGGED>(in, st_in, out, st_out, al);
 }
 
 // Measures with DIFFERENT rules in one launch (config 5: sum / average / first / last over the same roll-up): the rule
