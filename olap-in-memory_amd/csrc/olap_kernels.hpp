@@ -375,13 +375,20 @@ __global__ __launch_bounds__(kBlock) void drillup_rows_kernel(const Batch<T> b, 
 // of pair blockIdx.y is a workgroup-uniform switch in front of the same bodies.  The kernel carries every rule's code
 // and the registers of the greediest, so it only serves batches whose rules differ; one rule -> drillup_rows_kernel.
 template <typename T, bool HAS_STATUS, int VEC, int U, bool CONTIG>
-__global__ __launch_bounds__(kBlock) void drillup_rows_mixed_kernel(const Batch<T> b, const DrillUpAxis a) {
+__global__ __launch_bounds__(kBlock) void drillup_rows_mixed_kernel(const Batch<T> b, const DrillUpAxis a_) {
+  // (kernel arguments in one batch of scalar loads: see drillup_rows_kernel)
   const T *in = b.in[blockIdx.y];
   const int32_t *st_in = b.st_in[blockIdx.y];
   T *out = b.out[blockIdx.y];
   int32_t *st_out = b.st_out[blockIdx.y];
+  int32_t rule = b.method[blockIdx.y];
+  DrillUpAxis a = a_;
+  uint64_t pin = (uint64_t)in | (uint64_t)st_in | (uint64_t)out | (uint64_t)st_out | (uint64_t)a.gstart | (uint64_t)a.order;
+  asm("" : "+s"(pin), "+s"(rule), "+s"(a.K), "+s"(a.inner), "+s"(a.G), "+s"(a.n_vec), "+s"(a.blocks_per_row), "+s"(a.grid), "+s"(a.lanes),
+      "+s"(a.xcd_order), "+s"(a.def_nan));
+  a.blocks_per_row += pin >> 63;
   const bool fast = !HAS_STATUS && !a.def_nan;  // additive rules over a 0 default without a mask: plain running sums
-  switch (b.method[blockIdx.y]) {
+  switch (rule) {
     case OLAP_SUM:
       if (fast) drillup_rows_body<T, OLAP_SUM, HAS_STATUS, VEC, U, CONTIG, !HAS_STATUS>(in, st_in, out, st_out, a);
       else drillup_rows_body<T, OLAP_SUM, HAS_STATUS, VEC, U, CONTIG, false>(in, st_in, out, st_out, a);

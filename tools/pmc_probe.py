@@ -56,7 +56,7 @@ def cases(pkg):
     add("drillUp [1000,1000,100] interleaved (flat)", P.drillup("float32", 0.0, "sum", [1000, 1000, 100], [1000, 10, 100], [ident(1000), (np.arange(1000) % 10).astype(np.uint32), ident(100)]), 10 ** 8, 10 ** 6)
     add("drillUp [10]^8 dim0->all highest", P.drillup("float32", 0.0, "highest", [10] * 8, [1] + [10] * 7, [np.zeros(10, np.uint32)] + [ident(10)] * 7), 10 ** 8, 10 ** 7)
     add("drillUp [1e6,100]->[1,100] (reduce)", P.drillup("float32", 0.0, "sum", [10 ** 6, 100], [1, 100], [np.zeros(10 ** 6, np.uint32), ident(100)]), 10 ** 8, 100)
-    add("drillUp [1e4,1e4]->[1,1e4] (split4)", P.drillup("float32", 0.0, "sum", [10 ** 4, 10 ** 4], [1, 10 ** 4], [np.zeros(10 ** 4, np.uint32), ident(10 ** 4)]), 10 ** 8, 10 ** 4)
+    add("drillUp [1e4,1e4]->[1,1e4] (row kernel over segments + fold)", P.drillup("float32", 0.0, "sum", [10 ** 4, 10 ** 4], [1, 10 ** 4], [np.zeros(10 ** 4, np.uint32), ident(10 ** 4)]), 10 ** 8, 10 ** 4)
     add("drillUp odd location->10 interleaved", P.drillup("float32", 0.0, "sum", odd, [3653, 10, 271], [ident(3653), (np.arange(101) % 10).astype(np.uint32), ident(271)]), n_odd, 3653 * 10 * 271, width="4")
     # round 3: the regimes that were below 0.70 and the load kernels
     add("drillUp [4e5,250]->[1,250] (reduce4, wide rows)", P.drillup("float32", 0.0, "sum", [400000, 250], [1, 250], [np.zeros(400000, np.uint32), ident(250)]), 10 ** 8, 250)
@@ -64,7 +64,7 @@ def cases(pkg):
     add("drillUp [3001,3333,10]->11 groups (flat)", P.drillup("float32", 0.0, "sum", [3001, 3333, 10], [3001, 11, 10], [ident(3001), (np.arange(3333) // 303).astype(np.uint32), ident(10)]),
         3001 * 3333 * 10, 3001 * 11 * 10, width="4")
     add("drillUp C5 city->country", P.drillup("float32", 0.0, "sum", [3652, 100, 274], [3652, 10, 274], [ident(3652), (np.arange(100) // 10).astype(np.uint32), ident(274)]),
-        3652 * 100 * 274, 3652 * 10 * 274, width="8")
+        3652 * 100 * 274, 3652 * 10 * 274, width="16")
     add("drillDown [12000,8192]->[120000,8192]", P.drilldown("float32", 0.0, "sum", [1200, 8192], [12000, 8192], [np.repeat(np.arange(1200), 10).astype(np.uint32), ident(8192)]),
         1200 * 8192, 12000 * 8192)
     i8 = [sel(10)] * 8
@@ -74,7 +74,7 @@ def cases(pkg):
     add("load [10]^8 items of dim4 remapped", P.load("float32", 0.0, 0.0, [10] * 8, [10] * 8, p4), 10 ** 8, 10 ** 8)
     p7 = list(i8)
     p7[7] = np.array([3, 1, 4, 0, 9, 2, 6, 5, 8, 7], np.int32)
-    add("load [10]^8 items of dim7 remapped", P.load("float32", 0.0, 0.0, [10] * 8, [10] * 8, p7), 10 ** 8, 10 ** 8, width="16/4")
+    add("load [10]^8 items of dim7 permuted (rows through LDS)", P.load("float32", 0.0, 0.0, [10] * 8, [10] * 8, p7), 10 ** 8, 10 ** 8)
     return out
 
 
