@@ -269,8 +269,12 @@ int32_t *olap_store_status_ptr(const olap_store *store);    /* device pointer */
  * dice, reorder, drillDown and load — at the price of one more uint32 per cell once the order stops being the flat
  * index, and of a second pass per operation; results of operations on a tracked store are tracked.
  * olap_store_from_sparse turns tracking on by itself when its index list is not ascending.
- * Limits: stores below 2^31 cells; sum / average / product still accumulate in index order (a float64 rounding
- * difference at most); olap_store_totals refuses a tracked store ("ordered: ..."): run the chain of drillUps.
+ * sum / average / product depend on the order of their contributions (float64 addition is not associative, and a running
+ * value that hits the default drops the key, which re-enters at the end): over an order that is not the flat index the
+ * set cells are sorted by (output cell, insertion sequence) and every output cell is replayed in that order — the
+ * reference's values and key order exactly, at the price of a radix sort; so are `first` / `last` over several
+ * rolled-up dimensions at once.
+ * Limits: stores below 2^31 cells; olap_store_totals refuses a tracked store ("ordered: ..."): run the chain of drillUps.
  * olap_store_order_tracked: 0 = not tracked, 1 = tracked and still ascending, 2 = tracked with an explicit order. */
 int olap_store_track_order(olap_store *store, int on);
 int olap_store_order_tracked(const olap_store *store);

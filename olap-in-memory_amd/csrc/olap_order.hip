@@ -20,9 +20,13 @@
 //   drillDown       visits the new cells in ascending index order: ascending again
 //   load            visits HIS cells in ascending index order (:159): cells it creates are appended in that order
 // Values of order-independent methods come from the ordinary kernels; only seq is computed here.
-// Known limit, stated in the header: sum / average / product over a store whose order is not ascending are
-// accumulated in index order (the reference: insertion order) — a float64 rounding difference at most.
+// sum / average / product DO depend on the order — float64 addition is not associative, and a running value that
+// hits the default drops the key, which then re-enters the Map at the END (in-memory.js:311-318, :126-131).  Over a
+// store whose order is ascending the ordinary kernels already add in that order; over any other order the
+// contributions are SORTED by (output cell, seq) and every output cell is replayed contribution by contribution
+// (order_drillup_replay): the reference's values bit for bit and its key order exactly, at the price of a radix sort.
 #include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
 
 #include <algorithm>
 #include <vector>
@@ -123,6 +127,165 @@ __global__ __launch_bounds__(kBlock) void drillup_byseq_kernel(const T *__restri
     if (st_out) st_out[t] = has ? OLAP_STATUS_SET : 0;
     out_seq[t] = has ? lo : 0u;  // the output cell was inserted when its first member was visited
   }
+}
+
+// ---- drillUp of a store whose order is NOT the flat index, for the rules that depend on it ------------------------
+struct ReplayDims {
+  int nd;
+  uint32_t old_len[OLAP_MAX_DIMS];
+  uint64_t new_stride[OLAP_MAX_DIMS];
+  uint32_t tab_off[OLAP_MAX_DIMS];  // start of dimension d's map (old item -> new item) in `tab`
+  const uint32_t *tab;               // device
+};
+
+// key = (output cell << 32) | seq for a set cell, all ones for an unset one (sorted to the end); value = the cell's index
+__global__ __launch_bounds__(kBlock) void replay_keys_kernel(const uint32_t *__restrict__ seq, uint64_t n, const ReplayDims d, uint64_t *__restrict__ keys,
+                                                             uint32_t *__restrict__ vals) {
+  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kBlock) {
+    const uint32_t q = seq[i];
+    uint64_t key = ~0ull;
+    if (q) {
+      uint64_t c = i, o = 0;
+      for (int k = d.nd - 1; k >= 0; --k) {
+        const uint32_t digit = (uint32_t)(c % d.old_len[k]);
+        c /= d.old_len[k];
+        o += (uint64_t)d.tab[d.tab_off[k] + digit] * d.new_stride[k];
+      }
+      key = (o << 32) | (uint64_t)q;
+    }
+    keys[i] = key;
+    vals[i] = (uint32_t)i;
+  }
+}
+
+// One lane per output cell that has contributions: the lane whose sorted position starts the cell's run replays the
+// run in seq order through the reference's state machine (Agg: first contribution stores, later ones aggregate, a
+// running value equal to the default drops the key — which re-enters at the position of the contribution that
+// brings it back, in-memory.js:311-318).
+template <typename T, int METHOD>
+__global__ __launch_bounds__(kBlock) void replay_kernel(const T *__restrict__ in, const uint64_t *__restrict__ keys, const uint32_t *__restrict__ vals,
+                                                        uint64_t n, T *__restrict__ out, int32_t *__restrict__ st_out, uint32_t *__restrict__ out_seq,
+                                                        int def_nan_i) {
+  const bool def_nan = def_nan_i != 0;
+  for (uint64_t p = (uint64_t)blockIdx.x * kBlock + threadIdx.x; p < n; p += (uint64_t)gridDim.x * kBlock) {
+    const uint64_t key = keys[p];
+    if (key == ~0ull) continue;
+    const uint64_t cell = key >> 32;
+    if (p > 0 && (keys[p - 1] >> 32) == cell) continue;  // not the head of its run
+    Agg<METHOD> agg;
+    agg.init();
+    uint32_t inserted = 0;
+    for (uint64_t q = p; q < n; ++q) {
+      const uint64_t kq = keys[q];
+      if ((kq >> 32) != cell) break;  // (the all-ones keys of unset cells end the last run too)
+      const bool had = agg.has;
+      agg.add(Cell<T>::to_f64(in[vals[q]]), def_nan);
+      if (!had && agg.has) inserted = (uint32_t)kq;
+    }
+    agg.finish(def_nan);
+    T ov;
+    int32_t os;
+    emit_cell<T>(agg.acc, agg.has, def_nan, ov, os);
+    out[cell] = ov;
+    if (st_out) st_out[cell] = os;
+    out_seq[cell] = os ? inserted : 0u;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void replay_clear_kernel(T *__restrict__ out, int32_t *__restrict__ st_out, uint32_t *__restrict__ out_seq, uint64_t n,
+                                                              int def_nan) {
+  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kBlock) {
+    out[i] = Cell<T>::default_value(def_nan != 0);
+    if (st_out) st_out[i] = 0;
+    out_seq[i] = 0u;
+  }
+}
+
+template <typename T>
+void launch_replay(int method, const T *in, const uint64_t *keys, const uint32_t *vals, uint64_t n, T *out, int32_t *st_out, uint32_t *out_seq,
+                   int def_nan) {
+  const unsigned grid = (unsigned)std::min<uint64_t>(65536, (n + kBlock - 1) / kBlock);
+#define OLAP_REPLAY(M) hipLaunchKernelGGL((replay_kernel<T, M>), grid, kBlock, 0, nullptr, in, keys, vals, n, out, st_out, out_seq, def_nan)
+  switch (method) {
+    case OLAP_SUM: OLAP_REPLAY(OLAP_SUM); break;
+    case OLAP_AVERAGE: OLAP_REPLAY(OLAP_AVERAGE); break;
+    case OLAP_HIGHEST: OLAP_REPLAY(OLAP_HIGHEST); break;
+    case OLAP_LOWEST: OLAP_REPLAY(OLAP_LOWEST); break;
+    case OLAP_FIRST: OLAP_REPLAY(OLAP_FIRST); break;
+    case OLAP_LAST: OLAP_REPLAY(OLAP_LAST); break;
+    default: OLAP_REPLAY(OLAP_PRODUCT); break;
+  }
+#undef OLAP_REPLAY
+}
+
+// per workgroup: are the non-zero seq of its contiguous share ascending, and their smallest / largest
+struct AscendingPart {
+  uint32_t lo, hi;  // smallest / largest non-zero seq of the share (0xFFFFFFFF / 0: none)
+  uint32_t ok;
+};
+__global__ __launch_bounds__(kBlock) void seq_ascending_kernel(const uint32_t *__restrict__ seq, uint64_t n, uint64_t share, AscendingPart *__restrict__ parts) {
+  __shared__ uint32_t wave_max[kBlock / 64];
+  __shared__ uint32_t s_ok, s_lo;
+  const uint64_t beg = (uint64_t)blockIdx.x * share, end = beg + share < n ? beg + share : n;
+  if (threadIdx.x == 0) {
+    s_ok = 1u;
+    s_lo = 0xFFFFFFFFu;
+  }
+  __syncthreads();
+  uint32_t carry = 0;  // largest seq seen before this step (uniform)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (uint64_t base = beg; base < end; base += kBlock) {
+    const uint64_t i = base + threadIdx.x;
+    const uint32_t v = i < end ? seq[i] : 0u;
+    // exclusive prefix maximum over the step's 256 cells
+    uint32_t inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t up = __shfl_up(inc, d, 64);
+      if (lane >= d) inc = inc > up ? inc : up;
+    }
+    if (lane == 63) wave_max[wave] = inc;
+    __syncthreads();
+    uint32_t before = carry;
+    for (int w = 0; w < wave; ++w) before = before > wave_max[w] ? before : wave_max[w];
+    uint32_t exc = __shfl_up(inc, 1, 64);
+    exc = lane == 0 ? 0u : exc;
+    exc = exc > before ? exc : before;
+    if (v && v <= exc) atomicAnd(&s_ok, 0u);
+    if (v) atomicMin(&s_lo, v);
+    uint32_t step_max = carry;
+    for (int w = 0; w < kBlock / 64; ++w) step_max = step_max > wave_max[w] ? step_max : wave_max[w];
+    carry = step_max;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    parts[blockIdx.x].lo = s_lo;
+    parts[blockIdx.x].hi = carry;
+    parts[blockIdx.x].ok = s_ok;
+  }
+}
+
+// whether the set cells' seq ascend with the flat index (then the ordinary kernels already add in insertion order)
+int seq_is_ascending(const olap_store *s, bool *ascending) {
+  *ascending = true;
+  if (!s->seq || s->size == 0) return OLAP_OK;
+  const unsigned blocks = (unsigned)std::min<uint64_t>(1024, (s->size + kBlock - 1) / kBlock);
+  const uint64_t share = ((s->size + blocks - 1) / blocks + kBlock - 1) / kBlock * kBlock;
+  AscendingPart *dev = nullptr;
+  HIP_TRY(dev_alloc((void **)&dev, blocks * sizeof(AscendingPart)));
+  hipLaunchKernelGGL(seq_ascending_kernel, blocks, kBlock, 0, nullptr, s->seq, s->size, share, dev);
+  std::vector<AscendingPart> host(blocks);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipMemcpy(host.data(), dev, blocks * sizeof(AscendingPart), hipMemcpyDeviceToHost);
+  dev_free(dev);
+  if (e != hipSuccess) return hip_fail(e, "seq_ascending_kernel");
+  uint32_t seen = 0;
+  for (const AscendingPart &p : host) {
+    if (!p.ok || (p.hi && p.lo <= seen)) *ascending = false;
+    seen = std::max(seen, p.hi);
+  }
+  return OLAP_OK;
 }
 
 int seq_alloc(const olap_store *s) {
@@ -279,11 +442,109 @@ int order_sorted_keys(const olap_store *s, std::vector<uint64_t> &keys) {
   return OLAP_OK;
 }
 
+// drillUp of a tracked store by sorting its set cells by (output cell, seq) and replaying every output cell's run: any
+// rule, any maps, the reference's values and key order exactly (s->seq is materialised)
+static int order_drillup_replay(const olap_store *s, olap_store **out, int ndim, const uint32_t *old_len, const uint32_t *new_len,
+                                const uint32_t *const *maps, int method) {
+  uint64_t n_in = 1, n_out = 1;
+  for (int d = 0; d < ndim; ++d) {
+    if (old_len[d] && !maps[d]) return fail(OLAP_ERR_INVALID_ARGUMENT, "maps[%d] is NULL", d);
+    for (uint32_t k = 0; k < old_len[d]; ++k)
+      if (maps[d][k] >= new_len[d])
+        return fail(OLAP_ERR_INDEX_RANGE, "drillUp map of dimension %d: entry %u = %u is outside the new dimension (%u items)", d, k, maps[d][k], new_len[d]);
+    n_in *= old_len[d];
+    n_out *= new_len[d];
+  }
+  if (n_in != s->size) return fail(OLAP_ERR_LENGTH_MISMATCH, "store holds %llu cells but the dimensions describe %llu", (unsigned long long)s->size, (unsigned long long)n_in);
+  if (n_in >= 0x7FFFFFFFull || n_out >= 0x7FFFFFFFull) return fail(OLAP_ERR_INVALID_ARGUMENT, "insertion-order tracking supports stores below 2^31 cells");
+  olap_store *o = nullptr;
+  int rc = store_alloc(&o, n_out, s->dtype, s->default_kind);
+  if (rc) return rc;
+  inherit(s, o);
+  o->next_seq = s->next_seq;
+  if ((rc = seq_alloc(o))) {
+    olap_store_destroy(o);
+    return rc;
+  }
+  const int def_nan = s->default_kind == OLAP_DEFAULT_NAN;
+  ORDER_DISPATCH(s->dtype, hipLaunchKernelGGL((replay_clear_kernel<T>), grid_for_n(n_out), kBlock, 0, nullptr, (T *)o->values, o->status, o->seq, n_out, def_nan));
+  if (n_in == 0 || n_out == 0) {
+    rc = launched("replay_clear_kernel");
+    if (!rc) {
+      hipError_t e = hipStreamSynchronize(nullptr);
+      if (e != hipSuccess) rc = hip_fail(e, "replay_clear_kernel");
+    }
+    if (rc) olap_store_destroy(o);
+    else *out = o;
+    return rc;
+  }
+  ReplayDims dims{};
+  dims.nd = ndim;
+  std::vector<uint32_t> tab;
+  {
+    uint64_t stride = 1;
+    for (int d = ndim - 1; d >= 0; --d) {
+      dims.old_len[d] = old_len[d];
+      dims.new_stride[d] = stride;
+      stride *= new_len[d];
+    }
+    for (int d = 0; d < ndim; ++d) {
+      dims.tab_off[d] = (uint32_t)tab.size();
+      tab.insert(tab.end(), maps[d], maps[d] + old_len[d]);
+    }
+    if (tab.empty()) tab.push_back(0);
+  }
+  void *dev_tab = nullptr, *keys_a = nullptr, *keys_b = nullptr, *vals_a = nullptr, *vals_b = nullptr, *tmp = nullptr;
+  size_t tmp_bytes = 0;
+  // only the bits that differ need sorting: the seq (32) and the output cell's
+  int cell_bits = 1;
+  while ((n_out - 1) >> cell_bits) ++cell_bits;
+  const int end_bit = 32 + cell_bits + 1;  // (+1: the all-ones key of an unset cell must sort last)
+  hipError_t e = dev_alloc(&dev_tab, tab.size() * sizeof(uint32_t));
+  if (e == hipSuccess) e = hipMemcpy(dev_tab, tab.data(), tab.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = dev_alloc(&keys_a, n_in * sizeof(uint64_t));
+  if (e == hipSuccess) e = dev_alloc(&keys_b, n_in * sizeof(uint64_t));
+  if (e == hipSuccess) e = dev_alloc(&vals_a, n_in * sizeof(uint32_t));
+  if (e == hipSuccess) e = dev_alloc(&vals_b, n_in * sizeof(uint32_t));
+  if (e == hipSuccess)
+    e = hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, (const uint64_t *)keys_a, (uint64_t *)keys_b, (const uint32_t *)vals_a, (uint32_t *)vals_b,
+                                           (unsigned int)n_in, 0, end_bit > 64 ? 64 : end_bit, (hipStream_t) nullptr);
+  if (e == hipSuccess) e = dev_alloc(&tmp, tmp_bytes ? tmp_bytes : 16);
+  if (e == hipSuccess) {
+    dims.tab = (const uint32_t *)dev_tab;
+    hipLaunchKernelGGL(replay_keys_kernel, grid_for_n(n_in), kBlock, 0, nullptr, (const uint32_t *)s->seq, n_in, dims, (uint64_t *)keys_a, (uint32_t *)vals_a);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess)
+    e = hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, (const uint64_t *)keys_a, (uint64_t *)keys_b, (const uint32_t *)vals_a, (uint32_t *)vals_b,
+                                           (unsigned int)n_in, 0, end_bit > 64 ? 64 : end_bit, (hipStream_t) nullptr);
+  if (e == hipSuccess) {
+    ORDER_DISPATCH(s->dtype, launch_replay<T>(method, (const T *)s->values, (const uint64_t *)keys_b, (const uint32_t *)vals_b, n_in, (T *)o->values, o->status,
+                                               o->seq, def_nan));
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(nullptr);  // the scratch goes back to the pool
+  for (void *q : {dev_tab, keys_a, keys_b, vals_a, vals_b, tmp})
+    if (q) dev_free(q);
+  if (e != hipSuccess) {
+    olap_store_destroy(o);
+    return hip_fail(e, "drillUp in insertion order (sort + replay)");
+  }
+  *out = o;
+  return OLAP_OK;
+}
+
 int order_drillup(const olap_store *s, olap_store **out, int ndim, const uint32_t *old_len, const uint32_t *new_len,
                   const uint32_t *const *maps, int method) {
   *out = nullptr;
   const bool pick_by_order = (method == OLAP_FIRST || method == OLAP_LAST) && s->seq != nullptr;
   int rc;
+  if (s->seq != nullptr && (method == OLAP_SUM || method == OLAP_AVERAGE || method == OLAP_PRODUCT)) {
+    // these rules depend on the order of their contributions: replay them in it unless it is the flat index after all
+    bool ascending = true;
+    if ((rc = seq_is_ascending(s, &ascending))) return rc;
+    if (!ascending) return order_drillup_replay(s, out, ndim, old_len, new_len, maps, method);
+  }
   if (!pick_by_order) {
     // values: the ordinary kernels (first / last over an ascending store ARE by flat index)
     if ((rc = store_drillup_plain(s, out, ndim, old_len, new_len, maps, method))) return rc;
@@ -318,7 +579,7 @@ int order_drillup(const olap_store *s, olap_store **out, int ndim, const uint32_
       ident = ident && maps[d][k] == k;
     }
     if (!ident) {
-      if (changed >= 0) return fail(OLAP_ERR_INVALID_ARGUMENT, "first / last over a store with a tracked insertion order: one rolled-up dimension per drillUp");
+      if (changed >= 0) return order_drillup_replay(s, out, ndim, old_len, new_len, maps, method);  // several rolled-up dimensions at once
       changed = d;
     }
   }

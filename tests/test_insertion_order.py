@@ -152,6 +152,80 @@ def test_random_operation_chains_keep_the_reference_order(seed):
         same(o, g, "%s (step %d)" % (op, step))
 
 
+def fill_in_order(n, type_name, default, order, values):
+    o, g = pair(n, type_name, default)
+    for k in order:
+        o.set(int(k), float(values[int(k)]))
+        g.set_value(int(k), float(values[int(k)]))
+    return o, g
+
+
+def test_sums_add_in_insertion_order_not_index_order():
+    """float64 addition is not associative: [1e16, 1, -1e16] entered as cells 0, 2, 1 sums to 1 in the reference
+    (1e16 - 1e16 = 0 drops the key, the 1 brings it back) and to 0 in index order (1 is absorbed by 1e16 first)."""
+    vals = np.array([1e16, 1.0, -1e16, 4.0, 5.0, 0.0])
+    order = [0, 2, 1, 4, 3]
+    m = [np.array([0, 0, 0, 1, 1, 1], np.uint32)]
+    for method in ("sum", "average", "product"):
+        o, g = fill_in_order(6, "float64", 0.0, order, vals)
+        oo, gg = o.drill_up([6], [2], m, method), g.drill_up([6], [2], m, method)
+        same(oo, gg, method)
+    o, g = fill_in_order(6, "float64", 0.0, order, vals)
+    got = g.drill_up([6], [2], m, "sum")
+    assert got.get_data_f64().tolist() == [1.0, 9.0] and got.keys().tolist() == [0, 1]
+    # the same cells entered ascending: the ordinary kernels (index order = insertion order): 1e16 + 1 = 1e16, - 1e16 = 0,
+    # the key is dropped (in-memory.js:126-131) and never comes back
+    o, g = fill_in_order(6, "float64", 0.0, [0, 1, 2, 3, 4], vals)
+    same(o.drill_up([6], [2], m, "sum"), g.drill_up([6], [2], m, "sum"), "ascending")
+    got = g.drill_up([6], [2], m, "sum")
+    assert got.get_data_f64().tolist() == [0.0, 9.0] and got.keys().tolist() == [1]
+
+
+def test_a_key_dropped_by_a_running_default_re_enters_at_the_end():
+    """sum of [3, -3, 7] in that order: the key is deleted when the running sum hits 0 and re-inserted by the 7 — behind
+    the other output cell, whose first contribution came earlier (in-memory.js:311-318)."""
+    vals = np.array([3.0, 10.0, -3.0, 7.0])
+    m = [np.array([0, 1, 0, 0], np.uint32)]
+    o, g = fill_in_order(4, "float32", 0.0, [0, 2, 1, 3], vals)
+    oo, gg = o.drill_up([4], [2], m, "sum"), g.drill_up([4], [2], m, "sum")
+    assert oo.entries()[0].tolist() == [1, 0]
+    same(oo, gg, "drop and re-enter")
+    # `first` / `last` of that result see the order
+    m1 = [np.zeros(2, np.uint32)]
+    assert gg.drill_up([2], [1], m1, "first").get_data_f64().tolist() == [10.0] == oo.drill_up([2], [1], m1, "first").dense()[0].tolist()
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_replayed_rollups_random(seed):
+    """Stores filled in random order with values that cancel, absorb and hit the default; every rule, one or several
+    rolled-up dimensions (first / last over several at once included): values, mask and key order against the oracle."""
+    rng = np.random.default_rng(9100 + seed)
+    type_name, default = [("float64", 0.0), ("float32", 0.0), ("float64", float("nan")), ("int32", 0.0), ("uint32", float("nan")), ("float32", float("nan"))][seed % 6]
+    lens = [int(x) for x in rng.integers(2, 7, size=3)]
+    n = int(np.prod(lens))
+    # (2^54 absorbs 1 in float64 and, like every value here, is exact in float32 too)
+    pool = np.array([1.0, -1.0, 2.0, -2.0, 3.0, 0.5, 2.0 ** 54, -2.0 ** 54, 2.0 ** -10, 7.0]) if type_name.startswith("float") else np.array([1.0, 2.0, 3.0, 5.0, 7.0, 11.0])
+    if type_name == "int32":
+        pool = np.concatenate([pool, -pool])
+    vals = rng.choice(pool, size=n)
+    order = rng.permutation(n)[: max(2, int(n * 0.8))]
+    several = seed % 3 == 0
+    maps, new = [], []
+    for d, l in enumerate(lens):
+        if d == seed % 3 or several:
+            G = int(rng.integers(1, l + 1))
+            gm = rng.integers(0, G, size=l).astype(np.uint32)
+            gm[rng.integers(0, l)] = G - 1  # every new item is named by the extents, not necessarily by a member
+            maps.append(gm)
+            new.append(G)
+        else:
+            maps.append(ident(l))
+            new.append(l)
+    for method in ("sum", "average", "product", "first", "last", "highest", "lowest"):
+        o, g = fill_in_order(n, type_name, default, order, vals)
+        same(o.drill_up(lens, new, maps, method), g.drill_up(lens, new, maps, method), "%s %s %s" % (method, lens, new))
+
+
 def test_load_appends_in_the_other_stores_index_order():
     my_len, his_len = [3, 4], [2, 3]
     o, g = pair(12, "float32", float("nan"))
