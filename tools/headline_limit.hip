@@ -108,6 +108,34 @@ __global__ __launch_bounds__(256) void stripped_long_kernel(const float *__restr
   }
 }
 
+// persistent form: a fixed grid, every workgroup walks column blocks grid-stride; block b+1's rows are requested while block
+// b's store is still on its way
+template <bool XCD>
+__global__ __launch_bounds__(256) void stripped_persistent_kernel(const float *__restrict__ in, float *__restrict__ out, uint64_t inner, int K) {
+  const uint64_t inner4 = inner / 4;
+  const uint64_t blocks = (inner4 + 255) / 256;
+  // XCD: a workgroup's blocks stay inside its XCD's contiguous range of the output
+  const uint32_t x = blockIdx.x % 8, per = gridDim.x / 8, w = blockIdx.x / 8;
+  const uint64_t range = (blocks + 7) / 8;
+  const uint64_t b0 = XCD ? x * range + w : blockIdx.x;
+  const uint64_t bend = XCD ? (x * range + range < blocks ? x * range + range : blocks) : blocks;
+  const uint64_t step = XCD ? per : gridDim.x;
+  for (uint64_t b = b0; b < bend; b += step) {
+    const uint64_t i = b * 256 + threadIdx.x;
+    if (i >= inner4) continue;
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int k = 0; k < K; ++k) {
+      const Vec<float, 4> v = load_stream<float, 4>(in + (uint64_t)k * inner + i * 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[e] += (double)v.v[e];
+    }
+    Vec<float, 4> o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o.v[e] = (float)acc[e];
+    store_stream<float, 4>(out + i * 4, o);
+  }
+}
+
 // what bench.py calls the read ceiling: a workgroup reads two 4 KB pieces and ends
 __global__ __launch_bounds__(256) void read_short_kernel(const float *__restrict__ src, uint64_t n_vec, float *scratch) {
   const uint64_t base = (uint64_t)blockIdx.x * 512 + threadIdx.x;
@@ -190,6 +218,10 @@ int main() {
   vs.push_back({"stripped, plain stores to 1 MB", [&] { hipLaunchKernelGGL(stripped_kernel<5>, grid, 256, 0, 0, in, out, inner, (int)K, sink); }, rd, {}});
   vs.push_back({"stripped, 2 blocks per workgroup", [&] { hipLaunchKernelGGL(stripped_long_kernel<2>, (grid + 1) / 2, 256, 0, 0, in, out, inner, (int)K); }, rd + wr, {}});
   vs.push_back({"stripped, 4 blocks per workgroup", [&] { hipLaunchKernelGGL(stripped_long_kernel<4>, (grid + 3) / 4, 256, 0, 0, in, out, inner, (int)K); }, rd + wr, {}});
+  vs.push_back({"persistent 2048 workgroups, grid-stride", [&] { hipLaunchKernelGGL(stripped_persistent_kernel<false>, 2048, 256, 0, 0, in, out, inner, (int)K); }, rd + wr, {}});
+  vs.push_back({"persistent 2048 workgroups, per XCD", [&] { hipLaunchKernelGGL(stripped_persistent_kernel<true>, 2048, 256, 0, 0, in, out, inner, (int)K); }, rd + wr, {}});
+  vs.push_back({"persistent 4096 workgroups, per XCD", [&] { hipLaunchKernelGGL(stripped_persistent_kernel<true>, 4096, 256, 0, 0, in, out, inner, (int)K); }, rd + wr, {}});
+  vs.push_back({"persistent 1024 workgroups, per XCD", [&] { hipLaunchKernelGGL(stripped_persistent_kernel<true>, 1024, 256, 0, 0, in, out, inner, (int)K); }, rd + wr, {}});
   vs.push_back({"stripped, plain stores", [&] { hipLaunchKernelGGL(stripped_kernel<3>, grid, 256, 0, 0, in, out, inner, (int)K, sink); }, rd + wr, {}});
   vs.push_back({"stripped, plain loads", [&] { hipLaunchKernelGGL(stripped_kernel<4>, grid, 256, 0, 0, in, out, inner, (int)K, sink); }, rd + wr, {}});
   vs.push_back({"linear 10:1 (40 KB read, 4 KB written)", [&] { hipLaunchKernelGGL(linear_mix_kernel, grid, 256, 0, 0, in, out, inner, (int)K); }, rd + wr, {}});
