@@ -622,6 +622,55 @@ def test_group_tile_regime(lens, sizes, method, type_name, default):
     assert same_typed(out.get_data(), ev)
 
 
+@pytest.mark.parametrize("lens,kind", [
+    ([5, 1000, 100], "mod100"),      # 100 interleaved groups of 10 members, pieces of 100 cells
+    ([3, 900, 12], "mod50"),         # 18 members x 12 cells per group
+    ([2, 640, 64], "random"),        # a random map: ragged group sizes, members anywhere
+    ([4, 3000, 8], "long"),          # groups of 300 members
+    ([3, 700, 6], "mod35"),          # pieces of 6 cells: 8-byte lanes
+])
+@pytest.mark.parametrize("method", ["sum", "average", "highest", "first", "last", "product"])
+@pytest.mark.parametrize("type_name,default", [("float32", 0.0), ("float64", float("nan")), ("uint32", float("nan"))])
+def test_flat_regime_interleaved_groups(lens, kind, method, type_name, default, monkeypatch):
+    """Interleaved groups over short row pieces whose rows do not fit LDS: the flat form (a lane per 16 bytes of output walks
+    its group's member list).  (Gathering a tile's members into LDS and reducing there, as for contiguous groups, was
+    measured: 103 us against the flat form's 81 us on [1000,1000,100] -> 100 groups, modular, blocked or random maps.)"""
+    monkeypatch.setenv("OLAP_REDUCE_MAX_CELLS", "0")  # (small cubes: keep the few-outputs regime out of the way)
+    rng = np.random.default_rng(77)
+    K = lens[1]
+    if kind.startswith("mod"):
+        amap = (np.arange(K) % int(kind[3:])).astype(np.uint32)
+    elif kind == "long":
+        amap = (np.arange(K) % 10).astype(np.uint32)
+    else:
+        amap = rng.integers(0, 40, size=K).astype(np.uint32)
+        amap = np.unique(amap, return_inverse=True)[1].astype(np.uint32)
+    n = int(np.prod(lens))
+    if method == "product":
+        vals = np.where(rng.random(n) < 0.5, 1.0, -1.0) if type_name != "uint32" else np.ones(n)
+        vals = vals * np.where(rng.random(n) < 0.05, 2.0, 1.0)
+    else:
+        vals = rng.integers(0 if type_name == "uint32" else -8, 9, size=n).astype(np.float64)
+        if type_name != "uint32":
+            vals = vals * 0.5
+    dense = np.where(rng.random(n) < 0.4, default, vals)
+    new = [lens[0], int(amap.max()) + 1, lens[2]]
+    maps = [np.arange(lens[0], dtype=np.uint32), amap, np.arange(lens[2], dtype=np.uint32)]
+    plan = pkg.Plan.drillup(type_name, default, method, lens, new, maps)
+    assert plan.kernel_name == "drillup_flat_kernel", plan.kernel_name
+    o = OracleStore(n, type_name, default)
+    typed = to_typed(dense, type_name).astype(np.float64)
+    if type_name == "uint32":
+        typed = np.where(np.isnan(dense), np.nan, typed)
+    o.set_data(typed)
+    ev, es = expected_typed(o.drill_up(lens, new, maps, method))
+    g = pkg.HipStore(n, type_name, default)
+    g.set_data_f64(dense)
+    out = g.drill_up(lens, new, maps, method)
+    assert np.array_equal(out.get_status(), es)
+    assert same_typed(out.get_data(), ev)
+
+
 def _boundary_cases():
     """Seeded sample of one-axis drillUps whose extents sit on the boundaries between the kernel
     regimes (vector width, 128 vector slots, the 16 KiB tile, 256-member groups, 131 072 outputs)."""

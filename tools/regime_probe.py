@@ -17,6 +17,8 @@ CASES = {
     "tall1000_axis0": ([10 ** 5, 1000], 0, lambda K: np.zeros(K)),
     "tall250_axis0": ([4 * 10 ** 5, 250], 0, lambda K: np.zeros(K)),
     "flat100": ([1000, 1000, 100], 1, lambda K: np.arange(K) % 100),
+    "flat100_random": ([1000, 1000, 100], 1, lambda K: np.random.default_rng(5).permutation(K) % 100),
+    "flat100_blocks": ([1000, 1000, 100], 1, lambda K: (np.arange(K) // 5) % 100),
     "c5_country": ([3652, 100, 274], 1, lambda K: np.arange(K) // 10),
     "c5_interleaved": ([3652, 100, 274], 1, lambda K: np.arange(K) % 10),
     "narrow540": ([1800, 100, 540], 1, lambda K: np.arange(K) % 10),
