@@ -293,6 +293,13 @@ def read_ceiling(pkg, engine, torch, buf, n_bytes):
     return n_bytes / (us * 1e-6) / 1e9
 
 
+def write_ceiling(pkg, engine, torch, buf, n_bytes):
+    """The write-side counterpart (olap_diag_write_ceiling): 16-byte streaming stores over the output buffer, same run."""
+    L = pkg.lib()
+    us = _time(torch, lambda: pkg.capi.check(L.olap_diag_write_ceiling(buf.data_ptr(), n_bytes, engine.stream())), iters=50, warm=5)
+    return n_bytes / (us * 1e-6) / 1e9
+
+
 def launch_ranks(args):
     """N > 1 without a launcher: start the ranks as a child process tree BEFORE this process touches the GPU
     (never an exec of a process that has initialised HIP) and relay what they print."""
@@ -561,8 +568,10 @@ def main():
 
     with_mask = None
     ceiling = None
+    w_ceiling = None
     if not sharded_path:
         ceiling = read_ceiling(pkg, engine, torch, values, n * 4)
+        w_ceiling = write_ceiling(pkg, engine, torch, partial, n_out * 4)  # (the output buffer: rewritten by every step anyway)
         if not args.no_extras:
             # the same launch with the Int32 status mask read and written (10 % of the cells unset)
             sv, ss = engine.empty(n, "float32"), engine.empty(n, "int32")
@@ -704,6 +713,14 @@ def main():
         if ceiling:
             line["roofline"].update({"read_ceiling": ceiling, "frac_of_read_ceiling": achieved / ceiling,
                                      "read_ceiling_note": "plain 16-byte streaming read of the same 400 MB buffer, same run"})
+        if ceiling and w_ceiling:
+            # HBM is half-duplex: R bytes read and W bytes written cost R / read ceiling + W / write ceiling on this box
+            # (tools/headline_limit.hip, profiles/headline_ab_r03.txt), which is what bounds this roll-up — not (R + W) / peak
+            bound_us = (n * 4 / ceiling + n_out * 4 / w_ceiling) * 1e-3
+            line["roofline"].update({"write_ceiling": w_ceiling,
+                                     "half_duplex_bound": {"us": bound_us, "frac_of_peak": alg_bytes / (bound_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                                                           "achieved_over_bound": bound_us / (kernel_ms * 1e3),
+                                                           "note": "read time at the box's read ceiling + write time at its write ceiling, both measured in this run"}})
         if with_mask:
             line["with_status_mask"] = with_mask
         line.update(extra)

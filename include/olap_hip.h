@@ -230,6 +230,10 @@ int olap_memcpy_to_device(void *device, const void *host, uint64_t bytes);
  * lane (the achievable read ceiling of the box, measured in the same run as the kernels
  * it is compared with).  `scratch` needs 4 * 2048 bytes.  Asynchronous on `stream`. */
 int olap_diag_read_ceiling(const void *device, uint64_t bytes, void *scratch, void *stream);
+/* Diagnostic: the write-side counterpart — `bytes` bytes of `device` overwritten with 16-byte streaming stores (the box's
+ * write ceiling; HBM is half-duplex, so a kernel that reads R and writes W bytes is bounded by R / read ceiling +
+ * W / write ceiling, not by (R + W) / peak).  The buffer's contents are lost.  Asynchronous on `stream`. */
+int olap_diag_write_ceiling(void *device, uint64_t bytes, void *stream);
 /* Diagnostic, host-only (no device): where the cells of one row of the view [outer, K, inner] go in the LDS tile of the
  * row-tile drillUp regime when groups interleave (DESIGN.md K1', MODE 3) — cell_pos[K * inner] (LDS cell of every cell
  * of a row), group_bounds[2 G] (first and one-past-last member position of every group's run) and *pitch (members

@@ -110,6 +110,7 @@ SIGNATURES = {
     "olap_memcpy_to_host": (_i32, [_vp, _vp, _u64]),
     "olap_memcpy_to_device": (_i32, [_vp, _vp, _u64]),
     "olap_diag_read_ceiling": (_i32, [_vp, _u64, _vp, _vp]),
+    "olap_diag_write_ceiling": (_i32, [_vp, _u64, _vp]),
     # multi-GPU (include/olap_hip.h, "Multi-GPU")
     "olap_comm_unique_id": (_i32, [C.c_char_p]),
     "olap_comm_init_rank": (_i32, [_pvp, C.c_char_p, _i32, _i32, _i32]),

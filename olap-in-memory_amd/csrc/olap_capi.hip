@@ -2051,6 +2051,28 @@ __global__ __launch_bounds__(kBlock) void diag_read_kernel(const float *__restri
   if (acc == 123456.789f) scratch[blockIdx.x & 2047] = acc;  // keeps the loads alive without a store per lane
 }
 
+__global__ __launch_bounds__(kBlock) void diag_write_kernel(float *__restrict__ dst, uint64_t n_vec) {
+  const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n_vec) return;
+  Vec<float, 4> x;
+  x.v[0] = x.v[1] = x.v[2] = x.v[3] = (float)threadIdx.x;
+  store_stream<float, 4>(dst + i * 4, x);
+}
+
+extern "C" int olap_diag_write_ceiling(void *device, uint64_t bytes, void *stream) {
+  if (!device) return fail(OLAP_ERR_INVALID_ARGUMENT, "write ceiling: NULL buffer");
+  int rc;
+  if ((rc = require_device())) return rc;
+  const uint64_t n_vec = bytes / 16;
+  if (n_vec == 0) return OLAP_OK;
+  const uint64_t grid = (n_vec + kBlock - 1) / kBlock;
+  if (grid >= 0x7FFFFFFFull) return fail(OLAP_ERR_INVALID_ARGUMENT, "write ceiling: buffer too large");
+  hipLaunchKernelGGL(diag_write_kernel, (unsigned)grid, kBlock, 0, (hipStream_t)stream, (float *)device, n_vec);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return hip_fail(e, "diag_write_kernel");
+  return OLAP_OK;
+}
+
 extern "C" int olap_diag_tile_placement(int dtype, uint32_t K, uint32_t G, uint32_t inner, const uint32_t *map, uint32_t *cell_pos,
                                         uint32_t *group_bounds, uint32_t *pitch) {
   int rc;
