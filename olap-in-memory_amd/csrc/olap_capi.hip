@@ -470,7 +470,11 @@ extern "C" int olap_drillup_plan(olap_plan **out, int dtype, int default_kind, i
         uint32_t shortest = ~0u;
         for (uint32_t g = 0; g < a.G; ++g) shortest = std::min(shortest, gstart[g + 1] - gstart[g]);
         const bool coop = shortest >= 256 && !getenv("OLAP_GTILE_NO_COOP");  // (whatever the rule: a plan's tables do not depend on it)
-        const bool enough_lanes = a.G * a.inner >= 64 * (cut.size() - 1) || coop;
+        // (short groups too: a lane's work is its group's members, so a tile with few output cells is cheap when those are
+        // few — day -> month over 8-byte cells with the day innermost: 67 months per tile, 31 LDS reads each; 320 us flat)
+        uint32_t longest_group = 0;
+        for (uint32_t g = 0; g < a.G; ++g) longest_group = std::max(longest_group, gstart[g + 1] - gstart[g]);
+        const bool enough_lanes = a.G * a.inner >= 64 * (cut.size() - 1) || coop || longest_group <= 64;
         if (fits && enough_lanes && a.outer * (cut.size() - 1) < 0x7FFFFFFFull) {
           void *dev_cut = nullptr;
           if ((rc = upload(&dev_cut, cut.data(), cut.size() * sizeof(uint32_t)))) {
@@ -500,8 +504,12 @@ extern "C" int olap_drillup_plan(olap_plan **out, int dtype, int default_kind, i
         // (rows of up to 1 024 four-byte cells too when the 16-byte form below applies — one contiguous '-> all' group
         // whose steps are whole 16-byte groups: a unit then streams its segment as ONE contiguous range, 1-7 rows per
         // step, where the lane-per-cell split form reads 4 KB pieces a row apart: [4e5,250] -> [1,250] 88 us -> see DESIGN K1r)
-        const bool wide16 = a.inner > 128 && a.inner <= 1024 && contiguous && a.G == 1 && olap_dtype_size(dtype) == 4 && (a.K * a.inner) % 4 == 0 &&
-                            (a.inner % 4 == 0 || (a.inner % 2 == 0 && a.inner <= 512) || a.inner <= 256) && !getenv("OLAP_REDUCE_NO_WIDE");
+        // (V = cells per 16 bytes; the smallest whole number of rows that is whole 16-byte groups must fit a unit's lanes)
+        const uint64_t V16 = 16 / olap_dtype_size(dtype);
+        uint64_t rows_min = 1;
+        while ((rows_min * a.inner) % V16 != 0) rows_min *= 2;
+        const bool wide16 = a.inner > 128 && rows_min * a.inner <= (uint64_t)kBlock * V16 && contiguous && a.G == 1 && (a.K * a.inner) % V16 == 0 &&
+                            !getenv("OLAP_REDUCE_NO_WIDE");
         if (a.inner <= 128 || wide16) {
           const uint64_t groups = a.outer * a.G;
           // Segments per group.  More, shorter segments lose to the per-unit epilogue and to the partials they write
@@ -537,26 +545,25 @@ extern "C" int olap_drillup_plan(olap_plan **out, int dtype, int default_kind, i
           // 16 B form: one contiguous '-> all' group, whole rows and segments in multiples of 4 cells
           uint64_t seg_len = ((uint64_t)longest + S - 1) / S;
           seg_len = (seg_len + 3) & ~3ull;
-          // rows per step: a power of two whose cells are whole 16-byte groups (1 for rows of a multiple of 4 cells, 2 for
-          // even rows, 4 otherwise), doubled while the unit's lanes hold them
-          uint32_t rows4 = a.inner % 4 == 0 ? 1 : a.inner % 2 == 0 ? 2 : 4;
-          while ((uint64_t)rows4 * 2 * a.inner <= (uint64_t)rd.unit * 4) rows4 *= 2;
-          if (rows4 < 4 && a.inner <= 128) rows4 = 4;  // (narrow rows: as before)
-          if (contiguous && a.G == 1 && olap_dtype_size(dtype) == 4 && (a.K * a.inner) % 4 == 0 &&
-              (uint64_t)rows4 * a.inner <= (uint64_t)rd.unit * 4) {
+          // rows per step: a power of two whose cells are whole 16-byte groups (4-byte cells: 1 for rows of a multiple of 4
+          // cells, 2 for even rows, 4 otherwise; 8-byte cells: 1 for even rows, 2 otherwise), doubled while the unit's lanes hold them
+          uint32_t rows4 = (uint32_t)rows_min;
+          while ((uint64_t)rows4 * 2 * a.inner <= (uint64_t)rd.unit * V16) rows4 *= 2;
+          if (rows4 < V16 && a.inner <= 128) rows4 = (uint32_t)V16;  // (narrow rows: as before)
+          if (contiguous && a.G == 1 && (a.K * a.inner) % V16 == 0 && (uint64_t)rows4 * a.inner <= (uint64_t)rd.unit * V16) {
             // as many rows per step as the unit's lanes hold (whole 16-byte groups): 10 rows of 100 cells fill 250 of 256
             // lanes where the power of two below fills 200; the rows are then merged through LDS instead of lane to lane
-            uint64_t rows_any = (uint64_t)rd.unit * 4 / a.inner;
-            while (rows_any > rows4 && (rows_any * a.inner) % 4 != 0) --rows_any;
-            if (a.inner > 2 && rows_any * 10 >= (uint64_t)rows4 * 11 && !getenv("OLAP_REDUCE_POW2_ROWS")) rows4 = (uint32_t)rows_any;
+            uint64_t rows_any = (uint64_t)rd.unit * V16 / a.inner;
+            while (rows_any > rows4 && (rows_any * a.inner) % V16 != 0) --rows_any;
+            if (a.inner * 2 > V16 && rows_any * 10 >= (uint64_t)rows4 * 11 && !getenv("OLAP_REDUCE_POW2_ROWS")) rows4 = (uint32_t)rows_any;
             rd.vec4 = 1;
             rd.rows = rows4;
             rd.seg_len = (uint32_t)seg_len;
-          } else if (contiguous && a.G == 1 && olap_dtype_size(dtype) == 4 && a.inner == 1) {
+          } else if (contiguous && a.G == 1 && a.inner == 1) {
             // rows at any cell offset: aligned 16-byte groups with masked ends (every lane of the unit busy)
             rd.vec4 = 1;
             rd.edge = 1;
-            rd.rows = rd.unit * 4;
+            rd.rows = rd.unit * (uint32_t)V16;
             rd.seg_len = (uint32_t)seg_len;
           }
         } else {

@@ -1266,15 +1266,16 @@ __global__ __launch_bounds__(kBlock) void drillup_reduce_kernel(const T *__restr
 }
 
 // 16 B form of the cooperative reduction for '-> all' roll-ups of contiguous rows (G == 1, no member
-// table, K*inner and the segment length multiples of 4 cells): the unit streams `rows*inner`
-// consecutive cells per step as one float4 per lane; lane element e always lands on output cell
-// (lane*4 + e) % inner because the step is a whole number of rows.
+// table, K*inner and the segment length multiples of V cells, V = 16 / sizeof(T): 4 cells of 4 bytes, 2 of 8): the unit
+// streams `rows*inner` consecutive cells per step as one 16-byte group per lane; lane element e always lands on output
+// cell (lane*V + e) % inner because the step is a whole number of rows.
 template <typename T, int METHOD, bool HAS_STATUS, bool FAST>
 __global__ __launch_bounds__(kBlock) void drillup_reduce4_kernel(const T *__restrict__ in,
                                                                  const int32_t *__restrict__ st_in,
                                                                  T *__restrict__ out, int32_t *__restrict__ st_out,
                                                                  const DrillUpAxis a, const DrillUpReduce rd) {
-  __shared__ Partial lds[kBlock * 4];
+  constexpr int V = 16 / sizeof(T);
+  __shared__ Partial lds[kBlock * V];
   typedef typename OutCell<T, METHOD>::type O;  // float64 partials under OLAP_PARTIAL_AVERAGE
   O *outp = reinterpret_cast<O *>(out);
   const uint32_t inner = (uint32_t)a.inner;
@@ -1285,43 +1286,43 @@ __global__ __launch_bounds__(kBlock) void drillup_reduce4_kernel(const T *__rest
   const uint32_t seg = (uint32_t)(unit_id % rd.S);
   const uint64_t o = live ? unit_id / rd.S : 0;
   const uint32_t lane = threadIdx.x % rd.unit;
-  const uint32_t lds_base = (threadIdx.x - lane) * 4;
-  const uint32_t step_cells = rd.rows * inner;          // multiple of 4, <= unit * 4
-  const bool active = live && lane * 4 < step_cells;
+  const uint32_t lds_base = (threadIdx.x - lane) * V;
+  const uint32_t step_cells = rd.rows * inner;          // multiple of V, <= unit * V
+  const bool active = live && lane * V < step_cells;
   const bool def_nan = a.def_nan != 0;
   const uint64_t jbeg = (uint64_t)seg * rd.seg_len < a.K ? (uint64_t)seg * rd.seg_len : a.K;
   const uint64_t jend = jbeg + rd.seg_len < a.K ? jbeg + rd.seg_len : a.K;
   const uint64_t cell_beg = jbeg * inner, cell_end = jend * inner;  // within the row `o`
   const T *row = in + o * a.K * a.inner;
   const int32_t *srow = HAS_STATUS ? st_in + o * a.K * a.inner : nullptr;
-  Partial p[4];
+  Partial p[V];
 #pragma unroll
-  for (int e = 0; e < 4; ++e) p[e] = partial_identity<METHOD>();
+  for (int e = 0; e < V; ++e) p[e] = partial_identity<METHOD>();
   if (active && rd.edge) {
     // inner == 1, the row starts anywhere inside a 16-byte group: sweep the ALIGNED groups that cover
     // [gbeg, gend) of the buffer and let cells outside the row contribute nothing
     constexpr int U = 4;
     const int64_t gbeg = (int64_t)(o * a.K) + (int64_t)cell_beg, gend = (int64_t)(o * a.K) + (int64_t)cell_end;
     const int64_t n_cells = (int64_t)(a.outer * a.K);
-    for (int64_t gi = (gbeg & ~(int64_t)3) + (int64_t)lane * 4; gi < gend; gi += (int64_t)step_cells * U) {
-      Vec<T, 4> x[U];
-      Vec<int32_t, 4> sx[U];
+    for (int64_t gi = (gbeg & ~(int64_t)(V - 1)) + (int64_t)lane * V; gi < gend; gi += (int64_t)step_cells * U) {
+      Vec<T, V> x[U];
+      Vec<int32_t, V> sx[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const int64_t g4 = gi + (int64_t)u * step_cells;
-        if (g4 < gend && g4 + 4 <= n_cells) {
-          x[u] = load_stream<T, 4>(in + g4);
-          if constexpr (HAS_STATUS) sx[u] = load_stream<int32_t, 4>(st_in + g4);
+        if (g4 < gend && g4 + V <= n_cells) {
+          x[u] = load_stream<T, V>(in + g4);
+          if constexpr (HAS_STATUS) sx[u] = load_stream<int32_t, V>(st_in + g4);
         } else if (g4 < gend) {  // the last group of the buffer, cell by cell
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
+          for (int e = 0; e < V; ++e) {
             const bool ok = g4 + e < n_cells;
             x[u].v[e] = ok ? in[g4 + e] : T(0);
             if constexpr (HAS_STATUS) sx[u].v[e] = ok ? st_in[g4 + e] : 0;
           }
         } else {  // past the segment: nothing to read (the masks below drop these cells)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
+          for (int e = 0; e < V; ++e) {
             x[u].v[e] = T(0);
             if constexpr (HAS_STATUS) sx[u].v[e] = 0;
           }
@@ -1331,7 +1332,7 @@ __global__ __launch_bounds__(kBlock) void drillup_reduce4_kernel(const T *__rest
       for (int u = 0; u < U; ++u) {
         const int64_t g4 = gi + (int64_t)u * step_cells;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
+        for (int e = 0; e < V; ++e) {
           const bool valid = g4 + e >= gbeg && g4 + e < gend;
           if constexpr (FAST) {
             const double v = valid ? Cell<T>::to_f64(x[u].v[e]) : 0.0;
@@ -1347,15 +1348,14 @@ __global__ __launch_bounds__(kBlock) void drillup_reduce4_kernel(const T *__rest
     }
   } else if (active) {
     constexpr int U = 4;
-    constexpr int V = 4;
-    for (uint64_t c = cell_beg + lane * 4; c < cell_end; c += (uint64_t)step_cells * U) {
+    for (uint64_t c = cell_beg + lane * V; c < cell_end; c += (uint64_t)step_cells * U) {
       Vec<T, V> x[U];
       Vec<int32_t, V> sx[U];
       uint64_t cc[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         cc[u] = c + (uint64_t)u * step_cells;
-        const uint64_t at = cc[u] < cell_end ? cc[u] : c;  // cell_end - cell_beg is a multiple of 4
+        const uint64_t at = cc[u] < cell_end ? cc[u] : c;  // cell_end - cell_beg is a multiple of V
         x[u] = load_stream<T, V>(row + at);
         if constexpr (HAS_STATUS) sx[u] = load_stream<int32_t, V>(srow + at);
       }
@@ -1363,7 +1363,7 @@ __global__ __launch_bounds__(kBlock) void drillup_reduce4_kernel(const T *__rest
       for (int u = 0; u < U; ++u) {
         const bool in_range = cc[u] < cell_end;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
+        for (int e = 0; e < V; ++e) {
           if constexpr (FAST) {
             const double v = in_range ? Cell<T>::to_f64(x[u].v[e]) : 0.0;
             p[e].acc += v;
@@ -1377,68 +1377,72 @@ __global__ __launch_bounds__(kBlock) void drillup_reduce4_kernel(const T *__rest
       }
     }
   }
-  // When rows line up with lanes (inner a multiple of 4, or 1 / 2) the rows of a step are merged
+  // When rows line up with lanes (inner a multiple of V, or a divisor of it: 1 / 2) the rows of a step are merged
   // lane to lane: row r + s of a step sits s*inner/4 lanes further on.  Distances up to 32 lanes stay
   // inside the first wavefront and are wave shuffles; a workgroup-wide unit folds the longer ones
   // through LDS first (three levels at most).
   // Idle lanes hold the identity.  With one segment per group the result is final and leaves from here.
   // (rows per step need not be a power of two — 10 rows of 100 cells fill 250 of a unit's 256 lanes where 8 fill 200 —
   // but the lane-to-lane merge needs one: other row counts take the LDS tree below)
-  const bool by_shuffle = inner <= 2 || (inner % 4 == 0 && (rd.rows & (rd.rows - 1)) == 0);
+  const bool by_shuffle = inner * 2 <= (uint32_t)V || (inner % V == 0 && (rd.rows & (rd.rows - 1)) == 0);
   if (by_shuffle) {
     uint32_t m, top;  // lanes per row, rows spread over the unit's lanes
-    uint32_t ne = 4;  // accumulators per lane still in play
-    if (inner <= 2) {
-      if (inner == 1) {
-        partial_merge_fast<METHOD, FAST>(p[0], p[1], def_nan);
-        partial_merge_fast<METHOD, FAST>(p[2], p[3], def_nan);
-        partial_merge_fast<METHOD, FAST>(p[0], p[2], def_nan);
+    uint32_t ne = V;  // accumulators per lane still in play
+    if (inner * 2 <= (uint32_t)V) {  // a lane's 16 bytes hold several rows: fold them first
+      if constexpr (V == 4) {
+        if (inner == 1) {
+          partial_merge_fast<METHOD, FAST>(p[0], p[1], def_nan);
+          partial_merge_fast<METHOD, FAST>(p[2], p[3], def_nan);
+          partial_merge_fast<METHOD, FAST>(p[0], p[2], def_nan);
+        } else {
+          partial_merge_fast<METHOD, FAST>(p[0], p[2], def_nan);
+          partial_merge_fast<METHOD, FAST>(p[1], p[3], def_nan);
+        }
       } else {
-        partial_merge_fast<METHOD, FAST>(p[0], p[2], def_nan);
-        partial_merge_fast<METHOD, FAST>(p[1], p[3], def_nan);
+        partial_merge_fast<METHOD, FAST>(p[0], p[1], def_nan);  // (8-byte cells: inner == 1)
       }
       m = 1;
       top = rd.unit;
       ne = inner;
     } else {
-      m = inner / 4;
+      m = inner / V;
       top = rd.rows;
     }
     for (uint32_t s = top >> 1; s > 0; s >>= 1) {
       const uint32_t d = s * m;
       if (d > 32) {  // partner lane l + d may sit in another wavefront (only for rd.unit == kBlock): fold through LDS
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
+        for (int e = 0; e < V; ++e)
           if ((uint32_t)e < ne) lds[e * kBlock + threadIdx.x] = p[e];  // 16 B per lane, lanes adjacent: no bank conflicts
         __syncthreads();
         if (threadIdx.x < d) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e)
+          for (int e = 0; e < V; ++e)
             if ((uint32_t)e < ne) partial_merge_fast<METHOD, FAST>(p[e], lds[e * kBlock + threadIdx.x + d], def_nan);
         }
         __syncthreads();
       } else {
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
+        for (int e = 0; e < V; ++e)
           if ((uint32_t)e < ne) partial_merge_lane<METHOD, FAST>(p[e], d, def_nan);
       }
     }
     if constexpr (FAST) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) partial_seal(p[e]);
+      for (int e = 0; e < V; ++e) partial_seal(p[e]);
     }
-    if (live && lane * 4 < inner) {
+    if (live && lane * V < inner) {
       if (rd.S == 1) {
-        if (inner % 4 == 0) {
-          Vec<O, 4> ov;
-          Vec<int32_t, 4> os;
+        if (inner % V == 0) {
+          Vec<O, V> ov;
+          Vec<int32_t, V> os;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) partial_finish<T, METHOD>(p[e], def_nan, ov.v[e], os.v[e]);
-          store_vec<O, 4>(outp + o * a.inner + lane * 4, ov);
-          if (st_out) store_vec<int32_t, 4>(st_out + o * a.inner + lane * 4, os);
+          for (int e = 0; e < V; ++e) partial_finish<T, METHOD>(p[e], def_nan, ov.v[e], os.v[e]);
+          store_vec<O, V>(outp + o * a.inner + lane * V, ov);
+          if (st_out) store_vec<int32_t, V>(st_out + o * a.inner + lane * V, os);
         } else {
 #pragma unroll
-          for (int e = 0; e < 2; ++e) {  // constant indices: p[] must stay in registers
+          for (int e = 0; e < V / 2; ++e) {  // constant indices: p[] must stay in registers
             if ((uint32_t)e < inner) {
               O ov;
               int32_t os;
@@ -1450,14 +1454,14 @@ __global__ __launch_bounds__(kBlock) void drillup_reduce4_kernel(const T *__rest
         }
       } else {
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-          if (lane * 4 + e < inner) rd.part[(o * a.inner + lane * 4 + e) * rd.S + seg] = p[e];
+        for (int e = 0; e < V; ++e)
+          if (lane * V + e < inner) rd.part[(o * a.inner + lane * V + e) * rd.S + seg] = p[e];
       }
     }
     return;  // the whole workgroup takes this path
   }
 #pragma unroll
-  for (int e = 0; e < 4; ++e) lds[lds_base + lane * 4 + e] = p[e];
+  for (int e = 0; e < V; ++e) lds[lds_base + lane * V + e] = p[e];
   __syncthreads();
   // tree over the rows of a step: flat slot f = r*inner + i.  Rows beyond the largest power of two are folded onto
   // the first rows before the tree starts.
@@ -3743,11 +3747,11 @@ static hipError_t drillup_reduce_launch(bool has_status, const T *in, const int3
   const bool fast = kAdditive && !has_status && !a.def_nan;
   // cooperative form: rows of up to 128 cells, or — 16-byte form only — of up to 1 024 (the scalar form gives a lane
   // one cell of one row per step: rows must fit the unit's lanes; otherwise the lane-per-cell split form below)
-  const bool vec4_now = rd.vec4 && a.aligned16 && sizeof(T) == 4;
+  const bool vec4_now = rd.vec4 && a.aligned16 && (rd.rows > 0 || sizeof(T) == 4);  // (16-byte form: 4 cells of 4 bytes, 2 of 8)
   if (rd.rows > 0 && (vec4_now || a.inner <= rd.unit)) {
     const uint64_t upb = kBlock / rd.unit;
     const unsigned grid = (unsigned)((a.outer * a.G * rd.S + upb - 1) / upb);
-    if (rd.vec4 && a.aligned16 && sizeof(T) == 4) {
+    if (vec4_now) {
       if (has_status) hipLaunchKernelGGL((drillup_reduce4_kernel<T, METHOD, true, false>), grid, kBlock, 0, stream, in, st_in, out, st_out, a, rd);
       else if (kAdditive && fast) hipLaunchKernelGGL((drillup_reduce4_kernel<T, METHOD, false, kAdditive>), grid, kBlock, 0, stream, in, st_in, out, st_out, a, rd);
       else hipLaunchKernelGGL((drillup_reduce4_kernel<T, METHOD, false, false>), grid, kBlock, 0, stream, in, st_in, out, st_out, a, rd);

@@ -537,27 +537,27 @@ def test_reduce_regime_shapes(lens, axis, method):
                                        # inner = 1 with rows at odd offsets (K % 4 != 0): aligned groups, masked ends
                                        ([5000, 301], 1), ([3, 40001], 1), ([100001], 0), ([130000, 257], 1)])
 @pytest.mark.parametrize("method", ["sum", "average", "first", "last", "highest", "lowest", "product"])
-@pytest.mark.parametrize("type_name,default", [("float32", 0.0), ("float32", float("nan")), ("uint32", float("nan"))])
+@pytest.mark.parametrize("type_name,default", [("float32", 0.0), ("float32", float("nan")), ("uint32", float("nan")), ("float64", 0.0), ("float64", float("nan"))])
 def test_reduce_regime_to_all(lens, axis, method, type_name, default):
     """'-> all' roll-ups of contiguous rows with few output cells: the 16-byte cooperative form
-    (drillup_reduce4_kernel) in each of its geometries — wave-shuffle row merge (inner 1, 2, 4, 8, 12, 64)
-    and LDS tree (inner 10, 128), one segment per group (result written by the reduction itself), a few
-    segments (lane-per-cell merge) and hundreds (wave-per-cell merge), with and without the status mask."""
+    (drillup_reduce4_kernel: four 4-byte cells or two 8-byte cells per lane) in each of its geometries — wave-shuffle row
+    merge (inner 1, 2, 4, 8, 12, 64) and LDS tree (inner 10, 128), one segment per group (result written by the reduction
+    itself), a few segments (lane-per-cell merge) and hundreds (wave-per-cell merge), with and without the status mask."""
     rng = np.random.default_rng(17)
     n = int(np.prod(lens))
     if method == "product":
-        vals = np.where(rng.random(n) < 0.5, 1.0, -1.0) if type_name == "float32" else np.ones(n)
+        vals = np.where(rng.random(n) < 0.5, 1.0, -1.0) if type_name.startswith("float") else np.ones(n)
         vals = vals * np.where(rng.random(n) < 4.0 / lens[axis], 2.0, 1.0)
     else:
         vals = rng.integers(0 if type_name == "uint32" else -8, 9, size=n).astype(np.float64)
-        if type_name == "float32":
+        if type_name.startswith("float"):
             vals = vals * 0.5
     dense = np.where(rng.random(n) < 0.4, default, vals)
     new = list(lens)
     new[axis] = 1
     maps = [np.zeros(l, np.uint32) if i == axis else np.arange(l, dtype=np.uint32) for i, l in enumerate(lens)]
     plan = pkg.Plan.drillup(type_name, default, method, lens, new, maps)
-    assert "reduce" in plan.kernel_name, plan.kernel_name
+    assert "reduce4" in plan.kernel_name, plan.kernel_name
     o = OracleStore(n, type_name, default)
     typed = to_typed(dense, type_name).astype(np.float64)
     if type_name == "uint32":
@@ -1639,12 +1639,14 @@ def test_split_regime_wide_rows(lens, axis, kind, type_name, default, method):
             vals = vals * 0.25
     dense = np.where(rng.random(n) < 0.3, default, vals)
     plan = pkg.Plan.drillup(type_name, default, method, lens, new, maps)
-    # one contiguous '-> all' group of rows up to 1 024 four-byte cells: the cooperative 16-byte form streams whole
-    # segments (drillup_reduce4_kernel); everything else here takes the lane-per-cell split forms
+    # one contiguous '-> all' group whose smallest whole-16-byte run of rows fits a workgroup's lanes (1 024 four-byte
+    # cells, 512 eight-byte ones): the cooperative 16-byte form streams whole segments (drillup_reduce4_kernel);
+    # everything else here takes the lane-per-cell split forms or the row kernel over segments
     inner = int(np.prod(lens[axis + 1:]))
-    coop = (kind == "all" and type_name != "float64" and inner <= 1024 and (K * inner) % 4 == 0 and
-            (inner % 4 == 0 or (inner % 2 == 0 and inner <= 512) or inner <= 256))
     item = 8 if type_name == "float64" else 4
+    per16 = 16 // item
+    rows_min = next(r for r in (1, 2, 4) if (r * inner) % per16 == 0)
+    coop = kind == "all" and rows_min * inner <= 256 * per16 and (K * inner) % per16 == 0
     vec = next(v for v in (16 // item, 2, 1) if inner % v == 0 and v <= 16 // item)
     if coop:
         assert "reduce4" in plan.kernel_name, plan.kernel_name

@@ -16,6 +16,20 @@ CASES = {
     "sq_axis0": ([10 ** 4, 10 ** 4], 0, lambda K: np.zeros(K)),
     "tall1000_axis0": ([10 ** 5, 1000], 0, lambda K: np.zeros(K)),
     "tall250_axis0": ([4 * 10 ** 5, 250], 0, lambda K: np.zeros(K)),
+    "tall100_axis0": ([10 ** 6, 100], 0, lambda K: np.zeros(K)),
+    "tall10_axis0": ([10 ** 7, 10], 0, lambda K: np.zeros(K)),
+    "all_cells": ([10 ** 8], 0, lambda K: np.zeros(K)),
+    "wide_axis1": ([100, 10 ** 6], 1, lambda K: np.zeros(K)),
+    "day_innermost": ([27400, 3652], 1, lambda K: (np.arange(K) // 30.4375).astype(np.uint32)),
+    "axis5": ([10 ** 5, 10, 100], 1, lambda K: np.zeros(K)),
+    "axis6": ([10 ** 6, 10, 10], 1, lambda K: np.zeros(K)),
+    "axis7": ([10 ** 7, 10], 1, lambda K: np.zeros(K)),
+    "mid_month30": ([900, 3652, 30], 1, lambda K: (np.arange(K) // 30.4375).astype(np.uint32)),
+    "mid_month100": ([274, 3652, 100], 1, lambda K: (np.arange(K) // 30.4375).astype(np.uint32)),
+    "groups11": ([3001, 3333, 10], 1, lambda K: np.arange(K) // 303),
+    "tile_interleaved": ([10 ** 5, 1000], 1, lambda K: np.arange(K) % 10),
+    "rows1000_all": ([10 ** 5, 1000], 1, lambda K: np.zeros(K)),
+    "c5_product": ([3653, 101, 271], 2, lambda K: np.zeros(K)),
     "flat100": ([1000, 1000, 100], 1, lambda K: np.arange(K) % 100),
     "flat100_random": ([1000, 1000, 100], 1, lambda K: np.random.default_rng(5).permutation(K) % 100),
     "flat100_blocks": ([1000, 1000, 100], 1, lambda K: (np.arange(K) // 5) % 100),
@@ -55,11 +69,13 @@ def main():
     new = list(lens)
     new[axis] = int(amap.max()) + 1
     maps = [amap if i == axis else np.arange(l, dtype=np.uint32) for i, l in enumerate(lens)]
-    vals = eng.empty(n, "float32")
-    pkg.capi.check(L.olap_fill_seeded(vals.data_ptr(), None, n, 0, 2, 1234, 1.0, eng.stream()))
+    dtype = os.environ.get("DTYPE", "float32")  # float32 | float64
+    size, code = {"float32": (4, 2), "float64": (8, 3)}[dtype]
+    vals = eng.empty(n, dtype)
+    pkg.capi.check(L.olap_fill_seeded(vals.data_ptr(), None, n, 0, code, 1234, 1.0, eng.stream()))
     n_out = n // lens[axis] * new[axis]
-    out = eng.empty(n_out, "float32")
-    plan = pkg.Plan.drillup("float32", 0.0, method, lens, new, maps)
+    out = eng.empty(n_out, dtype)
+    plan = pkg.Plan.drillup(dtype, 0.0, method, lens, new, maps)
     args = (vals.data_ptr(), None, out.data_ptr(), None, eng.stream())
     for _ in range(3):
         plan.run(*args)
@@ -70,7 +86,7 @@ def main():
     b.record()
     torch.cuda.synchronize()
     ms = a.elapsed_time(b) / iters
-    gbs = (n + n_out) * 4 / (ms * 1e-3) / 1e9
+    gbs = (n + n_out) * size / (ms * 1e-3) / 1e9
     print("%-18s %-8s %9.1f us %9.1f GB/s  %.3f  %s" % (sys.argv[1], method, ms * 1e3, gbs, gbs / 8000, plan.kernel_name), flush=True)
 
 
