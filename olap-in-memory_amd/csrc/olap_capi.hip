@@ -243,7 +243,7 @@ struct olap_plan {
   Brick brick{};
   uint64_t n_bricks = 0;
   GatherReduce gr{};
-  bool xy_ok = false;                      // reorder of 4-byte cells without a mask: two-axis LDS transpose (olap_transpose.hip)
+  bool xy_ok = false;                      // reorder without a mask: two-axis LDS transpose (olap_transpose.hip; 4- and 8-byte cells)
   TransposeXY xy{};
   DrillUpReduce reduce{};                  // S > 0: reduce regime of the one-axis drillUp
   LoadPermute lperm{};                     // lperm.perm != nullptr: load whose innermost items are permuted, nothing else (load_permute_rows_kernel)
@@ -1050,7 +1050,7 @@ extern "C" int olap_reorder_plan(olap_plan **out, int dtype, int default_kind, i
     }
   }
   const bool contiguous_tail = m.empty() || m.back().stride == 1;
-  if (!contiguous_tail && olap_dtype_size(dtype) == 4 && p->out_cells > 0 && !getenv("OLAP_NO_XY")) {
+  if (!contiguous_tail && p->out_cells > 0 && !getenv("OLAP_NO_XY")) {
     // two-axis transpose: X = the source's fastest dimensions, Y = the destination's fastest ones (olap_transpose.hip)
     const int n = (int)m.size();
     std::vector<uint64_t> ostr(n);
@@ -1103,11 +1103,12 @@ extern "C" int olap_reorder_plan(olap_plan **out, int dtype, int default_kind, i
     for (int k = 0; k < t.nx; ++k) out4 = out4 && t.out_stride_x[k] % 4 == 0;
     if (ok) {
       // measured (tools/pmc_probe.py): long runs matter more on the write side
-      t.ty = t.ly >= 96 ? 128 : 64;
+      const bool wide_cells = olap_dtype_size(dtype) == 8;  // (64 x 64 tiles of 8-byte cells: the same 512-byte runs, 33 KB of LDS)
+      t.ty = t.ly >= 96 && !wide_cells ? 128 : 64;
       t.tx = 64;
       if (const char *e = getenv("OLAP_XY_TILE")) {  // developer knob: "64x64" | "128x64" | "64x128"
         int a = 0, b2 = 0;
-        if (sscanf(e, "%dx%d", &a, &b2) == 2 && (a == 64 || a == 128) && (b2 == 64 || b2 == 128)) {
+        if (sscanf(e, "%dx%d", &a, &b2) == 2 && (a == 64 || a == 128) && (b2 == 64 || b2 == 128) && !(wide_cells && a == 128 && b2 == 128)) {
           t.tx = a;
           t.ty = b2;
         }
@@ -1133,9 +1134,9 @@ extern "C" int olap_reorder_plan(olap_plan **out, int dtype, int default_kind, i
           if (!getenv("OLAP_XY_ORDER")) t.y_first = 0;
         }
       }
-      t.vec_in = in4 && t.lx % 4 == 0;
-      t.vec_out = out4 && t.ly % 4 == 0;
-      const bool is_float = dtype == OLAP_FLOAT32;
+      t.vec_in = !wide_cells && in4 && t.lx % 4 == 0;
+      t.vec_out = !wide_cells && out4 && t.ly % 4 == 0;
+      const bool is_float = dtype == OLAP_FLOAT32 || dtype == OLAP_FLOAT64;
       t.default_test = is_float ? (p->def_nan ? 2 : 1) : (p->def_nan ? 3 : 0);
       ok = (t.tiles_x + t.super - 1) / t.super * ((t.tiles_y + t.super - 1) / t.super) * t.super * t.super * t.batch < 0x7FFFFFFFull;  // the grid is padded to whole super-tiles
     }
@@ -1651,8 +1652,8 @@ static int run_typed(olap_plan *p, const void *in_v, const int32_t *in_s, void *
   T *out = (T *)out_v;
   const bool hs = in_s != nullptr;
   hipError_t e = hipSuccess;
-  if (p->xy_ok && !hs) {  // reorder without a mask to honour: pure permutation of 4-byte cells
-    e = launch_transpose_xy(p->xy, in_v, out_v, out_s, aligned16(in_v) && aligned16(out_v) && (!out_s || aligned16(out_s)), stream);
+  if (p->xy_ok && !hs) {  // reorder without a mask to honour: pure permutation of the cells
+    e = launch_transpose_xy(p->xy, (int)sizeof(T), in_v, out_v, out_s, aligned16(in_v) && aligned16(out_v) && (!out_s || aligned16(out_s)), stream);
     if (e != hipSuccess) return hip_fail(e, p->kernel_name.c_str());
     return OLAP_OK;
   }

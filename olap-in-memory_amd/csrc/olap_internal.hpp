@@ -92,7 +92,8 @@ struct TransposeXY {
   int vec_in, vec_out;                       // every tile row starts 16-byte aligned on that side
   int default_test;                          // how a generated mask tells the default: 0 int/0, 1 float/0, 2 float/NaN, 3 never
 };
-OLAP_INTERNAL hipError_t launch_transpose_xy(const TransposeXY &t, const void *in, void *out, int32_t *st_out, bool aligned16, hipStream_t stream);
+OLAP_INTERNAL hipError_t launch_transpose_xy(const TransposeXY &t, int cell_bytes, const void *in, void *out, int32_t *st_out, bool aligned16,
+                                              hipStream_t stream);
 
 // ---- insertion order of tracked stores (olap_order.hip) --------------------------------------------
 OLAP_INTERNAL void order_free(olap_store *s);

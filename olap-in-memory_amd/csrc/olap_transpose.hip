@@ -1,5 +1,6 @@
 // olap_transpose.hip — reorder (axis permutation, /root/reference/src/store/in-memory.js:178-211) of
-// 4-byte cells as a two-axis LDS transpose.
+// 4-byte cells (and, one cell per lane, 8-byte cells: Float64 measures, integer measures of the Node host) as a two-axis
+// LDS transpose.
 //
 // A permutation whose fastest dimension changes reads 4 bytes per cache line if it is written as a
 // gather.  Here the dimensions are split into
@@ -67,11 +68,14 @@ extern "C" int olap_diag_xy_probe(unsigned long long *host, unsigned long long n
 
 namespace {
 
-template <int TX, int TY, bool VIN, bool VOUT>
-__global__ __launch_bounds__(kBlock) void transpose_xy_kernel(const uint32_t *__restrict__ in, uint32_t *__restrict__ out,
+// W: the cell as bits — uint32_t, or uint64_t for 8-byte cells (one cell per lane on both sides: 512-byte runs per
+// wavefront; the 16-byte lane forms VIN / VOUT are the 4-byte cells')
+template <typename W, int TX, int TY, bool VIN, bool VOUT>
+__global__ __launch_bounds__(kBlock) void transpose_xy_kernel(const W *__restrict__ in, W *__restrict__ out,
                                                               int32_t *__restrict__ st_out, const TransposeXY t) {
   constexpr int P = TY + 1;
-  extern __shared__ __attribute__((aligned(16))) uint32_t tile[];  // TX * P cells
+  extern __shared__ __attribute__((aligned(16))) unsigned char tile_raw[];
+  W *tile = reinterpret_cast<W *>(tile_raw);  // TX * P cells
   __shared__ uint64_t out_x[TX];  // destination offset of tile column x (relative to the tile's base)
   __shared__ uint64_t in_y[TY];   // source offset of tile row y
 
@@ -144,9 +148,9 @@ __global__ __launch_bounds__(kBlock) void transpose_xy_kernel(const uint32_t *__
   __syncthreads();
   XY_PROBE(1);
 
-  const uint32_t *src = in + base_in;
+  const W *src = in + base_in;
   // ---- in: rows along X
-  if constexpr (VIN) {
+  if constexpr (VIN && sizeof(W) == 4) {
     // a 32-lane group = 8 quads x 4 rows; the workgroup's 8 groups tile QX quad-blocks x RY row-blocks
     constexpr int QX = TX / 32;          // 32-cell blocks across a row
     constexpr int RY = 8 / QX;           // row blocks per pass
@@ -180,7 +184,7 @@ __global__ __launch_bounds__(kBlock) void transpose_xy_kernel(const uint32_t *__
     constexpr int PASSES = TY / ROWS;
     constexpr int UB = 8;
     for (int p0 = 0; p0 < PASSES; p0 += UB) {
-      uint32_t v[UB];
+      W v[UB];
 #pragma unroll
       for (int u = 0; u < UB; ++u) {
         const uint32_t y = (p0 + u) * ROWS + r0;
@@ -199,19 +203,21 @@ __global__ __launch_bounds__(kBlock) void transpose_xy_kernel(const uint32_t *__
   XY_PROBE(2);
 
   // ---- out: rows along Y
-  uint32_t *dst = out + base_out;
+  W *dst = out + base_out;
   int32_t *sdst = st_out ? st_out + base_out : nullptr;
-  auto status_of = [&](uint32_t bits) -> int32_t {
+  auto status_of = [&](W bits) -> int32_t {
     bool is_default;
+    constexpr W kAbs = (W)(~(W)0 >> 1);                                     // everything but the sign bit
+    constexpr W kInf = sizeof(W) == 4 ? (W)0x7F800000u : (W)0x7FF0000000000000ull;
     switch (t.default_test) {
       case 0: is_default = bits == 0u; break;                               // integer cells, 0 default
-      case 1: is_default = (bits << 1) == 0u; break;                        // float cells, 0 default (+0 and -0)
-      case 2: is_default = (bits & 0x7FFFFFFFu) > 0x7F800000u; break;       // float cells, NaN default
+      case 1: is_default = (bits & kAbs) == 0u; break;                      // float cells, 0 default (+0 and -0)
+      case 2: is_default = (bits & kAbs) > kInf; break;                     // float cells, NaN default
       default: is_default = false; break;
     }
     return is_default ? 0 : OLAP_STATUS_SET;
   };
-  if constexpr (VOUT) {
+  if constexpr (VOUT && sizeof(W) == 4) {
     constexpr int QY = TY / 32;
     constexpr int RX = 8 / QY;
     constexpr int ROWS = RX * 4;
@@ -242,7 +248,7 @@ __global__ __launch_bounds__(kBlock) void transpose_xy_kernel(const uint32_t *__
     for (int p = 0; p < PASSES; ++p) {
       const uint32_t x = p * ROWS + r0;
       if (x < nx && y < ny) {
-        const uint32_t v = tile[x * P + y];
+        const W v = tile[x * P + y];
         if (t.cached_stores) dst[out_x[x] + y] = v;
         else __builtin_nontemporal_store(v, dst + out_x[x] + y);
         if (sdst) __builtin_nontemporal_store(status_of(v), sdst + out_x[x] + y);
@@ -252,18 +258,32 @@ __global__ __launch_bounds__(kBlock) void transpose_xy_kernel(const uint32_t *__
   XY_PROBE(3);
 }
 
-template <int TX, int TY, bool VIN, bool VOUT>
-hipError_t launch_one(const TransposeXY &t, const uint32_t *in, uint32_t *out, int32_t *st_out, unsigned grid, hipStream_t stream) {
-  constexpr size_t lds = (size_t)TX * (TY + 1) * sizeof(uint32_t);
+template <typename W, int TX, int TY, bool VIN, bool VOUT>
+hipError_t launch_one(const TransposeXY &t, const W *in, W *out, int32_t *st_out, unsigned grid, hipStream_t stream) {
+  constexpr size_t lds = (size_t)TX * (TY + 1) * sizeof(W);
   if (lds > 48 * 1024) {
     static PerDeviceFlag raised;  // (per instantiation, per device)
     if (!raised.test_and_set()) {
-      hipError_t e = hipFuncSetAttribute((const void *)transpose_xy_kernel<TX, TY, VIN, VOUT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipError_t e = hipFuncSetAttribute((const void *)transpose_xy_kernel<W, TX, TY, VIN, VOUT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) return e;
     }
   }
-  hipLaunchKernelGGL((transpose_xy_kernel<TX, TY, VIN, VOUT>), grid, kBlock, lds, stream, in, out, st_out, t);
+  hipLaunchKernelGGL((transpose_xy_kernel<W, TX, TY, VIN, VOUT>), grid, kBlock, lds, stream, in, out, st_out, t);
   return hipGetLastError();
+}
+
+static bool grid_of(const TransposeXY &t, unsigned *grid, hipError_t *err) {
+  const uint64_t kSuper = (uint64_t)t.super;
+  const uint64_t sx = (t.tiles_x + kSuper - 1) / kSuper, sy = (t.tiles_y + kSuper - 1) / kSuper;
+  const uint64_t tiles = sx * sy * kSuper * kSuper * t.batch;
+  *err = hipSuccess;
+  if (t.tiles_x * t.tiles_y * t.batch == 0) return false;
+  if (tiles > 0x7FFFFFFFull) {
+    *err = hipErrorInvalidValue;
+    return false;
+  }
+  *grid = (unsigned)tiles;
+  return true;
 }
 
 template <int TX, int TY>
@@ -274,15 +294,24 @@ hipError_t launch_tile(const TransposeXY &t, const uint32_t *in, uint32_t *out, 
   if (t.tiles_x * t.tiles_y * t.batch == 0) return hipSuccess;
   if (tiles > 0x7FFFFFFFull) return hipErrorInvalidValue;
   const unsigned grid = (unsigned)tiles;
-  if (vin && vout) return launch_one<TX, TY, true, true>(t, in, out, st_out, grid, stream);
-  if (vin) return launch_one<TX, TY, true, false>(t, in, out, st_out, grid, stream);
-  if (vout) return launch_one<TX, TY, false, true>(t, in, out, st_out, grid, stream);
-  return launch_one<TX, TY, false, false>(t, in, out, st_out, grid, stream);
+  if (vin && vout) return launch_one<uint32_t, TX, TY, true, true>(t, in, out, st_out, grid, stream);
+  if (vin) return launch_one<uint32_t, TX, TY, true, false>(t, in, out, st_out, grid, stream);
+  if (vout) return launch_one<uint32_t, TX, TY, false, true>(t, in, out, st_out, grid, stream);
+  return launch_one<uint32_t, TX, TY, false, false>(t, in, out, st_out, grid, stream);
 }
 
 }  // namespace
 
-hipError_t launch_transpose_xy(const TransposeXY &t, const void *in, void *out, int32_t *st_out, bool aligned16, hipStream_t stream) {
+hipError_t launch_transpose_xy(const TransposeXY &t, int cell_bytes, const void *in, void *out, int32_t *st_out, bool aligned16, hipStream_t stream) {
+  if (cell_bytes == 8) {  // one 8-byte cell per lane on both sides (the plan sets 64 x 64 tiles: 33 KB of LDS)
+    unsigned grid = 0;
+    hipError_t e;
+    if (!grid_of(t, &grid, &e)) return e;
+    if (t.tx == 64 && t.ty == 64) return launch_one<uint64_t, 64, 64, false, false>(t, (const uint64_t *)in, (uint64_t *)out, st_out, grid, stream);
+    if (t.tx == 128 && t.ty == 64) return launch_one<uint64_t, 128, 64, false, false>(t, (const uint64_t *)in, (uint64_t *)out, st_out, grid, stream);
+    if (t.tx == 64 && t.ty == 128) return launch_one<uint64_t, 64, 128, false, false>(t, (const uint64_t *)in, (uint64_t *)out, st_out, grid, stream);
+    return hipErrorInvalidValue;
+  }
   const bool vin = t.vec_in && aligned16, vout = t.vec_out && aligned16;
   const uint32_t *src = (const uint32_t *)in;
   uint32_t *dst = (uint32_t *)out;

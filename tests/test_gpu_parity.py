@@ -1208,10 +1208,11 @@ REORDER_CASES = [
 
 
 @pytest.mark.parametrize("lens,perm,kernel,xy", REORDER_CASES)
-@pytest.mark.parametrize("type_name,default", [("float32", 0.0), ("float32", float("nan")), ("int32", 0.0), ("uint32", float("nan")), ("float64", float("nan"))])
+@pytest.mark.parametrize("type_name,default", [("float32", 0.0), ("float32", float("nan")), ("int32", 0.0), ("uint32", float("nan")), ("float64", float("nan")),
+                                               ("float64", 0.0)])
 def test_reorder_forms(lens, perm, kernel, xy, type_name, default):
-    """reorder (in-memory.js:178-211) against numpy's transpose: the two-axis LDS transpose (4-byte cells without a
-    mask), the 16-byte brick form, the scalar (ragged) brick form and the gather form, with and without the mask."""
+    """reorder (in-memory.js:178-211) against numpy's transpose: the two-axis LDS transpose (4- and 8-byte cells without
+    a mask), the 16-byte brick form, the scalar (ragged) brick form and the gather form, with and without the mask."""
     rng = np.random.default_rng(29)
     n = int(np.prod(lens))
     vals = rng.integers(1, 1000, size=n).astype(np.float64)
@@ -1219,12 +1220,12 @@ def test_reorder_forms(lens, perm, kernel, xy, type_name, default):
     dense = np.where(unset, default, vals)
     plan = pkg.Plan.reorder(type_name, default, lens, perm)
     four_bytes = type_name != "float64"
-    if four_bytes and xy is not None:
+    if xy is not None:
         assert (plan.kernel_name == "transpose_xy_kernel") == xy, plan.kernel_name
-    if kernel is not None and not (four_bytes and xy) and (four_bytes or "brick4" not in kernel):
+    if kernel is not None and not xy and (four_bytes or "brick4" not in kernel):
         assert plan.kernel_name == kernel, plan.kernel_name
     if not four_bytes:
-        assert plan.kernel_name not in ("reorder_brick4_kernel", "transpose_xy_kernel")
+        assert plan.kernel_name != "reorder_brick4_kernel"
     g = pkg.HipStore(n, type_name, default)
     g.set_data_f64(dense)
     out = g.reorder(lens, perm)
