@@ -258,9 +258,11 @@ class HipStore {
 
   set data(values) {
     if (this._size !== values.length) throw new Error(`value length is invalid: ${this._size} !== ${values.length}`);
-    if (ArrayBuffer.isView(values) && !(values instanceof Float64Array) && values.constructor === TYPED_ARRAY[this._cells] &&
+    const widened = this._cells === 'float64' && (values instanceof Int32Array || values instanceof Uint32Array || values instanceof Float32Array);
+    if (ArrayBuffer.isView(values) && !(values instanceof Float64Array) && (values.constructor === TYPED_ARRAY[this._cells] || widened) &&
         !this._native.isSharded) {
-      this._writable.setData(values); // a typed array of the store's own element type: no conversion
+      // a typed array of the store's own element type: no conversion; a narrower one into Float64 cells: widened by the addon
+      this._writable.setData(values);
       return;
     }
     const d = this._defaultValue;

@@ -227,7 +227,15 @@ static napi_value StoreSetData(napi_env env, napi_callback_info info) {
   int rc;
   if (type == napi_float64_array && olap_store_dtype(s) != OLAP_FLOAT64) rc = olap_store_set_data_f64(s, (const double *)data, len);
   else if (type == ta_of(olap_store_dtype(s))) rc = olap_store_set_data(s, data, len);
-  else {
+  else if (olap_store_dtype(s) == OLAP_FLOAT64 && (type == napi_int32_array || type == napi_uint32_array || type == napi_float32_array)) {
+    // an integer (or Float32) typed array into Float64 cells — what the Node host keeps integer measures in: widened
+    // here, in one pass, instead of element by element in JavaScript
+    std::vector<double> wide(len);
+    if (type == napi_int32_array) for (size_t i = 0; i < len; ++i) wide[i] = (double)((const int32_t *)data)[i];
+    else if (type == napi_uint32_array) for (size_t i = 0; i < len; ++i) wide[i] = (double)((const uint32_t *)data)[i];
+    else for (size_t i = 0; i < len; ++i) wide[i] = (double)((const float *)data)[i];
+    rc = olap_store_set_data(s, wide.data(), len);
+  } else {
     napi_throw_type_error(env, nullptr, "setData: typed array does not match the store's element type");
     return nullptr;
   }

@@ -822,6 +822,19 @@ describe('integer measures hold the reference Map\'s float64 numbers (in-memory.
     b.load(a, [dim], [dim]);
     assert.deepEqual(b.data, [1.5, 0, -2.5]);
   });
+  it('typed arrays narrower than the Float64 cells are widened by the addon (data = Int32Array / Uint32Array / Float32Array)', () => {
+    const i32 = new HipStore(5, 'int32', 0);
+    i32.data = Int32Array.of(-3, 0, 7, 2147483647, -2147483648);
+    assert.deepEqual(i32.data, [-3, 0, 7, 2147483647, -2147483648]);
+    assert.deepEqual(Array.from(i32._dataMap.keys()), [0, 2, 3, 4]);
+    const u32 = new HipStore(3, 'uint32', Number.NaN);
+    u32.data = Uint32Array.of(0, 4294967295, 5);
+    assert.deepEqual(u32.data, [0, 4294967295, 5]);
+    const f64 = new HipStore(3, 'float64', 0);
+    f64.data = Float32Array.of(0.5, Number.NaN, 0);
+    assert.deepEqual(f64.data, [0.5, Number.NaN, 0]);
+    assert.deepEqual(Array.from(f64._dataMap.keys()), [0, 1]);
+  });
   it('backend.setCompactIntegers(true): 4-byte typed cells, values coerced after every operation', () => {
     backend.setCompactIntegers(true);
     try {
