@@ -621,6 +621,22 @@ def main():
                 except Exception as err:  # a capture problem must not cost the headline line
                     res["axis%d" % axis]["graph_error"] = str(err)[:200]
             extra["cache_resident_1e6"] = res
+            # the same headline roll-up over FLOAT64 cells — what Float64 measures are, and what the Node host keeps int32 /
+            # uint32 measures in (the reference's Map holds float64 numbers whatever the declared type): 880 MB per launch
+            try:
+                v64 = engine.empty(n, "float64")
+                capi.check(pkg.lib().olap_fill_seeded(v64.data_ptr(), None, n, 0, 3, 20240807, 1.0, stream))
+                o64 = engine.empty(n_out, "float64")
+                p64 = pkg.Plan.drillup("float64", 0.0, "sum", lens, [1] + lens[1:], maps)
+                us64 = _time(torch, lambda: p64.run(v64.data_ptr(), None, o64.data_ptr(), None, stream), iters=args.steps, warm=5)
+                b64 = (n + n_out) * 8
+                extra["float64_cells"] = {"kernel_ms": us64 * 1e-3, "algorithmic_bytes": b64, "achieved_GBps": b64 / (us64 * 1e-6) / 1e9,
+                                          "frac": b64 / (us64 * 1e-6) / 1e9 / HBM_PEAK_GBS, "cells_per_s": n / (us64 * 1e-6), "kernel": p64.kernel_name,
+                                          "note": "the headline shape with 8-byte cells (Float64 measures; integer measures of the Node host)"}
+                del v64, o64, p64
+                torch.cuda.empty_cache()
+            except Exception as err:  # (must not cost the headline line)
+                extra["float64_cells"] = {"error": str(err)[:200]}
             # several measures of a cube that share a rule: one launch for all (olap_plan_run_batch) against one
             # launch per measure, on the 10^6-cell cube (launch-bound) — what Cube.drillUp does per stored measure
             try:
