@@ -1298,6 +1298,28 @@ __global__ __launch_bounds__(kBlock) void drillup_reduce4_kernel(const T *__rest
   Partial p[V];
 #pragma unroll
   for (int e = 0; e < V; ++e) p[e] = partial_identity<METHOD>();
+  // highest / lowest / first / last: the running pick in the cell's own type (hardware max / min for float cells, selects —
+  // no float64 round trip, no per-cell branch), turned into a Partial once, after the sweep.  A lane meets its cells in
+  // ascending member order, so `first` keeps the first set one it meets and `last` the latest.
+  constexpr bool kPick = IsPick<METHOD>::value && !FAST;
+  Pick<T, METHOD> pk[V];
+  uint32_t ppos[V];
+#pragma unroll
+  for (int e = 0; e < V; ++e) {
+    pk[e].init();
+    ppos[e] = 0u;
+  }
+  // sum / average / product through the exact state machine (a mask, a NaN default, product): the running value, the
+  // key's presence and the contribution count in registers of their own (Agg), packed into a Partial after the sweep
+  constexpr bool kAgg = !IsPick<METHOD>::value && !FAST;
+  Agg<METHOD> ag[V];
+#pragma unroll
+  for (int e = 0; e < V; ++e) ag[e].init();
+  auto pick_cell = [&](int e, bool set, T x, uint32_t pos) {
+    if constexpr (METHOD == OLAP_FIRST) ppos[e] = (set && !pk[e].has) ? pos : ppos[e];
+    if constexpr (METHOD == OLAP_LAST) ppos[e] = set ? pos : ppos[e];
+    pk[e].add_if(set, x);
+  };
   if (active && rd.edge) {
     // inner == 1, the row starts anywhere inside a 16-byte group: sweep the ALIGNED groups that cover
     // [gbeg, gend) of the buffer and let cells outside the row contribute nothing
@@ -1340,15 +1362,23 @@ __global__ __launch_bounds__(kBlock) void drillup_reduce4_kernel(const T *__rest
             p[e].meta += (v != 0.0) ? 1u : 0u;
           } else {
             const int32_t st = HAS_STATUS ? sx[u].v[e] : OLAP_STATUS_SET;
-            if (valid && cell_is_set<T>(x[u].v[e], st, HAS_STATUS, def_nan))
-              partial_add<METHOD>(p[e], Cell<T>::to_f64(x[u].v[e]), (uint32_t)(g4 + e - (int64_t)(o * a.K)), def_nan);
+            const bool set = valid && cell_is_set<T>(x[u].v[e], st, HAS_STATUS, def_nan);
+            if constexpr (kPick) pick_cell(e, set, x[u].v[e], (uint32_t)(g4 + e - (int64_t)(o * a.K)));
+            else if (set) ag[e].add(Cell<T>::to_f64(x[u].v[e]), def_nan);
           }
         }
       }
     }
   } else if (active) {
     constexpr int U = 4;
-    for (uint64_t c = cell_beg + lane * V; c < cell_end; c += (uint64_t)step_cells * U) {
+    // member position of the lane's cells (first / last merge by it): a step is a whole number of rows, so it advances by
+    // rd.rows per step — ONE division per cell of the lane here instead of a 64-bit division per cell of the cube
+    // ([10^8] -> [1] highest / first / last: 150 us, of which the divisions were most)
+    uint32_t pos0[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) pos0[e] = (uint32_t)((cell_beg + lane * V + e) / inner);
+    uint32_t step = 0;
+    for (uint64_t c = cell_beg + lane * V; c < cell_end; c += (uint64_t)step_cells * U, step += U) {
       Vec<T, V> x[U];
       Vec<int32_t, V> sx[U];
       uint64_t cc[U];
@@ -1370,11 +1400,27 @@ __global__ __launch_bounds__(kBlock) void drillup_reduce4_kernel(const T *__rest
             p[e].meta += (v != 0.0) ? 1u : 0u;
           } else {
             const int32_t st = HAS_STATUS ? sx[u].v[e] : OLAP_STATUS_SET;
-            if (in_range && cell_is_set<T>(x[u].v[e], st, HAS_STATUS, def_nan))
-              partial_add<METHOD>(p[e], Cell<T>::to_f64(x[u].v[e]), (uint32_t)((cc[u] + e) / inner), def_nan);
+            const bool set = in_range && cell_is_set<T>(x[u].v[e], st, HAS_STATUS, def_nan);
+            if constexpr (kPick) pick_cell(e, set, x[u].v[e], pos0[e] + (step + (uint32_t)u) * rd.rows);
+            else if (set) ag[e].add(Cell<T>::to_f64(x[u].v[e]), def_nan);
           }
         }
       }
+    }
+  }
+  if constexpr (kPick) {
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+      p[e].acc = pk[e].has ? Cell<T>::to_f64(pk[e].value()) : 0.0;
+      p[e].meta = pk[e].has ? 0x80000001u : 0u;
+      p[e].pos = ppos[e];
+    }
+  }
+  if constexpr (kAgg) {
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+      p[e].acc = ag[e].has ? ag[e].acc : 0.0;
+      p[e].meta = (ag[e].has ? 0x80000000u : 0u) | (ag[e].count & 0x7FFFFFFFu);
     }
   }
   // When rows line up with lanes (inner a multiple of V, or a divisor of it: 1 / 2) the rows of a step are merged
