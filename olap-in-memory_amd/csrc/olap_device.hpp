@@ -297,6 +297,30 @@ struct Pick {
     if constexpr (kHw) return nan ? (T)__builtin_nan("") : cur;
     else return cur;
   }
+  // folds in the pick of ANOTHER lane over members that come AFTER this lane's (highest / lowest: order-free; first keeps
+  // its own when it has one, last takes the other's when that has one)
+  __device__ __forceinline__ void merge(const Pick &q) {
+    if constexpr (kHw) {
+      cur = METHOD == OLAP_HIGHEST ? hw_max(cur, q.cur) : hw_min(cur, q.cur);  // (the identity on a side without members)
+      nan = nan || q.nan;
+    } else {
+      T both;
+      if constexpr (METHOD == OLAP_HIGHEST) both = select_max<T>(cur, q.cur);
+      else if constexpr (METHOD == OLAP_LOWEST) both = select_min<T>(cur, q.cur);
+      else if constexpr (METHOD == OLAP_LAST) both = q.cur;
+      else both = cur;
+      cur = has ? (q.has ? both : cur) : q.cur;
+    }
+    has = has || q.has;
+  }
+  // this lane's pick as held `delta` lanes further on (wave shuffle)
+  __device__ __forceinline__ Pick shfl_down(uint32_t delta) const {
+    Pick q;
+    q.cur = __shfl_down(cur, delta, 64);
+    q.has = __shfl_down((int)has, delta, 64) != 0;
+    q.nan = __shfl_down((int)nan, delta, 64) != 0;
+    return q;
+  }
 };
 
 template <int METHOD> struct IsPick { static constexpr bool value = (METHOD == OLAP_HIGHEST || METHOD == OLAP_LOWEST || METHOD == OLAP_FIRST || METHOD == OLAP_LAST); };

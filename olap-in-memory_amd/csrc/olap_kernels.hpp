@@ -606,6 +606,134 @@ __device__ __forceinline__ void g_probe3(uint32_t) {}
 
 constexpr uint32_t kTileBytes = 16 * 1024;  // cells staged per workgroup: 8 workgroups (32 waves) per CU
 
+// Reduce regime (few output cells, long groups — [10^6,100] -> [1,100], [27400,3652] -> [27400,1],
+// [10^8] -> [1]): the natural one-lane-per-output mappings above would leave the chip idle, so the
+// member list of every group is cut into S segments and reduced cooperatively; partial states are
+// merged afterwards.  Sums are float64 but RE-ASSOCIATED here (tree order instead of the
+// reference's sequential order: ~1e-16 relative before the final rounding); highest / lowest are
+// order-free; first / last carry the member position and merge by it, so they stay exact.
+struct Partial {
+  double acc;
+  uint32_t meta;  // bit 31: set, bits 0..30: contributions
+  uint32_t pos;   // member position (first / last)
+};
+
+template <int METHOD>
+__device__ __forceinline__ Partial partial_identity() {
+  Partial p;
+  p.acc = 0.0;
+  p.meta = 0;
+  p.pos = 0;
+  return p;
+}
+
+template <int METHOD>
+__device__ __forceinline__ void partial_add(Partial &p, double v, uint32_t pos, bool def_nan) {
+  const uint32_t cnt = (p.meta & 0x7FFFFFFFu) + 1;
+  bool has = (p.meta & 0x80000000u) != 0;
+  if (!has) {
+    p.acc = v;
+    p.pos = pos;
+    has = true;
+  } else {
+    if constexpr (METHOD == OLAP_SUM || METHOD == OLAP_AVERAGE || METHOD == OLAP_PARTIAL_AVERAGE) p.acc += v;
+    else if constexpr (METHOD == OLAP_PRODUCT) p.acc *= v;
+    else if constexpr (METHOD == OLAP_HIGHEST) p.acc = js_max(p.acc, v);
+    else if constexpr (METHOD == OLAP_LOWEST) p.acc = js_min(p.acc, v);
+    else if constexpr (METHOD == OLAP_FIRST) { if (pos < p.pos) { p.acc = v; p.pos = pos; } }
+    else { if (pos >= p.pos) { p.acc = v; p.pos = pos; } }
+    if constexpr (METHOD == OLAP_SUM || METHOD == OLAP_AVERAGE || METHOD == OLAP_PARTIAL_AVERAGE || METHOD == OLAP_PRODUCT)
+      if (is_default_f64(p.acc, def_nan)) has = false;  // the key is dropped (in-memory.js:126-131)
+  }
+  p.meta = (has ? 0x80000000u : 0u) | (cnt & 0x7FFFFFFFu);
+}
+
+template <int METHOD>
+__device__ __forceinline__ void partial_merge(Partial &a, const Partial &b, bool def_nan) {
+  const uint32_t cnt = (a.meta & 0x7FFFFFFFu) + (b.meta & 0x7FFFFFFFu);
+  const bool ha = (a.meta & 0x80000000u) != 0, hb = (b.meta & 0x80000000u) != 0;
+  bool has = ha || hb;
+  if (ha && hb) {
+    if constexpr (METHOD == OLAP_SUM || METHOD == OLAP_AVERAGE || METHOD == OLAP_PARTIAL_AVERAGE) a.acc += b.acc;
+    else if constexpr (METHOD == OLAP_PRODUCT) a.acc *= b.acc;
+    else if constexpr (METHOD == OLAP_HIGHEST) a.acc = js_max(a.acc, b.acc);
+    else if constexpr (METHOD == OLAP_LOWEST) a.acc = js_min(a.acc, b.acc);
+    else if constexpr (METHOD == OLAP_FIRST) { if (b.pos < a.pos) { a.acc = b.acc; a.pos = b.pos; } }
+    else { if (b.pos >= a.pos) { a.acc = b.acc; a.pos = b.pos; } }
+    if constexpr (METHOD == OLAP_SUM || METHOD == OLAP_AVERAGE || METHOD == OLAP_PARTIAL_AVERAGE || METHOD == OLAP_PRODUCT)
+      if (is_default_f64(a.acc, def_nan)) has = false;
+  } else if (hb) {
+    a.acc = b.acc;
+    a.pos = b.pos;
+  }
+  a.meta = (has ? 0x80000000u : 0u) | (cnt & 0x7FFFFFFFu);
+}
+
+struct DrillUpReduce {
+  uint32_t S;         // segments per group
+  uint32_t seg_len;   // members per segment
+  uint32_t rows;      // member rows a unit reads per step: power of two, rows * inner <= unit
+  uint32_t unit;      // lanes cooperating on one (outer, group, segment): 64 (a wavefront) or 256
+  uint32_t vec4;      // 1: the 16 B form (drillup_reduce4_kernel) applies; `rows` is then sized for unit*4 cells
+  uint32_t edge;      // 16 B form with inner == 1 and rows at ANY cell offset (K % 4 != 0): aligned groups, masked ends
+  Partial *part;      // [outer*G*inner * S]
+};
+
+// Partial state -> output cell (what drillup_merge_kernel does after merging the segments).
+template <typename T, int METHOD>
+__device__ __forceinline__ void partial_finish(const Partial &p, bool def_nan, typename OutCell<T, METHOD>::type &ov, int32_t &os) {
+  Agg<METHOD> agg;
+  agg.acc = p.acc;
+  agg.has = (p.meta & 0x80000000u) != 0;
+  agg.count = p.meta & 0x7FFFFFFFu;
+  agg.finish(def_nan);
+  emit_out<T, METHOD>(agg.acc, agg.has, agg.count, def_nan, ov, os);
+}
+
+// Lane-to-lane merge step of the reduce regime.  FAST (sum / average over a 0 default, no mask): the
+// state is (running sum, count of non-zero contributions) and merging is two adds — the `set` bit
+// is derived once at the end (partial_seal).  A wave64 VALU instruction costs 4 cycles and a unit
+// runs 6-8 of these levels per element, so the generic partial_merge (~40 instructions) is kept
+// for the methods that need it.
+template <int METHOD, bool FAST>
+__device__ __forceinline__ void partial_merge_lane(Partial &a, uint32_t delta, bool def_nan) {
+  Partial q;
+  q.acc = __shfl_down(a.acc, delta, 64);
+  q.meta = __shfl_down(a.meta, delta, 64);
+  if constexpr (METHOD == OLAP_FIRST || METHOD == OLAP_LAST) q.pos = __shfl_down(a.pos, delta, 64);
+  else q.pos = 0;
+  if constexpr (FAST) {
+    a.acc += q.acc;
+    a.meta += q.meta;
+  } else {
+    partial_merge<METHOD>(a, q, def_nan);
+  }
+}
+
+template <int METHOD, bool FAST>
+__device__ __forceinline__ void partial_merge_fast(Partial &a, const Partial &q, bool def_nan) {
+  if constexpr (FAST) {
+    a.acc += q.acc;
+    a.meta += q.meta;
+  } else {
+    partial_merge<METHOD>(a, q, def_nan);
+  }
+}
+
+// FAST accumulators count contributions without the `set` bit; this adds it.
+__device__ __forceinline__ void partial_seal(Partial &p) {
+  p.meta = (p.meta & 0x7FFFFFFFu) | ((p.meta != 0 && p.acc != 0.0) ? 0x80000000u : 0u);
+}
+
+__device__ __forceinline__ Partial partial_shfl_down(const Partial &p, uint32_t delta) {
+  Partial q;
+  q.acc = __shfl_down(p.acc, delta, 64);
+  q.meta = __shfl_down(p.meta, delta, 64);
+  q.pos = __shfl_down(p.pos, delta, 64);
+  return q;
+}
+
+
 // (Measured and dropped twice: a PERSISTENT form — one workgroup per resident slot of the chip walking a contiguous run
 // of tiles, the next tile's cells requested into registers before the current tile is reduced, tables to LDS once per
 // workgroup: [10]^8 axes 5-7 70 -> 84 us, [27400,3652] day -> month 61 -> 75 us.)
@@ -771,6 +899,69 @@ __device__ __forceinline__ void drillup_tile_body(const T *__restrict__ in, cons
       return;
     }
   }
+  if constexpr (ALL && !FAST && METHOD != OLAP_FIRST && METHOD != OLAP_LAST) {
+    // the same sharing of a long row by 16 lanes for highest / lowest / product (and for masked / NaN-default sums): each
+    // lane folds its contiguous part of the row into a Partial (value, set bit, contribution count) and the parts are
+    // merged lane to lane — a lane per row left 15 of 256 lanes walking 271 members each ([3653,101,271] product -> all:
+    // `highest` 232 -> 95 us, `product` 481 -> 90 us, against 59 us for `sum`).  first / last keep the lane per row: it
+    // stops at the first / last set member, one LDS read on a dense cube.
+    if (tl.inner == 1 && a.K >= 256) {
+      constexpr uint32_t L = 16;
+      for (uint32_t slot = tid; slot < rows * L; slot += kBlock) {
+        const uint32_t r = slot / L, part = slot % L;
+        const uint32_t kb = (uint32_t)((uint64_t)a.K * part / L), ke = (uint32_t)((uint64_t)a.K * (part + 1) / L);
+        const T *cells = tile + r * tl.row_elems;
+        if constexpr (METHOD == OLAP_HIGHEST || METHOD == OLAP_LOWEST) {
+          // the running extreme in the cell's own type (hardware max / min for float cells), merged lane to lane
+          Pick<T, METHOD> pk;
+          pk.init();
+          uint32_t k = kb;
+          for (; k + 4 <= ke; k += 4) {  // four LDS reads in flight, then the four folds
+            T x[4];
+            int32_t sx[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              x[u] = cells[k + u];
+              sx[u] = HAS_STATUS ? stile[r * tl.row_elems + k + u] : OLAP_STATUS_SET;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) pk.add_if(cell_is_set<T>(x[u], sx[u], HAS_STATUS, def_nan), x[u]);
+          }
+          for (; k < ke; ++k) {
+            const T x = cells[k];
+            const int32_t sx = HAS_STATUS ? stile[r * tl.row_elems + k] : OLAP_STATUS_SET;
+            pk.add_if(cell_is_set<T>(x, sx, HAS_STATUS, def_nan), x);
+          }
+#pragma unroll
+          for (uint32_t d = L / 2; d > 0; d >>= 1) pk.merge(pk.shfl_down(d));  // (lanes past a row's 16 read a neighbour's state, which nobody consumes)
+          if (part == 0) {
+            dst[r] = pk.has ? pk.value() : Cell<T>::default_value(def_nan);
+            if (sdst) sdst[r] = pk.has ? OLAP_STATUS_SET : 0;
+          }
+        } else {
+          Partial p = partial_identity<METHOD>();
+          for (uint32_t k = kb; k < ke; ++k) {
+            const T x = cells[k];
+            const int32_t sx = HAS_STATUS ? stile[r * tl.row_elems + k] : OLAP_STATUS_SET;
+            if (cell_is_set<T>(x, sx, HAS_STATUS, def_nan)) partial_add<METHOD>(p, Cell<T>::to_f64(x), k, def_nan);
+          }
+#pragma unroll
+          for (uint32_t d = L / 2; d > 0; d >>= 1) {
+            const Partial q = partial_shfl_down(p, d);  // (lanes past a row's 16 read a neighbour's state, which nobody consumes)
+            partial_merge<METHOD>(p, q, def_nan);
+          }
+          if (part == 0) {
+            O ov;
+            int32_t os;
+            partial_finish<T, METHOD>(p, def_nan, ov, os);
+            dst[r] = ov;
+            if (sdst) sdst[r] = os;
+          }
+        }
+      }
+      return;
+    }
+  }
   for (uint32_t idx = tid; idx < n_out; idx += kBlock) {
     const uint32_t r = idx / tl.out_row;
     const uint32_t rem = idx - r * tl.out_row;
@@ -868,133 +1059,6 @@ __global__ __launch_bounds__(kBlock) void drillup_tile_mixed_kernel(const Batch<
 }
 
 
-// Reduce regime (few output cells, long groups — [10^6,100] -> [1,100], [27400,3652] -> [27400,1],
-// [10^8] -> [1]): the natural one-lane-per-output mappings above would leave the chip idle, so the
-// member list of every group is cut into S segments and reduced cooperatively; partial states are
-// merged afterwards.  Sums are float64 but RE-ASSOCIATED here (tree order instead of the
-// reference's sequential order: ~1e-16 relative before the final rounding); highest / lowest are
-// order-free; first / last carry the member position and merge by it, so they stay exact.
-struct Partial {
-  double acc;
-  uint32_t meta;  // bit 31: set, bits 0..30: contributions
-  uint32_t pos;   // member position (first / last)
-};
-
-template <int METHOD>
-__device__ __forceinline__ Partial partial_identity() {
-  Partial p;
-  p.acc = 0.0;
-  p.meta = 0;
-  p.pos = 0;
-  return p;
-}
-
-template <int METHOD>
-__device__ __forceinline__ void partial_add(Partial &p, double v, uint32_t pos, bool def_nan) {
-  const uint32_t cnt = (p.meta & 0x7FFFFFFFu) + 1;
-  bool has = (p.meta & 0x80000000u) != 0;
-  if (!has) {
-    p.acc = v;
-    p.pos = pos;
-    has = true;
-  } else {
-    if constexpr (METHOD == OLAP_SUM || METHOD == OLAP_AVERAGE || METHOD == OLAP_PARTIAL_AVERAGE) p.acc += v;
-    else if constexpr (METHOD == OLAP_PRODUCT) p.acc *= v;
-    else if constexpr (METHOD == OLAP_HIGHEST) p.acc = js_max(p.acc, v);
-    else if constexpr (METHOD == OLAP_LOWEST) p.acc = js_min(p.acc, v);
-    else if constexpr (METHOD == OLAP_FIRST) { if (pos < p.pos) { p.acc = v; p.pos = pos; } }
-    else { if (pos >= p.pos) { p.acc = v; p.pos = pos; } }
-    if constexpr (METHOD == OLAP_SUM || METHOD == OLAP_AVERAGE || METHOD == OLAP_PARTIAL_AVERAGE || METHOD == OLAP_PRODUCT)
-      if (is_default_f64(p.acc, def_nan)) has = false;  // the key is dropped (in-memory.js:126-131)
-  }
-  p.meta = (has ? 0x80000000u : 0u) | (cnt & 0x7FFFFFFFu);
-}
-
-template <int METHOD>
-__device__ __forceinline__ void partial_merge(Partial &a, const Partial &b, bool def_nan) {
-  const uint32_t cnt = (a.meta & 0x7FFFFFFFu) + (b.meta & 0x7FFFFFFFu);
-  const bool ha = (a.meta & 0x80000000u) != 0, hb = (b.meta & 0x80000000u) != 0;
-  bool has = ha || hb;
-  if (ha && hb) {
-    if constexpr (METHOD == OLAP_SUM || METHOD == OLAP_AVERAGE || METHOD == OLAP_PARTIAL_AVERAGE) a.acc += b.acc;
-    else if constexpr (METHOD == OLAP_PRODUCT) a.acc *= b.acc;
-    else if constexpr (METHOD == OLAP_HIGHEST) a.acc = js_max(a.acc, b.acc);
-    else if constexpr (METHOD == OLAP_LOWEST) a.acc = js_min(a.acc, b.acc);
-    else if constexpr (METHOD == OLAP_FIRST) { if (b.pos < a.pos) { a.acc = b.acc; a.pos = b.pos; } }
-    else { if (b.pos >= a.pos) { a.acc = b.acc; a.pos = b.pos; } }
-    if constexpr (METHOD == OLAP_SUM || METHOD == OLAP_AVERAGE || METHOD == OLAP_PARTIAL_AVERAGE || METHOD == OLAP_PRODUCT)
-      if (is_default_f64(a.acc, def_nan)) has = false;
-  } else if (hb) {
-    a.acc = b.acc;
-    a.pos = b.pos;
-  }
-  a.meta = (has ? 0x80000000u : 0u) | (cnt & 0x7FFFFFFFu);
-}
-
-struct DrillUpReduce {
-  uint32_t S;         // segments per group
-  uint32_t seg_len;   // members per segment
-  uint32_t rows;      // member rows a unit reads per step: power of two, rows * inner <= unit
-  uint32_t unit;      // lanes cooperating on one (outer, group, segment): 64 (a wavefront) or 256
-  uint32_t vec4;      // 1: the 16 B form (drillup_reduce4_kernel) applies; `rows` is then sized for unit*4 cells
-  uint32_t edge;      // 16 B form with inner == 1 and rows at ANY cell offset (K % 4 != 0): aligned groups, masked ends
-  Partial *part;      // [outer*G*inner * S]
-};
-
-// Partial state -> output cell (what drillup_merge_kernel does after merging the segments).
-template <typename T, int METHOD>
-__device__ __forceinline__ void partial_finish(const Partial &p, bool def_nan, typename OutCell<T, METHOD>::type &ov, int32_t &os) {
-  Agg<METHOD> agg;
-  agg.acc = p.acc;
-  agg.has = (p.meta & 0x80000000u) != 0;
-  agg.count = p.meta & 0x7FFFFFFFu;
-  agg.finish(def_nan);
-  emit_out<T, METHOD>(agg.acc, agg.has, agg.count, def_nan, ov, os);
-}
-
-// Lane-to-lane merge step of the reduce regime.  FAST (sum / average over a 0 default, no mask): the
-// state is (running sum, count of non-zero contributions) and merging is two adds — the `set` bit
-// is derived once at the end (partial_seal).  A wave64 VALU instruction costs 4 cycles and a unit
-// runs 6-8 of these levels per element, so the generic partial_merge (~40 instructions) is kept
-// for the methods that need it.
-template <int METHOD, bool FAST>
-__device__ __forceinline__ void partial_merge_lane(Partial &a, uint32_t delta, bool def_nan) {
-  Partial q;
-  q.acc = __shfl_down(a.acc, delta, 64);
-  q.meta = __shfl_down(a.meta, delta, 64);
-  if constexpr (METHOD == OLAP_FIRST || METHOD == OLAP_LAST) q.pos = __shfl_down(a.pos, delta, 64);
-  else q.pos = 0;
-  if constexpr (FAST) {
-    a.acc += q.acc;
-    a.meta += q.meta;
-  } else {
-    partial_merge<METHOD>(a, q, def_nan);
-  }
-}
-
-template <int METHOD, bool FAST>
-__device__ __forceinline__ void partial_merge_fast(Partial &a, const Partial &q, bool def_nan) {
-  if constexpr (FAST) {
-    a.acc += q.acc;
-    a.meta += q.meta;
-  } else {
-    partial_merge<METHOD>(a, q, def_nan);
-  }
-}
-
-// FAST accumulators count contributions without the `set` bit; this adds it.
-__device__ __forceinline__ void partial_seal(Partial &p) {
-  p.meta = (p.meta & 0x7FFFFFFFu) | ((p.meta != 0 && p.acc != 0.0) ? 0x80000000u : 0u);
-}
-
-__device__ __forceinline__ Partial partial_shfl_down(const Partial &p, uint32_t delta) {
-  Partial q;
-  q.acc = __shfl_down(p.acc, delta, 64);
-  q.meta = __shfl_down(p.meta, delta, 64);
-  q.pos = __shfl_down(p.pos, delta, 64);
-  return q;
-}
-
 constexpr uint32_t kTotalBlocks = 4096;  // workgroups (and partial slots) of the store total
 constexpr uint32_t kGroupTileMaxGroups = 1024;  // groups per tile of the group-tile regime (LDS holds their bounds)
 
@@ -1079,6 +1143,34 @@ __global__ __launch_bounds__(kBlock) void drillup_gtile_kernel(const Batch<T> b,
       const uint32_t j0 = l_gstart[g], len = l_gstart[g + 1] - j0;
       uint32_t k = live ? j0 + (uint32_t)((uint64_t)len * part / L) : 0u;
       const uint32_t ke = live ? j0 + (uint32_t)((uint64_t)len * (part + 1) / L) : 0u;
+      if constexpr (METHOD == OLAP_HIGHEST || METHOD == OLAP_LOWEST) {
+        // the running extreme in the cell's own type (hardware max / min for float cells), merged lane to lane
+        Pick<T, METHOD> pk;
+        pk.init();
+        for (; k + 4 <= ke; k += 4) {  // four LDS reads in flight, then the four folds
+          T x[4];
+          int32_t sx[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            x[u] = tile[shift + i + (k + u) * inner];
+            sx[u] = HAS_STATUS ? stile[shift + i + (k + u) * inner] : OLAP_STATUS_SET;
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) pk.add_if(cell_is_set<T>(x[u], sx[u], HAS_STATUS, def_nan), x[u]);
+        }
+        for (; k < ke; ++k) {
+          const T x = tile[shift + i + k * inner];
+          const int32_t sx = HAS_STATUS ? stile[shift + i + k * inner] : OLAP_STATUS_SET;
+          pk.add_if(cell_is_set<T>(x, sx, HAS_STATUS, def_nan), x);
+        }
+        for (uint32_t d = L / 2; d > 0; d >>= 1) pk.merge(pk.shfl_down(d));
+        if (live && part == 0) {
+          const uint64_t at = (o * a.G + g0) * a.inner + cell;
+          out[at] = pk.has ? pk.value() : Cell<T>::default_value(def_nan);
+          if (st_out) st_out[at] = pk.has ? OLAP_STATUS_SET : 0;
+        }
+        return;
+      }
       Partial p = partial_identity<METHOD>();
       for (; k < ke; ++k) {
         const T x = tile[shift + i + k * inner];

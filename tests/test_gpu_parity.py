@@ -671,6 +671,42 @@ def test_flat_regime_interleaved_groups(lens, kind, method, type_name, default, 
     assert same_typed(out.get_data(), ev)
 
 
+@pytest.mark.parametrize("lens", [[37, 5, 300], [9, 271], [3, 4, 1000]])
+@pytest.mark.parametrize("method", ["sum", "average", "highest", "lowest", "first", "last", "product"])
+@pytest.mark.parametrize("type_name,default", [("float32", 0.0), ("float32", float("nan")), ("float64", 0.0), ("int32", 0.0), ("uint32", float("nan"))])
+def test_tile_regime_long_rows_every_rule(lens, method, type_name, default, monkeypatch):
+    """The LAST dimension (256 - 4 096 items) rolled up to 'all' with more rows than the few-outputs regime takes: a tile
+    holds a dozen rows, 16 lanes share each — plain float64 sums for sum / average over a 0 default, the Partial state
+    machine merged lane to lane for every other rule, the mask and the NaN default."""
+    monkeypatch.setenv("OLAP_REDUCE_MAX_CELLS", "0")
+    rng = np.random.default_rng(len(lens) * 100 + lens[-1])
+    n = int(np.prod(lens))
+    if method == "product":
+        vals = np.where(rng.random(n) < 0.5, 1.0, -1.0) if type_name not in ("uint32",) else np.ones(n)
+        vals = vals * np.where(rng.random(n) < 0.02, 2.0, 1.0)
+    else:
+        vals = rng.integers(0 if type_name == "uint32" else -9, 10, size=n).astype(np.float64)
+        if type_name.startswith("float"):
+            vals = vals * 0.5
+    dense = np.where(rng.random(n) < 0.5, default, vals)
+    dense.reshape(-1, lens[-1])[0, :] = default  # a row nobody set
+    new = lens[:-1] + [1]
+    maps = [np.arange(l, dtype=np.uint32) for l in lens[:-1]] + [np.zeros(lens[-1], np.uint32)]
+    plan = pkg.Plan.drillup(type_name, default, method, lens, new, maps)
+    assert plan.kernel_name == "drillup_tile_kernel", plan.kernel_name
+    o = OracleStore(n, type_name, default)
+    typed = to_typed(dense, type_name).astype(np.float64)
+    if type_name in ("int32", "uint32") and default != default:
+        typed = np.where(np.isnan(dense), np.nan, typed)
+    o.set_data(typed)
+    ev, es = expected_typed(o.drill_up(lens, new, maps, method))
+    g = pkg.HipStore(n, type_name, default)
+    g.set_data_f64(dense)
+    out = g.drill_up(lens, new, maps, method)
+    assert np.array_equal(out.get_status(), es)
+    assert same_typed(out.get_data(), ev)  # (half-integers: the re-associated float64 sums are exact)
+
+
 def _boundary_cases():
     """Seeded sample of one-axis drillUps whose extents sit on the boundaries between the kernel
     regimes (vector width, 128 vector slots, the 16 KiB tile, 256-member groups, 131 072 outputs)."""
