@@ -962,6 +962,40 @@ __device__ __forceinline__ void drillup_tile_body(const T *__restrict__ in, cons
       return;
     }
   }
+  if constexpr (METHOD == OLAP_HIGHEST || METHOD == OLAP_LOWEST) {
+    // few output cells per tile and long groups (ten groups of a hundred members per row, four rows per tile): L lanes
+    // share an output cell, each takes a contiguous L-th of the group's members as a typed pick, merged lane to lane —
+    // order-free, so exact whatever the group size ([1e5,1000] -> 10 interleaved groups, highest: 91 us against 62 for sum)
+    if (n_out * 2 <= kBlock && a.K >= 16 * a.G) {
+      uint32_t L = 2;
+      while (L < 64 && L * 2 * n_out <= kBlock) L *= 2;
+      const uint32_t cell = tid / L, part = tid % L;
+      const bool live = cell < n_out;
+      const uint32_t r = live ? cell / tl.out_row : 0u;
+      const uint32_t rem = live ? cell - r * tl.out_row : 0u;
+      const uint32_t g = rem / tl.inner, i = rem - g * tl.inner;
+      const uint32_t base = (PERMUTE ? r * tl.pitch_cells : r * tl.row_elems) + i;
+      const uint32_t jb = ALL ? 0u : PERMUTE ? l_gstart[2 * g] : l_gstart[g];
+      const uint32_t je = ALL ? (uint32_t)a.K : PERMUTE ? l_gstart[2 * g + 1] : l_gstart[g + 1];
+      const uint32_t len = je - jb;
+      uint32_t j = live ? jb + (uint32_t)((uint64_t)len * part / L) : 0u;
+      const uint32_t jend = live ? jb + (uint32_t)((uint64_t)len * (part + 1) / L) : 0u;
+      Pick<T, METHOD> pk;
+      pk.init();
+      for (; j < jend; ++j) {
+        const uint32_t k = MODE == 0 ? l_order[j] : j;
+        const T x = tile[base + k * tl.inner];
+        const int32_t sx = HAS_STATUS ? stile[base + k * tl.inner] : OLAP_STATUS_SET;
+        pk.add_if(cell_is_set<T>(x, sx, HAS_STATUS, def_nan), x);
+      }
+      for (uint32_t d = L / 2; d > 0; d >>= 1) pk.merge(pk.shfl_down(d));  // (lanes past a cell's L read a neighbour's state, which nobody consumes)
+      if (live && part == 0) {
+        reinterpret_cast<T *>(dst)[cell] = pk.has ? pk.value() : Cell<T>::default_value(def_nan);
+        if (sdst) sdst[cell] = pk.has ? OLAP_STATUS_SET : 0;
+      }
+      return;
+    }
+  }
   for (uint32_t idx = tid; idx < n_out; idx += kBlock) {
     const uint32_t r = idx / tl.out_row;
     const uint32_t rem = idx - r * tl.out_row;
