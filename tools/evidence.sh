@@ -22,6 +22,8 @@ timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$O/prof_wri
 cd "$R"
 timeout -k 10 300 python tools/sweep.py > "$O/sweep.txt" 2>&1 && tail -3 "$O/sweep.txt"
 timeout -k 10 300 python tools/sweep2.py > "$O/sweep_awkward.txt" 2>&1 && tail -3 "$O/sweep_awkward.txt"
+DTYPE=float64 timeout -k 10 300 python tools/sweep.py 2>&1 | grep -v amdgpu.ids > "$O/sweep_f64.txt" && tail -3 "$O/sweep_f64.txt"
+for d in float32 float64; do DTYPE=$d timeout -k 10 300 python tools/cross_sweep.py 2>&1 | grep -v amdgpu.ids; done > "$O/cross_sweep.txt" && tail -3 "$O/cross_sweep.txt"
 timeout -k 10 200 python tools/dd_bench.py > "$O/dd_bench.txt" 2>&1 && tail -5 "$O/dd_bench.txt"
 timeout -k 10 200 python tools/odd.py 2>&1 | grep -v amdgpu.ids > "$O/odd.txt" && cat "$O/odd.txt"
 timeout -k 10 200 python tools/big.py 2>&1 | grep -v amdgpu.ids > "$O/big.txt" && cat "$O/big.txt"
@@ -32,6 +34,8 @@ timeout -k 10 200 python tools/transpose_probe.py 2>&1 | grep -v amdgpu.ids > "$
 if [ ! -x tools/tile_probe.bin ]; then hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -DOLAP_TILE_PROBE -I include -I olap-in-memory_amd/csrc tools/tile_probe.hip -o tools/tile_probe.bin; fi
 timeout -k 10 120 ./tools/tile_probe.bin > "$O/tile_probe.txt" 2>&1 && tail -4 "$O/tile_probe.txt"
 timeout -k 10 200 python tools/totals_probe.py 2>&1 | grep -v amdgpu.ids > "$O/totals_probe.txt" && tail -5 "$O/totals_probe.txt"
+if [ ! -x tools/headline_limit.bin ]; then hipcc --offload-arch=gfx950 -O3 -std=c++17 -I include -I olap-in-memory_amd/csrc tools/headline_limit.hip -o tools/headline_limit.bin; fi
+timeout -k 10 120 ./tools/headline_limit.bin > "$O/headline_limit.txt" 2>&1 && tail -3 "$O/headline_limit.txt"
 if [ ! -x tools/pattern_ceiling.bin ]; then hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/pattern_ceiling.hip -o tools/pattern_ceiling.bin; fi
 timeout -k 10 300 ./tools/pattern_ceiling.bin > "$O/pattern_ceiling.txt" 2>&1 && tail -3 "$O/pattern_ceiling.txt"
 echo evidence done
