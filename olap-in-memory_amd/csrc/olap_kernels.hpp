@@ -962,40 +962,9 @@ __device__ __forceinline__ void drillup_tile_body(const T *__restrict__ in, cons
       return;
     }
   }
-  if constexpr (METHOD == OLAP_HIGHEST || METHOD == OLAP_LOWEST) {
-    // few output cells per tile and long groups (ten groups of a hundred members per row, four rows per tile): L lanes
-    // share an output cell, each takes a contiguous L-th of the group's members as a typed pick, merged lane to lane —
-    // order-free, so exact whatever the group size ([1e5,1000] -> 10 interleaved groups, highest: 91 us against 62 for sum)
-    if (n_out * 2 <= kBlock && a.K >= 16 * a.G) {
-      uint32_t L = 2;
-      while (L < 64 && L * 2 * n_out <= kBlock) L *= 2;
-      const uint32_t cell = tid / L, part = tid % L;
-      const bool live = cell < n_out;
-      const uint32_t r = live ? cell / tl.out_row : 0u;
-      const uint32_t rem = live ? cell - r * tl.out_row : 0u;
-      const uint32_t g = rem / tl.inner, i = rem - g * tl.inner;
-      const uint32_t base = (PERMUTE ? r * tl.pitch_cells : r * tl.row_elems) + i;
-      const uint32_t jb = ALL ? 0u : PERMUTE ? l_gstart[2 * g] : l_gstart[g];
-      const uint32_t je = ALL ? (uint32_t)a.K : PERMUTE ? l_gstart[2 * g + 1] : l_gstart[g + 1];
-      const uint32_t len = je - jb;
-      uint32_t j = live ? jb + (uint32_t)((uint64_t)len * part / L) : 0u;
-      const uint32_t jend = live ? jb + (uint32_t)((uint64_t)len * (part + 1) / L) : 0u;
-      Pick<T, METHOD> pk;
-      pk.init();
-      for (; j < jend; ++j) {
-        const uint32_t k = MODE == 0 ? l_order[j] : j;
-        const T x = tile[base + k * tl.inner];
-        const int32_t sx = HAS_STATUS ? stile[base + k * tl.inner] : OLAP_STATUS_SET;
-        pk.add_if(cell_is_set<T>(x, sx, HAS_STATUS, def_nan), x);
-      }
-      for (uint32_t d = L / 2; d > 0; d >>= 1) pk.merge(pk.shfl_down(d));  // (lanes past a cell's L read a neighbour's state, which nobody consumes)
-      if (live && part == 0) {
-        reinterpret_cast<T *>(dst)[cell] = pk.has ? pk.value() : Cell<T>::default_value(def_nan);
-        if (sdst) sdst[cell] = pk.has ? OLAP_STATUS_SET : 0;
-      }
-      return;
-    }
-  }
+  // (Measured and dropped: tiles with few output cells over long groups — ten interleaved groups of a hundred members, four
+  // rows per tile — sharing a cell among four lanes for highest / lowest: 90 -> 84 us there, but the mere presence of that
+  // block in the kernel cost the ordinary path 25 % — day -> month with the day innermost, `highest`: 76 -> 96 us.)
   for (uint32_t idx = tid; idx < n_out; idx += kBlock) {
     const uint32_t r = idx / tl.out_row;
     const uint32_t rem = idx - r * tl.out_row;
@@ -1534,7 +1503,57 @@ __global__ __launch_bounds__(kBlock) void drillup_reduce4_kernel(const T *__rest
       }
     }
   }
+  const bool by_shuffle = inner * 2 <= (uint32_t)V || (inner % V == 0 && (rd.rows & (rd.rows - 1)) == 0);
+  bool merged = false;  // the rows of a step are already folded (typed, below)
   if constexpr (kPick) {
+    // A wavefront-sized unit (short segments: the last dimension of [10^5,1000] rolled up) merges its rows by wave
+    // shuffles only — done here on the typed picks (a hardware max, or a compare of member positions, per level) before
+    // they become Partials: the generic Partial merge is ~40 instructions a level, nine levels a segment, more than the
+    // sweep of a 1 000-cell segment itself (highest / first / last 108-117 us against 62 us for sum)
+    if (by_shuffle && rd.unit == 64) {
+      auto fold = [&](Pick<T, METHOD> &x, uint32_t &xpos, const Pick<T, METHOD> &y, uint32_t ypos) {
+        if constexpr (METHOD == OLAP_FIRST || METHOD == OLAP_LAST) {
+          const bool take = y.has && (!x.has || (METHOD == OLAP_FIRST ? ypos < xpos : ypos >= xpos));
+          x.cur = take ? y.cur : x.cur;
+          xpos = take ? ypos : xpos;
+          x.has = x.has || y.has;
+        } else {
+          x.merge(y);
+        }
+      };
+      uint32_t m, top, ne = V;
+      if (inner * 2 <= (uint32_t)V) {
+        if constexpr (V == 4) {
+          if (inner == 1) {
+            fold(pk[0], ppos[0], pk[1], ppos[1]);
+            fold(pk[2], ppos[2], pk[3], ppos[3]);
+            fold(pk[0], ppos[0], pk[2], ppos[2]);
+          } else {
+            fold(pk[0], ppos[0], pk[2], ppos[2]);
+            fold(pk[1], ppos[1], pk[3], ppos[3]);
+          }
+        } else {
+          fold(pk[0], ppos[0], pk[1], ppos[1]);
+        }
+        m = 1;
+        top = rd.unit;
+        ne = inner;
+      } else {
+        m = inner / V;
+        top = rd.rows;
+      }
+      for (uint32_t sft = top >> 1; sft > 0; sft >>= 1) {
+        const uint32_t d = sft * m;  // <= 32: a unit is one wavefront
+#pragma unroll
+        for (int e = 0; e < V; ++e)
+          if ((uint32_t)e < ne) {
+            const Pick<T, METHOD> q = pk[e].shfl_down(d);
+            const uint32_t qpos = __shfl_down(ppos[e], d, 64);
+            fold(pk[e], ppos[e], q, qpos);
+          }
+      }
+      merged = true;
+    }
 #pragma unroll
     for (int e = 0; e < V; ++e) {
       p[e].acc = pk[e].has ? Cell<T>::to_f64(pk[e].value()) : 0.0;
@@ -1556,11 +1575,14 @@ __global__ __launch_bounds__(kBlock) void drillup_reduce4_kernel(const T *__rest
   // Idle lanes hold the identity.  With one segment per group the result is final and leaves from here.
   // (rows per step need not be a power of two — 10 rows of 100 cells fill 250 of a unit's 256 lanes where 8 fill 200 —
   // but the lane-to-lane merge needs one: other row counts take the LDS tree below)
-  const bool by_shuffle = inner * 2 <= (uint32_t)V || (inner % V == 0 && (rd.rows & (rd.rows - 1)) == 0);
   if (by_shuffle) {
     uint32_t m, top;  // lanes per row, rows spread over the unit's lanes
     uint32_t ne = V;  // accumulators per lane still in play
-    if (inner * 2 <= (uint32_t)V) {  // a lane's 16 bytes hold several rows: fold them first
+    if (merged) {
+      m = 1;
+      top = 1;  // nothing left to fold
+      ne = inner * 2 <= (uint32_t)V ? inner : (uint32_t)V;
+    } else if (inner * 2 <= (uint32_t)V) {  // a lane's 16 bytes hold several rows: fold them first
       if constexpr (V == 4) {
         if (inner == 1) {
           partial_merge_fast<METHOD, FAST>(p[0], p[1], def_nan);
