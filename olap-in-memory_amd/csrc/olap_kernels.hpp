@@ -987,6 +987,30 @@ __device__ __forceinline__ void drillup_tile_body(const T *__restrict__ in, cons
       }
       j = jend;
     }
+    if constexpr (METHOD == OLAP_PRODUCT) {
+      // The plain chain first: prod *= (set ? v : 1).  It IS the reference's result unless a running product hit the
+      // default on the way (then the key drops and the product restarts, in-memory.js:311-318) — and in that case the
+      // plain product ends as 0 (default 0: a zero stays zero) or NaN (NaN default), which is what is tested; only then
+      // is the group walked again through the exact state machine below.  Three instructions a member instead of a dozen.
+      double prod = 1.0;
+      bool any = false;
+      for (uint32_t jj = j; jj < jend; ++jj) {
+        const uint32_t k = MODE == 0 ? l_order[jj] : jj;
+        const T xv = tile[base + k * tl.inner];
+        const int32_t sv = HAS_STATUS ? stile[base + k * tl.inner] : OLAP_STATUS_SET;
+        const bool set = cell_is_set<T>(xv, sv, HAS_STATUS, def_nan);
+        prod *= set ? Cell<T>::to_f64(xv) : 1.0;
+        any = any || set;
+      }
+      if (!any || (prod != 0.0 && prod == prod)) {
+        T ov;
+        int32_t os;
+        emit_cell<T>(prod, any, def_nan, ov, os);
+        reinterpret_cast<T *>(dst)[idx] = ov;
+        if (sdst) sdst[idx] = os;
+        continue;
+      }
+    }
     constexpr int UJ = (MODE == 0 || MODE == 3) ? 8 : 4;  // independent LDS reads in flight (MODE 0: member index, then cell — two dependent reads; MODE 3: long runs, few lanes)
     Vec<T, 1> x[UJ], y[UJ];
     Vec<int32_t, 1> sx[UJ], sy[UJ];
@@ -1269,6 +1293,26 @@ __global__ __launch_bounds__(kBlock) void drillup_gtile_kernel(const Batch<T> b,
         lane.pick[0].cur = xv;
       }
       j = jend;
+    }
+    if constexpr (METHOD == OLAP_PRODUCT) {
+      // (the plain chain first, the exact state machine only when it ends as 0 or NaN: see drillup_tile_body)
+      double prod = 1.0;
+      bool any = false;
+      for (uint32_t jj = j; jj < jend; ++jj) {
+        const T xv = tile[at0 + jj * inner];
+        const int32_t sv = HAS_STATUS ? stile[at0 + jj * inner] : OLAP_STATUS_SET;
+        const bool set = cell_is_set<T>(xv, sv, HAS_STATUS, def_nan);
+        prod *= set ? Cell<T>::to_f64(xv) : 1.0;
+        any = any || set;
+      }
+      if (!any || (prod != 0.0 && prod == prod)) {
+        T ov;
+        int32_t os;
+        emit_cell<T>(prod, any, def_nan, ov, os);
+        dst[idx] = ov;
+        if (sdst) sdst[idx] = os;
+        continue;
+      }
     }
     constexpr int UJ = 4;
     Vec<T, 1> x[UJ];

@@ -707,6 +707,47 @@ def test_tile_regime_long_rows_every_rule(lens, method, type_name, default, monk
     assert same_typed(out.get_data(), ev)  # (half-integers: the re-associated float64 sums are exact)
 
 
+@pytest.mark.parametrize("default", [0.0, float("nan")])
+@pytest.mark.parametrize("lens,groups", [([64, 3], 1), ([2, 6000, 1], 2000), ([5, 9, 4], 3)])
+def test_product_that_hits_the_default_restarts(lens, groups, default):
+    """`product` runs as a plain chain first in the LDS regimes; a running product that equals the default on the way — an
+    underflow to 0 under the 0 default, inf x 0 = NaN under the NaN default — drops the key and restarts with the next
+    member (in-memory.js:311-318): those groups are walked again through the exact state machine.  Against the oracle."""
+    rng = np.random.default_rng(3)
+    axis = 1 if len(lens) > 1 else 0
+    K = lens[axis]
+    n = int(np.prod(lens))
+    vals = rng.choice([2.0, -3.0, 0.5, 7.0], size=n)
+    cube = vals.reshape(lens[0], K, -1)
+    per = K // groups
+    for o in range(cube.shape[0]):
+        for g in range(0, groups, 2):  # every other group: the first two members wipe the running product out
+            k0 = g * per
+            if default == 0.0:
+                cube[o, k0, :] = 1e-200
+                cube[o, k0 + 1, :] = 1e-200
+            else:
+                cube[o, k0, :] = np.inf
+                cube[o, k0 + 1, :] = 0.0
+    dense = cube.ravel().copy()
+    dense[rng.random(n) < 0.1] = default
+    amap = (np.arange(K) // per).astype(np.uint32)
+    new = list(lens)
+    new[axis] = groups
+    maps = [amap if d == axis else np.arange(l, dtype=np.uint32) for d, l in enumerate(lens)]
+    plan = pkg.Plan.drillup("float64", default, "product", lens, new, maps)
+    assert plan.kernel_name in ("drillup_tile_kernel", "drillup_gtile_kernel"), plan.kernel_name
+    o = OracleStore(n, "float64", default)
+    o.set_data(dense)
+    ev, es = expected_typed(o.drill_up(lens, new, maps, "product"))
+    g = pkg.HipStore(n, "float64", default)
+    g.set_data_f64(dense)
+    out = g.drill_up(lens, new, maps, "product")
+    assert np.array_equal(out.get_status(), es)
+    assert same_typed(out.get_data(), ev)
+    assert np.isfinite(ev[es == 2]).mean() > 0.9  # (the wiped-out groups restarted: their products are ordinary numbers)
+
+
 def _boundary_cases():
     """Seeded sample of one-axis drillUps whose extents sit on the boundaries between the kernel
     regimes (vector width, 128 vector slots, the 16 KiB tile, 256-member groups, 131 072 outputs)."""
