@@ -34,8 +34,9 @@ def cases(pkg):
     n_odd = int(np.prod(odd))
     out = []
 
-    def add(name, plan, n_in, n_out, n_read=None, width="16"):
-        out.append(dict(name=name, plan=plan, n_in=n_in, n_out=n_out, alg_bytes=((n_in if n_read is None else n_read) + n_out) * 4, width=width))
+    def add(name, plan, n_in, n_out, n_read=None, width="16", dtype="float32"):
+        elem = 8 if dtype == "float64" else 4
+        out.append(dict(name=name, plan=plan, n_in=n_in, n_out=n_out, alg_bytes=((n_in if n_read is None else n_read) + n_out) * elem, width=width, dtype=dtype))
 
     # calibration: known bytes, one access width each
     add("calib rows 16B/lane [10]^8 dim0->all", P.drillup("float32", 0.0, "sum", [10] * 8, [1] + [10] * 7, [np.zeros(10, np.uint32)] + [ident(10)] * 7), 10 ** 8, 10 ** 7)
@@ -75,6 +76,14 @@ def cases(pkg):
     p7 = list(i8)
     p7[7] = np.array([3, 1, 4, 0, 9, 2, 6, 5, 8, 7], np.int32)
     add("load [10]^8 items of dim7 permuted (rows through LDS)", P.load("float32", 0.0, 0.0, [10] * 8, [10] * 8, p7), 10 ** 8, 10 ** 8)
+    # Float64 cells (Float64 measures; integer measures of the Node host): the forms generalised for them in round 3
+    add("Float64 drillUp [10]^8 dim0->all", P.drillup("float64", 0.0, "sum", [10] * 8, [1] + [10] * 7, [np.zeros(10, np.uint32)] + [ident(10)] * 7), 10 ** 8, 10 ** 7, dtype="float64")
+    add("Float64 drillUp [1e8]->[1] (reduce4, two cells per lane)", P.drillup("float64", 0.0, "sum", [10 ** 8], [1], [np.zeros(10 ** 8, np.uint32)]), 10 ** 8, 1, dtype="float64")
+    month = (np.arange(3652) // 30.4375).astype(np.uint32)
+    add("Float64 drillUp [27400,3652] day innermost -> month (gtile)", P.drillup("float64", 0.0, "sum", [27400, 3652], [27400, int(month.max()) + 1], [ident(27400), month]),
+        27400 * 3652, 27400 * (int(month.max()) + 1), dtype="float64")
+    add("Float64 reorder [10]^8 reversed", P.reorder("float64", 0.0, [10] * 8, list(range(7, -1, -1))), 10 ** 8, 10 ** 8, dtype="float64")
+    add("Float64 reorder 2-D [10^4,10^4]", P.reorder("float64", 0.0, [10000, 10000], [1, 0]), 10 ** 8, 10 ** 8, dtype="float64")
     return out
 
 
@@ -92,9 +101,9 @@ def probe(quiet):
     scratch = eng.empty(2048, "float32")
     meta = []
     for c in cases(pkg):
-        vals = eng.empty(c["n_in"], "float32")
-        pkg.capi.check(L.olap_fill_seeded(vals.data_ptr(), None, c["n_in"], 0, 2, 99, 1.0, eng.stream()))
-        dst = eng.empty(c["n_out"], "float32")
+        vals = eng.empty(c["n_in"], c["dtype"])
+        pkg.capi.check(L.olap_fill_seeded(vals.data_ptr(), None, c["n_in"], 0, 3 if c["dtype"] == "float64" else 2, 99, 1.0, eng.stream()))
+        dst = eng.empty(c["n_out"], c["dtype"])
         args = (vals.data_ptr(), None, dst.data_ptr(), None, eng.stream())
         torch.cuda.synchronize()
         pkg.capi.check(L.olap_diag_read_ceiling(marker.data_ptr(), 4096 * 4, scratch.data_ptr(), eng.stream()))
