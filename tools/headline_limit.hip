@@ -136,6 +136,35 @@ __global__ __launch_bounds__(256) void stripped_persistent_kernel(const float *_
   }
 }
 
+// the workgroup's 4 KB of results leave through LDS from ONE wavefront (4 stores of 16 bytes per lane): three of four
+// wavefronts end without a store of their own in flight
+__global__ __launch_bounds__(256) void stripped_onewave_store_kernel(const float *__restrict__ in, float *__restrict__ out, uint64_t inner, int K) {
+  __shared__ __attribute__((aligned(16))) float res[1024];
+  const uint64_t inner4 = inner / 4;
+  const uint64_t b = xcd_contiguous(blockIdx.x, gridDim.x);
+  const uint64_t i = b * 256 + threadIdx.x;
+  double acc[4] = {0.0, 0.0, 0.0, 0.0};
+  if (i < inner4) {
+    for (int k = 0; k < K; ++k) {
+      const Vec<float, 4> v = load_stream<float, 4>(in + (uint64_t)k * inner + i * 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[e] += (double)v.v[e];
+    }
+  }
+  Vec<float, 4> o;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) o.v[e] = (float)acc[e];
+  *reinterpret_cast<Vec<float, 4> *>(res + threadIdx.x * 4) = o;
+  __syncthreads();
+  if (threadIdx.x < 64) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const uint64_t j = b * 256 + u * 64 + threadIdx.x;
+      if (j < inner4) store_stream<float, 4>(out + j * 4, *reinterpret_cast<const Vec<float, 4> *>(res + (u * 64 + threadIdx.x) * 4));
+    }
+  }
+}
+
 // what bench.py calls the read ceiling: a workgroup reads two 4 KB pieces and ends
 __global__ __launch_bounds__(256) void read_short_kernel(const float *__restrict__ src, uint64_t n_vec, float *scratch) {
   const uint64_t base = (uint64_t)blockIdx.x * 512 + threadIdx.x;
@@ -222,6 +251,7 @@ int main() {
   vs.push_back({"persistent 2048 workgroups, per XCD", [&] { hipLaunchKernelGGL(stripped_persistent_kernel<true>, 2048, 256, 0, 0, in, out, inner, (int)K); }, rd + wr, {}});
   vs.push_back({"persistent 4096 workgroups, per XCD", [&] { hipLaunchKernelGGL(stripped_persistent_kernel<true>, 4096, 256, 0, 0, in, out, inner, (int)K); }, rd + wr, {}});
   vs.push_back({"persistent 1024 workgroups, per XCD", [&] { hipLaunchKernelGGL(stripped_persistent_kernel<true>, 1024, 256, 0, 0, in, out, inner, (int)K); }, rd + wr, {}});
+  vs.push_back({"stripped, one wavefront stores (via LDS)", [&] { hipLaunchKernelGGL(stripped_onewave_store_kernel, grid, 256, 0, 0, in, out, inner, (int)K); }, rd + wr, {}});
   vs.push_back({"stripped, plain stores", [&] { hipLaunchKernelGGL(stripped_kernel<3>, grid, 256, 0, 0, in, out, inner, (int)K, sink); }, rd + wr, {}});
   vs.push_back({"stripped, plain loads", [&] { hipLaunchKernelGGL(stripped_kernel<4>, grid, 256, 0, 0, in, out, inner, (int)K, sink); }, rd + wr, {}});
   vs.push_back({"linear 10:1 (40 KB read, 4 KB written)", [&] { hipLaunchKernelGGL(linear_mix_kernel, grid, 256, 0, 0, in, out, inner, (int)K); }, rd + wr, {}});
