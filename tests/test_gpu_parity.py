@@ -748,6 +748,39 @@ def test_product_that_hits_the_default_restarts(lens, groups, default):
     assert np.isfinite(ev[es == 2]).mean() > 0.9  # (the wiped-out groups restarted: their products are ordinary numbers)
 
 
+@pytest.mark.parametrize("type_name,default,flag", [("float32", 0.0, False), ("int32", 0.0, False), ("float64", float("nan"), True), ("uint32", float("nan"), False)])
+def test_drilldown_plans_are_reused_across_stores(type_name, default, flag):
+    """drillDown plans without distributions are cached by (cell type, default, rule, shapes, maps): three stores with
+    different cells take the same plan one after the other, each against the oracle (the integer remainder rule included,
+    also for a declared-integer measure in float64 cells)."""
+    rng = np.random.default_rng(11)
+    old_len, new_len = [4, 6, 130], [4, 15, 130]
+    child = np.repeat(np.arange(6), [1, 4, 2, 3, 2, 3]).astype(np.uint32)
+    maps = [np.arange(4, dtype=np.uint32), child, np.arange(130, dtype=np.uint32)]
+    n = int(np.prod(old_len))
+    for round_ in range(3):
+        vals = rng.integers(0 if type_name == "uint32" else -50, 200, size=n).astype(np.float64)
+        dense = np.where(rng.random(n) < 0.3, default, vals)
+        declared = "int32" if flag else type_name
+        o = OracleStore(n, declared, default)
+        typed = dense if flag else to_typed(dense, type_name).astype(np.float64)
+        if type_name in ("int32", "uint32") and default != default:
+            typed = np.where(np.isnan(dense), np.nan, typed)
+        o.set_data(typed)
+        g = pkg.HipStore(n, type_name, default)
+        g.set_data_f64(dense)
+        for method in ("sum", "average"):
+            want = o.drill_down(old_len, new_len, maps, method)
+            out = g.drill_down(old_len, new_len, maps, method, integer_measure=flag)
+            if flag:
+                v, present = want.dense()
+                assert np.array_equal(out.get_data_f64(), np.where(present, v, default), equal_nan=True), (round_, method)
+            else:
+                ev, es = expected_typed(want)
+                assert np.array_equal(out.get_status(), es), (round_, method)
+                assert same_typed(out.get_data(), ev), (round_, method)
+
+
 def _boundary_cases():
     """Seeded sample of one-axis drillUps whose extents sit on the boundaries between the kernel
     regimes (vector width, 128 vector slots, the 16 KiB tile, 256-member groups, 131 072 outputs)."""
